@@ -1,0 +1,370 @@
+"""ctypes bindings over lib/libimagecodecs_mi355x.so (see package docstring).
+
+Nothing here computes pixels: every function forwards to the C-ABI.  The library is loaded
+lazily; a missing library raises (no fallback).  Decode calls need a gfx950 GPU and fail with
+the library's own reason ("no gpu device") without one.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libimagecodecs_mi355x.so")
+
+MIJ_FLAG_WIDE_IDCT = 1
+COLOR_NAMES = {0: "grey", 1: "ycbcr", 2: "rgb", 3: "cmyk", 4: "ycck", 5: "ycbcra"}
+
+ROWSLOT = (0, 4, 2, 5, 1, 6, 3, 7)  # include/mij.h mij_rowslot
+
+
+class MijError(RuntimeError):
+    pass
+
+
+class CompDesc(C.Structure):
+    _fields_ = [("h", C.c_int32), ("v", C.c_int32), ("tq", C.c_int32), ("x", C.c_int32), ("y", C.c_int32),
+                ("bw", C.c_int32), ("bh", C.c_int32)]
+
+
+class ImageDesc(C.Structure):
+    """mij_image_desc (include/mij.h)."""
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("ncomp", C.c_int32), ("n_out", C.c_int32),
+                ("color", C.c_int32), ("flags", C.c_uint32), ("h_max", C.c_int32), ("v_max", C.c_int32),
+                ("mcu_x", C.c_int32), ("mcu_y", C.c_int32), ("comp", CompDesc * 4),
+                ("dequant", (C.c_uint16 * 64) * 4)]
+
+    def plane_elems(self, c):
+        nblk = self.comp[c].bw * self.comp[c].bh
+        return ((nblk + 63) >> 6) << 12
+
+    def coef_elems(self):
+        return sum(self.plane_elems(c) for c in range(self.ncomp))
+
+
+_lib = None
+
+
+def build_library(force=False):
+    """Compile the HIP/C sources in csrc/ for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.run(["make", "-C", os.path.join(_HERE, "csrc")] + (["-B"] if force else []), check=True)
+    return LIB_PATH
+
+
+def lib():
+    """The loaded shared library (raises if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MijError("%s is missing: run `python __graft_entry__.py` (build()) or `make -C image-codecs_amd/csrc`" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    p_int = C.POINTER(C.c_int)
+    L.stbi_load_from_memory.restype = C.POINTER(C.c_ubyte)
+    L.stbi_load_from_memory.argtypes = [C.c_char_p, C.c_int, p_int, p_int, p_int, C.c_int]
+    L.stbi_load.restype = C.POINTER(C.c_ubyte)
+    L.stbi_load.argtypes = [C.c_char_p, p_int, p_int, p_int, C.c_int]
+    L.stbi_load_16_from_memory.restype = C.POINTER(C.c_ushort)
+    L.stbi_load_16_from_memory.argtypes = [C.c_char_p, C.c_int, p_int, p_int, p_int, C.c_int]
+    L.stbi_info_from_memory.restype = C.c_int
+    L.stbi_info_from_memory.argtypes = [C.c_char_p, C.c_int, p_int, p_int, p_int]
+    L.stbi_failure_reason.restype = C.c_char_p
+    L.stbi_image_free.argtypes = [C.c_void_p]
+    L.stbi_set_flip_vertically_on_load.argtypes = [C.c_int]
+    L.stbi_write_jpg_to_func.restype = C.c_int
+    L.mij_last_error.restype = C.c_char_p
+    L.mij_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.mij_ctx_destroy.argtypes = [C.c_void_p]
+    L.mij_ctx_info.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, p_int, C.POINTER(C.c_size_t)]
+    L.mij_batch_create.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p)]
+    L.mij_batch_destroy.argtypes = [C.c_void_p]
+    L.mij_batch_reset.argtypes = [C.c_void_p]
+    L.mij_image_coef_bytes.restype = C.c_size_t
+    L.mij_image_coef_bytes.argtypes = [C.POINTER(ImageDesc)]
+    L.mij_image_out_bytes.restype = C.c_size_t
+    L.mij_image_out_bytes.argtypes = [C.POINTER(ImageDesc)]
+    L.mij_batch_add.argtypes = [C.c_void_p, C.POINTER(ImageDesc)]
+    L.mij_batch_add_clone.argtypes = [C.c_void_p, C.c_int]
+    L.mij_batch_coef.restype = C.c_void_p
+    L.mij_batch_coef.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.mij_batch_set_flags.argtypes = [C.c_void_p, C.c_int, C.c_uint32]
+    for name in ("mij_batch_upload", "mij_batch_launch", "mij_batch_submit", "mij_batch_wait", "mij_batch_timer_begin",
+                 "mij_batch_timer_end", "mij_batch_image_count"):
+        getattr(L, name).argtypes = [C.c_void_p]
+    L.mij_batch_fetch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    L.mij_batch_device_out.restype = C.c_void_p
+    L.mij_batch_device_out.argtypes = [C.c_void_p, C.c_int]
+    L.mij_batch_timer_elapsed_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    L.mij_batch_hash_out.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
+    L.mij_batch_slot_path.argtypes = [C.c_void_p, C.c_int]
+    L.mij_batch_force_generic.argtypes = [C.c_void_p, C.c_int]
+    L.mjh_probe_memory.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(ImageDesc), C.POINTER(C.c_char_p)]
+    L.mjh_decode_memory.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(ImageDesc), C.c_void_p, C.c_size_t,
+                                    C.POINTER(C.c_char_p)]
+    _lib = L
+    return L
+
+
+def gpu_available():
+    """True when the library sees at least one HIP device (no torch involved)."""
+    try:
+        return lib().mij_device_count() > 0
+    except (MijError, OSError):
+        return False
+
+
+# ---------------------------------------------------------------- stb-style surface
+
+def stbi_failure_reason():
+    r = lib().stbi_failure_reason()
+    return r.decode() if r else None
+
+
+def stbi_set_flip_vertically_on_load(flag):
+    lib().stbi_set_flip_vertically_on_load(int(flag))
+
+
+def _take(ptr, shape, dtype):
+    n = int(np.prod(shape))
+    arr = np.ctypeslib.as_array(ptr, shape=(n,)).view(dtype).reshape(shape).copy()
+    lib().stbi_image_free(ptr)
+    return arr
+
+
+def stbi_load_from_memory(data, req_comp=0):
+    """-> (pixels[h, w, n] uint8, w, h, comp_in_file) or None (see stbi_failure_reason())."""
+    x, y, c = C.c_int(), C.c_int(), C.c_int()
+    p = lib().stbi_load_from_memory(bytes(data), len(data), C.byref(x), C.byref(y), C.byref(c), int(req_comp))
+    if not p:
+        return None
+    n = req_comp if req_comp else c.value
+    return _take(p, (y.value, x.value, n), np.uint8), x.value, y.value, c.value
+
+
+def stbi_load(filename, req_comp=0):
+    x, y, c = C.c_int(), C.c_int(), C.c_int()
+    p = lib().stbi_load(os.fsencode(filename), C.byref(x), C.byref(y), C.byref(c), int(req_comp))
+    if not p:
+        return None
+    n = req_comp if req_comp else c.value
+    return _take(p, (y.value, x.value, n), np.uint8), x.value, y.value, c.value
+
+
+def stbi_load_16_from_memory(data, req_comp=0):
+    x, y, c = C.c_int(), C.c_int(), C.c_int()
+    p = lib().stbi_load_16_from_memory(bytes(data), len(data), C.byref(x), C.byref(y), C.byref(c), int(req_comp))
+    if not p:
+        return None
+    n = req_comp if req_comp else c.value
+    cnt = y.value * x.value * n
+    arr = np.ctypeslib.as_array(p, shape=(cnt,)).astype(np.uint16).reshape(y.value, x.value, n).copy()
+    lib().stbi_image_free(p)
+    return arr, x.value, y.value, c.value
+
+
+def stbi_info_from_memory(data):
+    """-> (ok, w, h, comp)"""
+    x, y, c = C.c_int(), C.c_int(), C.c_int()
+    ok = lib().stbi_info_from_memory(bytes(data), len(data), C.byref(x), C.byref(y), C.byref(c))
+    return ok, x.value, y.value, c.value
+
+
+_WRITE_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int)
+
+
+def stbi_write_jpg_to_memory(pixels, quality=90):
+    """stbi_write_jpg_to_func into a bytes object.  pixels: uint8 [h, w, comp] (comp 1..4) or [h, w]."""
+    a = np.ascontiguousarray(pixels, dtype=np.uint8)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    h, w, comp = a.shape
+    chunks = []
+
+    def sink(_ctx, data, size):
+        chunks.append(C.string_at(data, size))
+
+    cb = _WRITE_CB(sink)
+    ok = lib().stbi_write_jpg_to_func(cb, None, C.c_int(w), C.c_int(h), C.c_int(comp), a.ctypes.data_as(C.c_void_p), C.c_int(int(quality)))
+    if not ok:
+        return None
+    return b"".join(chunks)
+
+
+# ---------------------------------------------------------------- host entropy stage
+
+class HostDecoder:
+    """mjh_probe_memory / mjh_decode_memory: marker parse + Huffman walk into tile-layout planes."""
+
+    @staticmethod
+    def probe(data, req_comp=0):
+        d = ImageDesc()
+        why = C.c_char_p()
+        ok = lib().mjh_probe_memory(bytes(data), len(data), int(req_comp), C.byref(d), C.byref(why))
+        if not ok:
+            raise MijError(why.value.decode() if why.value else "decode failed")
+        return d
+
+    @staticmethod
+    def decode(data, req_comp=0, out=None):
+        """-> (desc, arena int16[coef_elems]) ; `out` may be a preallocated int16 array (e.g. a view of pinned staging)."""
+        d = HostDecoder.probe(data, req_comp)
+        n = d.coef_elems()
+        arena = out if out is not None else np.empty(n, dtype=np.int16)
+        if arena.size < n:
+            raise MijError("arena too small")
+        why = C.c_char_p()
+        ok = lib().mjh_decode_memory(bytes(data), len(data), int(req_comp), C.byref(d), arena.ctypes.data_as(C.c_void_p),
+                                     C.c_size_t(arena.size), C.byref(why))
+        if not ok:
+            raise MijError(why.value.decode() if why.value else "decode failed")
+        return d, arena
+
+
+def detile_coefficients(desc, arena):
+    """Tile layout -> list of per-component arrays [bh, bw, 8, 8] (natural row, col order), for tests."""
+    out = []
+    off = 0
+    pos = np.empty((8, 8), dtype=np.int64)  # [row, col] -> P
+    for r in range(8):
+        for c in range(8):
+            pos[r, c] = 8 * c + ROWSLOT[r]
+    for ci in range(desc.ncomp):
+        bw, bh = desc.comp[ci].bw, desc.comp[ci].bh
+        n = desc.plane_elems(ci)
+        plane = np.asarray(arena[off:off + n]).reshape(-1, 8, 64, 8)  # [tile, chunk, lane, j]
+        off += n
+        L = np.arange(bw * bh)
+        blk = plane[L >> 6, :, L & 63, :]  # [nblk, chunk, j]
+        flat = blk.reshape(-1, 64)  # index P = 8*chunk + j
+        nat = flat[:, pos.reshape(-1)].reshape(bh, bw, 8, 8)
+        out.append(nat)
+    return out
+
+
+# ---------------------------------------------------------------- GPU back end
+
+def _check(rc, what):
+    if rc < 0:
+        raise MijError("%s: %s" % (what, lib().mij_last_error().decode()))
+    return rc
+
+
+class Context:
+    """mij_ctx: one per (process, device)."""
+
+    def __init__(self, device=-1):
+        self._h = C.c_void_p()
+        _check(lib().mij_ctx_create(int(device), C.byref(self._h)), "mij_ctx_create")
+
+    def info(self):
+        arch = C.create_string_buffer(64)
+        cu = C.c_int()
+        mem = C.c_size_t()
+        _check(lib().mij_ctx_info(self._h, arch, 64, C.byref(cu), C.byref(mem)), "mij_ctx_info")
+        return arch.value.decode(), cu.value, mem.value
+
+    def close(self):
+        if self._h:
+            lib().mij_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+class Batch:
+    """mij_batch: staging + device arenas + stream.  Thin, order-preserving wrapper."""
+
+    def __init__(self, ctx, max_images, stage_bytes, coef_bytes, out_bytes):
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        _check(lib().mij_batch_create(ctx._h, int(max_images), C.c_size_t(stage_bytes), C.c_size_t(coef_bytes), C.c_size_t(out_bytes),
+                                      C.byref(self._h)), "mij_batch_create")
+        self.descs = []
+
+    @staticmethod
+    def coef_bytes(desc):
+        return lib().mij_image_coef_bytes(C.byref(desc))
+
+    @staticmethod
+    def out_bytes(desc):
+        return lib().mij_image_out_bytes(C.byref(desc))
+
+    def add(self, desc):
+        slot = _check(lib().mij_batch_add(self._h, C.byref(desc)), "mij_batch_add")
+        self.descs.append(desc)
+        return slot
+
+    def add_clone(self, src):
+        slot = _check(lib().mij_batch_add_clone(self._h, int(src)), "mij_batch_add_clone")
+        self.descs.append(self.descs[src])
+        return slot
+
+    def staging(self, slot):
+        """int16 numpy view over the slot's pinned planes (all components, back to back)."""
+        d = self.descs[slot]
+        p = lib().mij_batch_coef(self._h, int(slot), 0)
+        if not p:
+            raise MijError("mij_batch_coef: %s" % lib().mij_last_error().decode())
+        n = d.coef_elems()
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int16)), shape=(n,))
+
+    def add_jpeg(self, data, req_comp=0):
+        """Host stage of one image straight into a new slot's pinned staging; returns the slot."""
+        d = HostDecoder.probe(data, req_comp)
+        slot = self.add(d)
+        d2, _ = HostDecoder.decode(data, req_comp, out=self.staging(slot))
+        if d2.flags:
+            _check(lib().mij_batch_set_flags(self._h, slot, d2.flags), "mij_batch_set_flags")
+        return slot
+
+    def set_flags(self, slot, flags):
+        _check(lib().mij_batch_set_flags(self._h, int(slot), int(flags)), "mij_batch_set_flags")
+
+    def force_generic(self, on=True):
+        _check(lib().mij_batch_force_generic(self._h, int(bool(on))), "mij_batch_force_generic")
+
+    def upload(self):
+        _check(lib().mij_batch_upload(self._h), "mij_batch_upload")
+
+    def launch(self):
+        _check(lib().mij_batch_launch(self._h), "mij_batch_launch")
+
+    def submit(self):
+        _check(lib().mij_batch_submit(self._h), "mij_batch_submit")
+
+    def wait(self):
+        _check(lib().mij_batch_wait(self._h), "mij_batch_wait")
+
+    def fetch(self, slot):
+        d = self.descs[slot]
+        out = np.empty((d.height, d.width, d.n_out), dtype=np.uint8)
+        _check(lib().mij_batch_fetch(self._h, int(slot), out.ctypes.data_as(C.c_void_p), C.c_size_t(out.size)), "mij_batch_fetch")
+        return out
+
+    def hash_out(self, slot):
+        h = C.c_uint64()
+        _check(lib().mij_batch_hash_out(self._h, int(slot), C.byref(h)), "mij_batch_hash_out")
+        return h.value
+
+    def slot_path(self, slot):
+        return lib().mij_batch_slot_path(self._h, int(slot))
+
+    def timer_begin(self):
+        _check(lib().mij_batch_timer_begin(self._h), "mij_batch_timer_begin")
+
+    def timer_end(self):
+        _check(lib().mij_batch_timer_end(self._h), "mij_batch_timer_end")
+
+    def timer_ms(self):
+        ms = C.c_float()
+        _check(lib().mij_batch_timer_elapsed_ms(self._h, C.byref(ms)), "mij_batch_timer_elapsed_ms")
+        return ms.value
+
+    def reset(self):
+        _check(lib().mij_batch_reset(self._h), "mij_batch_reset")
+        self.descs = []
+
+    def close(self):
+        if self._h:
+            lib().mij_batch_destroy(self._h)
+            self._h = C.c_void_p()

@@ -1,0 +1,443 @@
+/*
+ * image_api.c -- the stb-compatible load / info surface of include/image_api.h on top of the
+ * host entropy decoder (jpeg_entropy.c) and the GPU back end (mij.h).
+ *
+ * Mirrors, for JPEG only, the reference's dispatch and post-processing:
+ *   stbi__load_main                     image_api.c:3-56    (type test, then load)
+ *   stbi__load_and_postprocess_8bit/16  convert.c:78-133    (8<->16 conversion, vertical flip)
+ *   stbi_load* / stbi_info* / is_16_bit / is_hdr            convert.c:188-266,345-398 image_api.c:74-145
+ *   load_jpeg_image's argument checks and outputs           codec/jpeg.c:2224-2249,2293,2433-2438
+ * The pixel work itself (IDCT, upsample, colour) runs on the GPU; there is no CPU fallback.
+ */
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "image_api.h"
+#include "jpeg_entropy.h"
+#include "mij.h"
+
+static __thread const char *t_reason = NULL;
+static int g_flip_on_load = 0; /* process-global like the reference's stbi__vertically_flip_on_load */
+
+const char *stbi_failure_reason(void) { return t_reason; }
+void stbi_image_free(void *p) { free(p); }
+void stbi_set_flip_vertically_on_load(int flag) { g_flip_on_load = flag; }
+
+static unsigned char *fail_ptr(const char *why)
+{
+	t_reason = why;
+	return NULL;
+}
+static int fail_int(const char *why)
+{
+	t_reason = why;
+	return 0;
+}
+
+/* ------------------------------------------------------------------ per-thread GPU batch cache */
+
+static pthread_mutex_t g_ctx_lock = PTHREAD_MUTEX_INITIALIZER;
+static mij_ctx *g_ctx = NULL;
+static int g_ctx_failed = 0;
+
+static mij_ctx *shared_ctx(void)
+{
+	mij_ctx *c;
+	pthread_mutex_lock(&g_ctx_lock);
+	if (!g_ctx && !g_ctx_failed) {
+		const char *env = getenv("MIJ_DEVICE");
+		int dev = env ? atoi(env) : -1;
+		if (mij_ctx_create(dev, &g_ctx) != MIJ_OK) {
+			g_ctx = NULL;
+			g_ctx_failed = 1;
+		}
+	}
+	c = g_ctx;
+	pthread_mutex_unlock(&g_ctx_lock);
+	return c;
+}
+
+typedef struct {
+	mij_batch *b;
+	size_t coef_cap, out_cap;
+} tl_batch;
+
+static __thread tl_batch t_batch = {NULL, 0, 0};
+static pthread_key_t g_batch_key;
+static pthread_once_t g_batch_key_once = PTHREAD_ONCE_INIT;
+
+static void batch_key_dtor(void *p)
+{
+	if (p)
+		mij_batch_destroy((mij_batch *)p);
+}
+static void batch_key_init(void) { pthread_key_create(&g_batch_key, batch_key_dtor); }
+
+/* a one-image batch big enough for `d`, grown geometrically and reused across calls */
+static mij_batch *thread_batch(mij_ctx *ctx, const mij_image_desc *d)
+{
+	size_t cb = mij_image_coef_bytes(d), ob = mij_image_out_bytes(d);
+	if (t_batch.b && cb <= t_batch.coef_cap && ob <= t_batch.out_cap) {
+		if (mij_batch_reset(t_batch.b) != MIJ_OK)
+			return NULL;
+		return t_batch.b;
+	}
+	if (t_batch.b) {
+		mij_batch_destroy(t_batch.b);
+		t_batch.b = NULL;
+		t_batch.coef_cap = t_batch.out_cap = 0;
+	}
+	{
+		size_t ccap = cb + cb / 4 + 4096, ocap = ob + ob / 4 + 4096;
+		mij_batch *b = NULL;
+		if (mij_batch_create(ctx, 1, ccap, ccap, ocap, &b) != MIJ_OK) {
+			/* retry without slack before giving up */
+			if (mij_batch_create(ctx, 1, cb, cb, ob, &b) != MIJ_OK)
+				return NULL;
+			ccap = cb;
+			ocap = ob;
+		}
+		t_batch.b = b;
+		t_batch.coef_cap = ccap;
+		t_batch.out_cap = ocap;
+		pthread_once(&g_batch_key_once, batch_key_init);
+		pthread_setspecific(g_batch_key, b);
+	}
+	return t_batch.b;
+}
+
+/* ------------------------------------------------------------------ load */
+
+/* convert.c:37-61 */
+static void vertical_flip(void *image, int w, int h, int bytes_per_pixel)
+{
+	size_t row_bytes = (size_t)w * (size_t)bytes_per_pixel;
+	unsigned char *bytes = (unsigned char *)image, tmp[2048];
+	int row;
+	for (row = 0; row < (h >> 1); ++row) {
+		unsigned char *a = bytes + (size_t)row * row_bytes, *b = bytes + (size_t)(h - row - 1) * row_bytes;
+		size_t left = row_bytes;
+		while (left) {
+			size_t n = left < sizeof(tmp) ? left : sizeof(tmp);
+			memcpy(tmp, a, n);
+			memcpy(a, b, n);
+			memcpy(b, tmp, n);
+			a += n;
+			b += n;
+			left -= n;
+		}
+	}
+}
+
+/* stbi__load_main (image_api.c:3-56) + stbi__jpeg_load / load_jpeg_image (codec/jpeg.c:2224-2452) */
+static unsigned char *load_main(mjh_reader *r, int *x, int *y, int *comp, int req_comp)
+{
+	mjh_decoder *d;
+	mij_image_desc desc;
+	mij_ctx *ctx;
+	mij_batch *b;
+	unsigned char *pixels = NULL;
+	int slot, i;
+	size_t nbytes;
+
+	d = (mjh_decoder *)calloc(1, sizeof(*d));
+	if (!d)
+		return fail_ptr("outofmem");
+
+	/* stbi__jpeg_test: SOI present?  (every other codec of the reference is out of scope) */
+	if (!mjh_decode_header(d, r, MJH_SCAN_TYPE)) {
+		mjh_reader_rewind(r);
+		free(d);
+		return fail_ptr("unknown image type");
+	}
+	mjh_reader_rewind(r);
+
+	if (req_comp < 0 || req_comp > 4) {
+		free(d);
+		return fail_ptr("bad req_comp");
+	}
+	if (!mjh_decode_header(d, r, MJH_SCAN_LOAD)) {
+		const char *why = d->reason;
+		free(d);
+		return fail_ptr(why);
+	}
+	if (!mjh_describe(d, req_comp, &desc)) {
+		free(d);
+		return fail_ptr("bad req_comp");
+	}
+
+	ctx = shared_ctx();
+	if (!ctx) {
+		free(d);
+		return fail_ptr("no gpu device");
+	}
+	b = thread_batch(ctx, &desc);
+	if (!b) {
+		free(d);
+		return fail_ptr("outofmem");
+	}
+	slot = mij_batch_add(b, &desc);
+	if (slot < 0) {
+		free(d);
+		return fail_ptr("outofmem");
+	}
+	for (i = 0; i < desc.ncomp; ++i)
+		d->comp[i].plane = mij_batch_coef(b, slot, i);
+
+	if (!mjh_decode_scans(d)) {
+		const char *why = d->reason;
+		free(d);
+		return fail_ptr(why);
+	}
+	if (mjh_needs_wide_idct(d))
+		mij_batch_set_flags(b, slot, MIJ_FLAG_WIDE_IDCT);
+
+	/* codec/jpeg.c:2293: n * x * y + 1 bytes */
+	nbytes = (size_t)desc.n_out * (size_t)desc.width * (size_t)desc.height;
+	if (nbytes > 0x7fffffffu - 1) {
+		free(d);
+		return fail_ptr("outofmem");
+	}
+	pixels = (unsigned char *)malloc(nbytes + 1);
+	if (!pixels) {
+		free(d);
+		return fail_ptr("outofmem");
+	}
+	if (mij_batch_submit(b) != MIJ_OK || mij_batch_fetch(b, slot, pixels, nbytes) != MIJ_OK) {
+		free(pixels);
+		free(d);
+		return fail_ptr("gpu decode failed");
+	}
+	*x = desc.width;
+	*y = desc.height;
+	if (comp)
+		*comp = d->img_n >= 3 ? 3 : 1;
+	free(d);
+	return pixels;
+}
+
+/* convert.c:78-104 */
+static unsigned char *load_and_postprocess_8bit(mjh_reader *r, int *x, int *y, int *comp, int req_comp)
+{
+	int file_comp = 0;
+	unsigned char *result = load_main(r, x, y, &file_comp, req_comp);
+	if (!result)
+		return NULL;
+	if (comp)
+		*comp = file_comp;
+	if (g_flip_on_load) {
+		int channels = req_comp ? req_comp : file_comp;
+		vertical_flip(result, *x, *y, channels);
+	}
+	return result;
+}
+
+/* convert.c:106-133 with stbi__convert_8_to_16 (convert.c:18-33) */
+static stbi_us *load_and_postprocess_16bit(mjh_reader *r, int *x, int *y, int *comp, int req_comp)
+{
+	int file_comp = 0, channels, n, i;
+	stbi_us *wide;
+	unsigned char *result = load_main(r, x, y, &file_comp, req_comp);
+	if (!result)
+		return NULL;
+	if (comp)
+		*comp = file_comp;
+	channels = req_comp == 0 ? file_comp : req_comp;
+	n = *x * *y * channels;
+	wide = (stbi_us *)malloc((size_t)n * 2);
+	if (!wide) {
+		free(result);
+		return (stbi_us *)fail_ptr("outofmem");
+	}
+	for (i = 0; i < n; ++i)
+		wide[i] = (stbi_us)((result[i] << 8) + result[i]);
+	free(result);
+	if (g_flip_on_load)
+		vertical_flip(wide, *x, *y, channels * (int)sizeof(stbi_us));
+	return wide;
+}
+
+stbi_uc *stbi_load_from_memory(stbi_uc const *buffer, int len, int *x, int *y, int *comp, int req_comp)
+{
+	mjh_reader r;
+	mjh_reader_mem(&r, buffer, len);
+	return load_and_postprocess_8bit(&r, x, y, comp, req_comp);
+}
+
+stbi_uc *stbi_load_from_callbacks(stbi_io_callbacks const *clbk, void *user, int *x, int *y, int *comp, int req_comp)
+{
+	mjh_reader r;
+	mjh_reader_callbacks(&r, clbk, user);
+	return load_and_postprocess_8bit(&r, x, y, comp, req_comp);
+}
+
+stbi_uc *stbi_load_from_file(FILE *f, int *x, int *y, int *comp, int req_comp)
+{
+	mjh_reader r;
+	unsigned char *result;
+	mjh_reader_file(&r, f);
+	result = load_and_postprocess_8bit(&r, x, y, comp, req_comp);
+	if (result)
+		fseek(f, -(long)mjh_reader_unread(&r), SEEK_CUR); /* convert.c:208 */
+	return result;
+}
+
+stbi_uc *stbi_load(char const *filename, int *x, int *y, int *comp, int req_comp)
+{
+	FILE *f = fopen(filename, "rb");
+	unsigned char *result;
+	if (!f)
+		return fail_ptr("can't fopen");
+	result = stbi_load_from_file(f, x, y, comp, req_comp);
+	fclose(f);
+	return result;
+}
+
+stbi_us *stbi_load_16_from_memory(stbi_uc const *buffer, int len, int *x, int *y, int *comp, int req_comp)
+{
+	mjh_reader r;
+	mjh_reader_mem(&r, buffer, len);
+	return load_and_postprocess_16bit(&r, x, y, comp, req_comp);
+}
+
+stbi_us *stbi_load_16_from_callbacks(stbi_io_callbacks const *clbk, void *user, int *x, int *y, int *comp, int req_comp)
+{
+	mjh_reader r;
+	mjh_reader_callbacks(&r, clbk, user);
+	return load_and_postprocess_16bit(&r, x, y, comp, req_comp);
+}
+
+stbi_us *stbi_load_from_file_16(FILE *f, int *x, int *y, int *comp, int req_comp)
+{
+	mjh_reader r;
+	stbi_us *result;
+	mjh_reader_file(&r, f);
+	result = load_and_postprocess_16bit(&r, x, y, comp, req_comp);
+	if (result)
+		fseek(f, -(long)mjh_reader_unread(&r), SEEK_CUR);
+	return result;
+}
+
+stbi_us *stbi_load_16(char const *filename, int *x, int *y, int *comp, int req_comp)
+{
+	FILE *f = fopen(filename, "rb");
+	stbi_us *result;
+	if (!f)
+		return (stbi_us *)fail_ptr("can't fopen");
+	result = stbi_load_from_file_16(f, x, y, comp, req_comp);
+	fclose(f);
+	return result;
+}
+
+/* ------------------------------------------------------------------ info (host only) */
+
+/* stbi__info_main -> stbi__jpeg_info (codec/jpeg.c:2466-2490) */
+static int info_main(mjh_reader *r, int *x, int *y, int *comp)
+{
+	mjh_decoder *d = (mjh_decoder *)calloc(1, sizeof(*d));
+	int ok;
+	if (!d)
+		return fail_int("outofmem");
+	ok = mjh_decode_header(d, r, MJH_SCAN_HEADER);
+	if (!ok) {
+		mjh_reader_rewind(r);
+		free(d);
+		return fail_int("unknown image type");
+	}
+	if (x)
+		*x = d->img_x;
+	if (y)
+		*y = d->img_y;
+	if (comp)
+		*comp = d->img_n >= 3 ? 3 : 1;
+	free(d);
+	return 1;
+}
+
+int stbi_info_from_memory(stbi_uc const *buffer, int len, int *x, int *y, int *comp)
+{
+	mjh_reader r;
+	mjh_reader_mem(&r, buffer, len);
+	return info_main(&r, x, y, comp);
+}
+
+int stbi_info_from_callbacks(stbi_io_callbacks const *clbk, void *user, int *x, int *y, int *comp)
+{
+	mjh_reader r;
+	mjh_reader_callbacks(&r, clbk, user);
+	return info_main(&r, x, y, comp);
+}
+
+int stbi_info_from_file(FILE *f, int *x, int *y, int *comp)
+{
+	mjh_reader r;
+	long pos = ftell(f);
+	int ok;
+	mjh_reader_file(&r, f);
+	ok = info_main(&r, x, y, comp);
+	fseek(f, pos, SEEK_SET);
+	return ok;
+}
+
+int stbi_info(char const *filename, int *x, int *y, int *comp)
+{
+	FILE *f = fopen(filename, "rb");
+	int ok;
+	if (!f)
+		return fail_int("can't fopen");
+	ok = stbi_info_from_file(f, x, y, comp);
+	fclose(f);
+	return ok;
+}
+
+/* JPEG is never 16-bit (image_api.c:58-71 only asks PNG and PSD) and never HDR */
+int stbi_is_16_bit_from_memory(stbi_uc const *buffer, int len)
+{
+	(void)buffer;
+	(void)len;
+	return 0;
+}
+int stbi_is_16_bit_from_callbacks(stbi_io_callbacks const *clbk, void *user)
+{
+	(void)clbk;
+	(void)user;
+	return 0;
+}
+int stbi_is_16_bit_from_file(FILE *f)
+{
+	(void)f;
+	return 0;
+}
+int stbi_is_16_bit(char const *filename)
+{
+	FILE *f = fopen(filename, "rb");
+	if (!f)
+		return fail_int("can't fopen");
+	fclose(f);
+	return 0;
+}
+int stbi_is_hdr_from_memory(stbi_uc const *buffer, int len)
+{
+	(void)buffer;
+	(void)len;
+	return 0;
+}
+int stbi_is_hdr_from_callbacks(stbi_io_callbacks const *clbk, void *user)
+{
+	(void)clbk;
+	(void)user;
+	return 0;
+}
+int stbi_is_hdr_from_file(FILE *f)
+{
+	(void)f;
+	return 0;
+}
+int stbi_is_hdr(char const *filename)
+{
+	FILE *f = fopen(filename, "rb");
+	if (f)
+		fclose(f);
+	return 0;
+}

@@ -1,0 +1,1146 @@
+/*
+ * jpeg_entropy.c -- host half of the JPEG decode path: byte source, marker parsing, Huffman
+ * tables and the sequential entropy-coded-segment walk (baseline + progressive).
+ *
+ * Behaviour follows /root/reference/codec/jpeg.c (line numbers cited per function); the code
+ * is written for this project: decoded coefficients are NOT de-quantised or inverse
+ * transformed here, they are stored as int16 in the GPU staging planes of mij.h (tile layout).
+ * The bit reader keeps the reference's exact state machine (32-bit buffer, refill to >24 bits,
+ * zero feed after a marker) because the observable behaviour on truncated, padded and
+ * restart-marker streams depends on it.
+ */
+#include "jpeg_entropy.h"
+
+#include <limits.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ byte source */
+
+void mjh_reader_mem(mjh_reader *r, const uint8_t *data, int len)
+{
+	memset(&r->io, 0, sizeof(r->io));
+	r->user = NULL;
+	r->from_callbacks = 0;
+	r->already_read = 0;
+	r->buflen = 0;
+	r->p = r->orig = data;
+	r->end = r->orig_end = data + len;
+}
+
+/* common.c:10-28 */
+static void reader_refill(mjh_reader *r)
+{
+	int n = r->io.read(r->user, (char *)r->buf, r->buflen);
+	r->already_read += (int)(r->p - r->orig);
+	if (n == 0) {
+		/* end of file: behave like a memory source that holds one 0 byte */
+		r->from_callbacks = 0;
+		r->buf[0] = 0;
+		r->p = r->buf;
+		r->end = r->buf + 1;
+	} else {
+		r->p = r->buf;
+		r->end = r->buf + n;
+	}
+}
+
+void mjh_reader_callbacks(mjh_reader *r, const stbi_io_callbacks *io, void *user)
+{
+	r->io = *io;
+	r->user = user;
+	r->buflen = (int)sizeof(r->buf);
+	r->from_callbacks = 1;
+	r->already_read = 0;
+	r->p = r->orig = r->buf;
+	reader_refill(r);
+	r->orig_end = r->end;
+}
+
+static int file_read(void *user, char *data, int size) { return (int)fread(data, 1, (size_t)size, (FILE *)user); }
+static void file_skip(void *user, int n)
+{
+	int ch;
+	fseek((FILE *)user, n, SEEK_CUR);
+	ch = fgetc((FILE *)user); /* make feof() meaningful right after the seek */
+	if (ch != EOF)
+		ungetc(ch, (FILE *)user);
+}
+static int file_eof(void *user) { return feof((FILE *)user) || ferror((FILE *)user); }
+
+void mjh_reader_file(mjh_reader *r, FILE *f)
+{
+	stbi_io_callbacks io;
+	io.read = file_read;
+	io.skip = file_skip;
+	io.eof = file_eof;
+	mjh_reader_callbacks(r, &io, (void *)f);
+}
+
+void mjh_reader_rewind(mjh_reader *r)
+{
+	r->p = r->orig;
+	r->end = r->orig_end;
+}
+
+long mjh_reader_unread(const mjh_reader *r) { return (long)(r->end - r->p); }
+
+/* common.c:30-40 */
+static inline unsigned rd8(mjh_reader *r)
+{
+	if (r->p < r->end)
+		return *r->p++;
+	if (r->from_callbacks) {
+		reader_refill(r);
+		return *r->p++;
+	}
+	return 0;
+}
+
+/* common.c:45-58 */
+static int rd_eof(mjh_reader *r)
+{
+	if (r->io.read) {
+		if (!r->io.eof(r->user))
+			return 0;
+		if (r->from_callbacks == 0)
+			return 1;
+	}
+	return r->p >= r->end;
+}
+
+/* common.c:64-84 */
+static void rd_skip(mjh_reader *r, int n)
+{
+	if (n == 0)
+		return;
+	if (n < 0) {
+		r->p = r->end;
+		return;
+	}
+	if (r->io.read) {
+		int have = (int)(r->end - r->p);
+		if (have < n) {
+			r->p = r->end;
+			r->io.skip(r->user, n - have);
+			return;
+		}
+	}
+	/* a memory source may step past its end: every later read then yields 0 */
+	if ((long)(r->end - r->p) < (long)n)
+		r->p = r->end;
+	else
+		r->p += n;
+}
+
+static int rd16be(mjh_reader *r)
+{
+	int hi = (int)rd8(r);
+	return (hi << 8) + (int)rd8(r);
+}
+
+/* ------------------------------------------------------------------ tables */
+
+static int fail(mjh_decoder *d, const char *why)
+{
+	d->reason = why;
+	return 0;
+}
+
+/* zigzag index -> natural index, with the reference's 15 spill entries (codec/jpeg.c:293-305) */
+static const uint8_t k_dezigzag[64 + 15] = {
+	0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5,
+	12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+	35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
+	58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63,
+	63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63};
+
+/* zigzag index -> int16 offset inside the block's tile slot: (P>>3)*512 + (P&7) */
+static uint16_t k_tile_off[64 + 15];
+static int k_tile_off_ready;
+
+static void init_tile_off(void)
+{
+	int k;
+	if (k_tile_off_ready)
+		return;
+	for (k = 0; k < 64 + 15; ++k) {
+		int nat = k_dezigzag[k];
+		int P = 8 * (nat & 7) + mij_rowslot[nat >> 3];
+		k_tile_off[k] = (uint16_t)(((P >> 3) << 9) + (P & 7));
+	}
+	k_tile_off_ready = 1;
+}
+
+static inline size_t block_base(int L) { return ((size_t)(L >> 6) << 12) + ((size_t)(L & 63) << 3); }
+
+/* codec/jpeg.c:88-134 */
+static int build_huffman(mjh_decoder *d, mjh_huff *h, const int *count)
+{
+	int i, j, k = 0;
+	unsigned code = 0;
+	for (i = 0; i < 16; ++i)
+		for (j = 0; j < count[i]; ++j) {
+			if (k >= 256)
+				return fail(d, "bad code lengths"); /* the reference would overrun its arrays here */
+			h->size[k++] = (uint8_t)(i + 1);
+		}
+	h->size[k] = 0;
+
+	k = 0;
+	for (j = 1; j <= 16; ++j) {
+		h->delta[j] = k - (int)code;
+		if (h->size[k] == j) {
+			while (h->size[k] == j)
+				h->code[k++] = (uint16_t)(code++);
+			if (code - 1 >= (1u << j))
+				return fail(d, "bad code lengths");
+		}
+		h->maxcode[j] = code << (16 - j);
+		code <<= 1;
+	}
+	h->maxcode[17] = 0xffffffffu;
+
+	memset(h->fast, 255, sizeof(h->fast));
+	for (i = 0; i < k; ++i) {
+		int s = h->size[i];
+		if (s <= MJH_FAST_BITS) {
+			int first = h->code[i] << (MJH_FAST_BITS - s);
+			int span = 1 << (MJH_FAST_BITS - s);
+			memset(h->fast + first, i, (size_t)span); /* symbol index 255 keeps meaning "slow path" */
+		}
+	}
+	return 1;
+}
+
+/* codec/jpeg.c:138-165 */
+static void build_fast_ac(int16_t *fac, const mjh_huff *h)
+{
+	int i;
+	for (i = 0; i < (1 << MJH_FAST_BITS); ++i) {
+		int sym = h->fast[i];
+		fac[i] = 0;
+		if (sym < 255) {
+			int rs = h->values[sym];
+			int run = (rs >> 4) & 15, magbits = rs & 15, len = h->size[sym];
+			if (magbits && len + magbits <= MJH_FAST_BITS) {
+				int v = ((i << len) & ((1 << MJH_FAST_BITS) - 1)) >> (MJH_FAST_BITS - magbits);
+				if (v < (1 << (magbits - 1)))
+					v += (int)((~0u << magbits) + 1);
+				if (v >= -128 && v <= 127)
+					fac[i] = (int16_t)(v * 256 + run * 16 + len + magbits);
+			}
+		}
+	}
+}
+
+/* ------------------------------------------------------------------ bit reader */
+
+static const uint32_t k_bmask[17] = {0, 1, 3, 7, 15, 31, 63, 127, 255, 511, 1023, 2047, 4095, 8191, 16383, 32767, 65535};
+/* (-1 << n) + 1; the reference's table stops at n = 15 (codec/jpeg.c:246) */
+static const int32_t k_bias[17] = {0, -1, -3, -7, -15, -31, -63, -127, -255, -511, -1023, -2047, -4095, -8191, -16383, -32767, -65535};
+
+#define MARKER_NONE 0xff
+
+/* codec/jpeg.c:167-187 */
+static void bits_grow(mjh_decoder *d)
+{
+	do {
+		unsigned b = d->nomore ? 0 : rd8(d->r);
+		if (b == 0xff) {
+			unsigned c = rd8(d->r);
+			while (c == 0xff)
+				c = rd8(d->r);
+			if (c != 0) {
+				d->marker = (unsigned char)c;
+				d->nomore = 1;
+				return;
+			}
+		}
+		/* code_bits can be negative on streams that ran dry at a marker; the byte is then 0 */
+		if (b)
+			d->code_buffer |= b << (24 - d->code_bits);
+		d->code_bits += 8;
+	} while (d->code_bits <= 24);
+}
+
+static inline uint32_t rotl32(uint32_t x, int n) { return (x << (n & 31)) | (x >> ((32 - n) & 31)); }
+
+/* codec/jpeg.c:193-243 */
+static inline int huff_decode(mjh_decoder *d, const mjh_huff *h)
+{
+	unsigned top, temp;
+	int k, c;
+	if (d->code_bits < 16)
+		bits_grow(d);
+	top = d->code_buffer >> (32 - MJH_FAST_BITS);
+	k = h->fast[top];
+	if (k < 255) {
+		int s = h->size[k];
+		if (s > d->code_bits)
+			return -1;
+		d->code_buffer <<= s;
+		d->code_bits -= s;
+		return h->values[k];
+	}
+	temp = d->code_buffer >> 16;
+	for (k = MJH_FAST_BITS + 1;; ++k)
+		if (temp < h->maxcode[k])
+			break;
+	if (k == 17) {
+		d->code_bits -= 16;
+		return -1;
+	}
+	if (k > d->code_bits)
+		return -1;
+	c = (int)((d->code_buffer >> (32 - k)) & k_bmask[k]) + h->delta[k];
+	d->code_bits -= k;
+	d->code_buffer <<= k;
+	return h->values[c & 255];
+}
+
+/* codec/jpeg.c:250-265 */
+static inline int extend_receive(mjh_decoder *d, int n)
+{
+	uint32_t k;
+	int32_t sgn;
+	if (d->code_bits < n)
+		bits_grow(d);
+	if (n < 0 || n > 16)
+		return 0;
+	sgn = (int32_t)d->code_buffer >> 31;
+	k = rotl32(d->code_buffer, n);
+	d->code_buffer = k & ~k_bmask[n];
+	k &= k_bmask[n];
+	d->code_bits -= n;
+	return (int)k + (k_bias[n] & ~sgn);
+}
+
+/* codec/jpeg.c:268-278 */
+static inline int get_bits(mjh_decoder *d, int n)
+{
+	uint32_t k;
+	if (d->code_bits < n)
+		bits_grow(d);
+	k = rotl32(d->code_buffer, n);
+	d->code_buffer = k & ~k_bmask[n];
+	k &= k_bmask[n];
+	d->code_bits -= n;
+	return (int)k;
+}
+
+/* codec/jpeg.c:280-289 */
+static inline int get_bit(mjh_decoder *d)
+{
+	uint32_t k;
+	if (d->code_bits < 1)
+		bits_grow(d);
+	k = d->code_buffer;
+	d->code_buffer <<= 1;
+	--d->code_bits;
+	return (int)(k & 0x80000000u);
+}
+
+/* ------------------------------------------------------------------ block decoders */
+
+static void zero_block(int16_t *blk)
+{
+	int c;
+	for (c = 0; c < 8; ++c)
+		memset(blk + (c << 9), 0, 16);
+}
+
+static inline int iabs16(int v)
+{
+	int s = (int16_t)v;
+	return s < 0 ? -s : s;
+}
+
+/*
+ * Baseline block (codec/jpeg.c:308-370).  blk points at the block's tile slot; qz is the
+ * component's quantisation table in zigzag order (only used for the WIDE_IDCT bound: the
+ * multiply itself happens on the GPU).
+ */
+static int decode_block(mjh_decoder *d, int16_t *blk, const mjh_huff *hdc, const mjh_huff *hac, const int16_t *fac, mjh_comp *cp,
+								const uint16_t *qz)
+{
+	int diff, dc, k, t;
+	int32_t l1;
+
+	if (d->code_bits < 16)
+		bits_grow(d);
+	t = huff_decode(d, hdc);
+	if (t < 0)
+		return fail(d, "bad huffman code");
+	if (cp->touched)
+		zero_block(blk);
+
+	diff = t ? extend_receive(d, t) : 0;
+	dc = (int)((unsigned)cp->dc_pred + (unsigned)diff);
+	cp->dc_pred = dc;
+	blk[0] = (int16_t)dc;
+	l1 = iabs16((int)((unsigned)dc * qz[0]));
+
+	k = 1;
+	do {
+		int c, r, s;
+		if (d->code_bits < 16)
+			bits_grow(d);
+		c = (int)(d->code_buffer >> (32 - MJH_FAST_BITS));
+		r = fac[c];
+		if (r) {
+			k += (r >> 4) & 15;
+			s = r & 15;
+			d->code_buffer <<= s;
+			d->code_bits -= s;
+			blk[k_tile_off[k]] = (int16_t)(r >> 8);
+			l1 += iabs16((r >> 8) * qz[k]);
+			++k;
+		} else {
+			int rs = huff_decode(d, hac);
+			if (rs < 0)
+				return fail(d, "bad huffman code");
+			s = rs & 15;
+			r = rs >> 4;
+			if (s == 0) {
+				if (rs != 0xf0)
+					break;
+				k += 16;
+			} else {
+				int v;
+				k += r;
+				v = extend_receive(d, s);
+				blk[k_tile_off[k]] = (int16_t)v;
+				l1 += iabs16((int)((unsigned)v * qz[k]));
+				++k;
+			}
+		}
+	} while (k < 64);
+	if (l1 > d->max_block_l1)
+		d->max_block_l1 = l1;
+	return 1;
+}
+
+/* codec/jpeg.c:372-402 */
+static int decode_block_prog_dc(mjh_decoder *d, int16_t *blk, const mjh_huff *hdc, mjh_comp *cp)
+{
+	if (d->spec_end != 0)
+		return fail(d, "can't merge dc and ac");
+	if (d->code_bits < 16)
+		bits_grow(d);
+	if (d->succ_high == 0) {
+		int t, diff, dc;
+		zero_block(blk);
+		t = huff_decode(d, hdc);
+		if (t < 0)
+			return fail(d, "can't merge dc and ac");
+		diff = t ? extend_receive(d, t) : 0;
+		dc = (int)((unsigned)cp->dc_pred + (unsigned)diff);
+		cp->dc_pred = dc;
+		blk[0] = (int16_t)((unsigned)dc << d->succ_low);
+	} else {
+		if (get_bit(d))
+			blk[0] = (int16_t)(blk[0] + (int16_t)(1 << d->succ_low));
+	}
+	return 1;
+}
+
+static inline void refine_nonzero(mjh_decoder *d, int16_t *p, int bit)
+{
+	if (get_bit(d))
+		if ((*p & bit) == 0) {
+			if (*p > 0)
+				*p = (int16_t)(*p + bit);
+			else
+				*p = (int16_t)(*p - bit);
+		}
+}
+
+/* codec/jpeg.c:406-558 */
+static int decode_block_prog_ac(mjh_decoder *d, int16_t *blk, const mjh_huff *hac, const int16_t *fac)
+{
+	int k;
+	if (d->spec_start == 0)
+		return fail(d, "can't merge dc and ac");
+
+	if (d->succ_high == 0) {
+		int shift = d->succ_low;
+		if (d->eob_run) {
+			--d->eob_run;
+			return 1;
+		}
+		k = d->spec_start;
+		do {
+			int c, r, s;
+			if (d->code_bits < 16)
+				bits_grow(d);
+			c = (int)(d->code_buffer >> (32 - MJH_FAST_BITS));
+			r = fac[c];
+			if (r) {
+				k += (r >> 4) & 15;
+				s = r & 15;
+				d->code_buffer <<= s;
+				d->code_bits -= s;
+				blk[k_tile_off[k]] = (int16_t)((unsigned)(r >> 8) << shift);
+				++k;
+			} else {
+				int rs = huff_decode(d, hac);
+				if (rs < 0)
+					return fail(d, "bad huffman code");
+				s = rs & 15;
+				r = rs >> 4;
+				if (s == 0) {
+					if (r < 15) {
+						d->eob_run = (1 << r);
+						if (r)
+							d->eob_run += get_bits(d, r);
+						--d->eob_run;
+						break;
+					}
+					k += 16;
+				} else {
+					k += r;
+					blk[k_tile_off[k]] = (int16_t)((unsigned)extend_receive(d, s) << shift);
+					++k;
+				}
+			}
+		} while (k <= d->spec_end);
+	} else {
+		int bit = (int16_t)(1 << d->succ_low);
+		if (d->eob_run) {
+			--d->eob_run;
+			for (k = d->spec_start; k <= d->spec_end; ++k) {
+				int16_t *p = &blk[k_tile_off[k]];
+				if (*p != 0)
+					refine_nonzero(d, p, bit);
+			}
+		} else {
+			k = d->spec_start;
+			do {
+				int r, s;
+				int rs = huff_decode(d, hac);
+				if (rs < 0)
+					return fail(d, "bad huffman code");
+				s = rs & 15;
+				r = rs >> 4;
+				if (s == 0) {
+					if (r < 15) {
+						d->eob_run = (1 << r) - 1;
+						if (r)
+							d->eob_run += get_bits(d, r);
+						r = 64; /* run to the end of the band */
+					}
+					/* r == 15: sixteen zeros, handled by the run below with s = 0 */
+				} else {
+					if (s != 1)
+						return fail(d, "bad huffman code");
+					s = get_bit(d) ? bit : -bit;
+				}
+				while (k <= d->spec_end) {
+					int16_t *p = &blk[k_tile_off[k++]];
+					if (*p != 0) {
+						refine_nonzero(d, p, bit);
+					} else {
+						if (r == 0) {
+							*p = (int16_t)s;
+							break;
+						}
+						--r;
+					}
+				}
+			} while (k <= d->spec_end);
+		}
+	}
+	return 1;
+}
+
+/* ------------------------------------------------------------------ scans */
+
+#define IS_RESTART(x) ((x) >= 0xd0 && (x) <= 0xd7)
+
+/* codec/jpeg.c:1142-1153 */
+static void entropy_reset(mjh_decoder *d)
+{
+	d->code_bits = 0;
+	d->code_buffer = 0;
+	d->nomore = 0;
+	d->comp[0].dc_pred = d->comp[1].dc_pred = d->comp[2].dc_pred = d->comp[3].dc_pred = 0;
+	d->marker = MARKER_NONE;
+	d->todo = d->restart_interval ? d->restart_interval : 0x7fffffff;
+	d->eob_run = 0;
+}
+
+/* after each MCU: count the restart interval down (codec/jpeg.c:1180-1189 and twins).
+ * Returns 0 to keep going, 1 when the scan must stop here (missing RST: keep what we have). */
+static inline int restart_check(mjh_decoder *d)
+{
+	if (--d->todo <= 0) {
+		if (d->code_bits < 24)
+			bits_grow(d);
+		if (!IS_RESTART(d->marker))
+			return 1;
+		entropy_reset(d);
+	}
+	return 0;
+}
+
+/* codec/jpeg.c:1155-1317 */
+static int parse_entropy_coded_data(mjh_decoder *d)
+{
+	uint16_t qz[4][64 + 15];
+	int ci, k;
+	entropy_reset(d);
+	for (ci = 0; ci < d->scan_n; ++ci) {
+		const uint16_t *q = d->dequant[d->comp[d->order[ci]].tq];
+		for (k = 0; k < 64 + 15; ++k)
+			qz[ci][k] = q[k_dezigzag[k]];
+	}
+
+	if (!d->progressive) {
+		if (d->scan_n == 1) {
+			mjh_comp *cp = &d->comp[d->order[0]];
+			int w = (cp->x + 7) >> 3, h = (cp->y + 7) >> 3, i, j;
+			const mjh_huff *hdc = &d->huff_dc[cp->hd], *hac = &d->huff_ac[cp->ha];
+			const int16_t *fac = d->fast_ac[cp->ha];
+			for (j = 0; j < h; ++j)
+				for (i = 0; i < w; ++i) {
+					if (!decode_block(d, cp->plane + block_base(i + j * cp->bw), hdc, hac, fac, cp, qz[0]))
+						return 0;
+					if (restart_check(d)) {
+						cp->touched = 1;
+						return 1;
+					}
+				}
+			cp->touched = 1;
+			return 1;
+		} else {
+			int i, j, x, y;
+			for (j = 0; j < d->mcu_y; ++j)
+				for (i = 0; i < d->mcu_x; ++i) {
+					for (ci = 0; ci < d->scan_n; ++ci) {
+						mjh_comp *cp = &d->comp[d->order[ci]];
+						const mjh_huff *hdc = &d->huff_dc[cp->hd], *hac = &d->huff_ac[cp->ha];
+						const int16_t *fac = d->fast_ac[cp->ha];
+						for (y = 0; y < cp->v; ++y)
+							for (x = 0; x < cp->h; ++x) {
+								int L = (i * cp->h + x) + (j * cp->v + y) * cp->bw;
+								if (!decode_block(d, cp->plane + block_base(L), hdc, hac, fac, cp, qz[ci]))
+									return 0;
+							}
+					}
+					if (restart_check(d))
+						goto interleaved_done;
+				}
+		interleaved_done:
+			for (ci = 0; ci < d->scan_n; ++ci)
+				d->comp[d->order[ci]].touched = 1;
+			return 1;
+		}
+	} else {
+		if (d->scan_n == 1) {
+			mjh_comp *cp = &d->comp[d->order[0]];
+			int w = (cp->x + 7) >> 3, h = (cp->y + 7) >> 3, i, j;
+			for (j = 0; j < h; ++j)
+				for (i = 0; i < w; ++i) {
+					int16_t *blk = cp->plane + block_base(i + j * cp->bw);
+					if (d->spec_start == 0) {
+						if (!decode_block_prog_dc(d, blk, &d->huff_dc[cp->hd], cp))
+							return 0;
+					} else {
+						if (!decode_block_prog_ac(d, blk, &d->huff_ac[cp->ha], d->fast_ac[cp->ha]))
+							return 0;
+					}
+					if (restart_check(d))
+						return 1;
+				}
+			return 1;
+		} else {
+			int i, j, x, y;
+			for (j = 0; j < d->mcu_y; ++j)
+				for (i = 0; i < d->mcu_x; ++i) {
+					for (ci = 0; ci < d->scan_n; ++ci) {
+						mjh_comp *cp = &d->comp[d->order[ci]];
+						for (y = 0; y < cp->v; ++y)
+							for (x = 0; x < cp->h; ++x) {
+								int L = (i * cp->h + x) + (j * cp->v + y) * cp->bw;
+								if (!decode_block_prog_dc(d, cp->plane + block_base(L), &d->huff_dc[cp->hd], cp))
+									return 0;
+							}
+					}
+					if (restart_check(d))
+						return 1;
+				}
+			return 1;
+		}
+	}
+}
+
+/* ------------------------------------------------------------------ markers */
+
+/* codec/jpeg.c:1119-1134 */
+static unsigned get_marker(mjh_decoder *d)
+{
+	unsigned x;
+	if (d->marker != MARKER_NONE) {
+		x = d->marker;
+		d->marker = MARKER_NONE;
+		return x;
+	}
+	x = rd8(d->r);
+	if (x != 0xff)
+		return MARKER_NONE;
+	while (x == 0xff)
+		x = rd8(d->r);
+	return x;
+}
+
+/* codec/jpeg.c:1349-1468 */
+static int process_marker(mjh_decoder *d, unsigned m)
+{
+	mjh_reader *r = d->r;
+	int L;
+	switch (m) {
+	case MARKER_NONE:
+		return fail(d, "expected marker");
+
+	case 0xDD: /* DRI */
+		if (rd16be(r) != 4)
+			return fail(d, "bad DRI len");
+		d->restart_interval = rd16be(r);
+		return 1;
+
+	case 0xDB: /* DQT */
+		L = rd16be(r) - 2;
+		while (L > 0) {
+			int q = (int)rd8(r);
+			int p = q >> 4, t = q & 15, i;
+			if (p != 0 && p != 1)
+				return fail(d, "bad DQT type");
+			if (t > 3)
+				return fail(d, "bad DQT table");
+			for (i = 0; i < 64; ++i)
+				d->dequant[t][k_dezigzag[i]] = (uint16_t)(p ? rd16be(r) : (int)rd8(r));
+			L -= p ? 129 : 65;
+		}
+		return L == 0;
+
+	case 0xC4: /* DHT */
+		L = rd16be(r) - 2;
+		while (L > 0) {
+			int sizes[16], i, n = 0;
+			int q = (int)rd8(r);
+			int tc = q >> 4, th = q & 15;
+			mjh_huff *h;
+			if (tc > 1 || th > 3)
+				return fail(d, "bad DHT header");
+			for (i = 0; i < 16; ++i) {
+				sizes[i] = (int)rd8(r);
+				n += sizes[i];
+			}
+			L -= 17;
+			h = tc == 0 ? &d->huff_dc[th] : &d->huff_ac[th];
+			if (!build_huffman(d, h, sizes))
+				return 0;
+			for (i = 0; i < n; ++i)
+				h->values[i] = (uint8_t)rd8(r);
+			if (tc != 0)
+				build_fast_ac(d->fast_ac[th], h);
+			L -= n;
+		}
+		return L == 0;
+	}
+
+	if ((m >= 0xE0 && m <= 0xEF) || m == 0xFE) {
+		L = rd16be(r);
+		if (L < 2)
+			return fail(d, m == 0xFE ? "bad COM len" : "bad APP len");
+		L -= 2;
+		if (m == 0xE0 && L >= 5) {
+			static const unsigned char tag[5] = {'J', 'F', 'I', 'F', 0};
+			int ok = 1, i;
+			for (i = 0; i < 5; ++i)
+				if (rd8(r) != tag[i])
+					ok = 0;
+			L -= 5;
+			if (ok)
+				d->jfif = 1;
+		} else if (m == 0xEE && L >= 12) {
+			static const unsigned char tag[6] = {'A', 'd', 'o', 'b', 'e', 0};
+			int ok = 1, i;
+			for (i = 0; i < 6; ++i)
+				if (rd8(r) != tag[i])
+					ok = 0;
+			L -= 6;
+			if (ok) {
+				rd8(r);    /* version */
+				rd16be(r); /* flags0 */
+				rd16be(r); /* flags1 */
+				d->app14 = (int)rd8(r);
+				L -= 6;
+			}
+		}
+		rd_skip(r, L);
+		return 1;
+	}
+	return fail(d, "unknown marker");
+}
+
+/* codec/jpeg.c:1471-1521 */
+static int process_scan_header(mjh_decoder *d)
+{
+	mjh_reader *r = d->r;
+	int i, aa;
+	int Ls = rd16be(r);
+	d->scan_n = (int)rd8(r);
+	if (d->scan_n < 1 || d->scan_n > 4 || d->scan_n > d->img_n)
+		return fail(d, "bad SOS component count");
+	if (Ls != 6 + 2 * d->scan_n)
+		return fail(d, "bad SOS len");
+	for (i = 0; i < d->scan_n; ++i) {
+		int id = (int)rd8(r), which;
+		int q = (int)rd8(r);
+		for (which = 0; which < d->img_n; ++which)
+			if (d->comp[which].id == id)
+				break;
+		if (which == d->img_n)
+			return 0; /* no reason set by the reference either */
+		d->comp[which].hd = q >> 4;
+		if (d->comp[which].hd > 3)
+			return fail(d, "bad DC huff");
+		d->comp[which].ha = q & 15;
+		if (d->comp[which].ha > 3)
+			return fail(d, "bad AC huff");
+		d->order[i] = which;
+	}
+	d->spec_start = (int)rd8(r);
+	d->spec_end = (int)rd8(r);
+	aa = (int)rd8(r);
+	d->succ_high = aa >> 4;
+	d->succ_low = aa & 15;
+	if (d->progressive) {
+		if (d->spec_start > 63 || d->spec_end > 63 || d->spec_start > d->spec_end || d->succ_high > 13 || d->succ_low > 13)
+			return fail(d, "bad SOS");
+	} else {
+		if (d->spec_start != 0)
+			return fail(d, "bad SOS");
+		if (d->succ_high != 0 || d->succ_low != 0)
+			return fail(d, "bad SOS");
+		d->spec_end = 63;
+	}
+	return 1;
+}
+
+static int mul_fits_int(int a, int b)
+{
+	if (a < 0 || b < 0)
+		return 0;
+	if (b == 0)
+		return 1;
+	return a <= INT_MAX / b;
+}
+
+/* codec/jpeg.c:1549-1659 */
+static int process_frame_header(mjh_decoder *d, int mode)
+{
+	mjh_reader *r = d->r;
+	int Lf, p, i, q, h_max = 1, v_max = 1, c;
+	Lf = rd16be(r);
+	if (Lf < 11)
+		return fail(d, "bad SOF len");
+	p = (int)rd8(r);
+	if (p != 8)
+		return fail(d, "only 8-bit");
+	d->img_y = rd16be(r);
+	if (d->img_y == 0)
+		return fail(d, "no header height");
+	d->img_x = rd16be(r);
+	if (d->img_x == 0)
+		return fail(d, "0 width");
+	/* 16-bit fields cannot exceed STBI_MAX_DIMENSIONS (1<<24): the "too large" tests of :1565-1568 never fire */
+	c = (int)rd8(r);
+	if (c != 3 && c != 1 && c != 4)
+		return fail(d, "bad component count");
+	d->img_n = c;
+	if (Lf != 8 + 3 * d->img_n)
+		return fail(d, "bad SOF len");
+
+	d->rgb = 0;
+	for (i = 0; i < d->img_n; ++i) {
+		static const unsigned char rgb[3] = {'R', 'G', 'B'};
+		d->comp[i].id = (int)rd8(r);
+		if (d->img_n == 3 && d->comp[i].id == rgb[i])
+			++d->rgb;
+		q = (int)rd8(r);
+		d->comp[i].h = q >> 4;
+		if (!d->comp[i].h || d->comp[i].h > 4)
+			return fail(d, "bad H");
+		d->comp[i].v = q & 15;
+		if (!d->comp[i].v || d->comp[i].v > 4)
+			return fail(d, "bad V");
+		d->comp[i].tq = (int)rd8(r);
+		if (d->comp[i].tq > 3)
+			return fail(d, "bad TQ");
+	}
+	if (mode != MJH_SCAN_LOAD)
+		return 1;
+
+	if (!(mul_fits_int(d->img_x, d->img_y) && mul_fits_int(d->img_x * d->img_y, d->img_n)))
+		return fail(d, "too large");
+
+	for (i = 0; i < d->img_n; ++i) {
+		if (d->comp[i].h > h_max)
+			h_max = d->comp[i].h;
+		if (d->comp[i].v > v_max)
+			v_max = d->comp[i].v;
+	}
+	d->h_max = h_max;
+	d->v_max = v_max;
+	d->mcu_w = h_max * 8;
+	d->mcu_h = v_max * 8;
+	d->mcu_x = (d->img_x + d->mcu_w - 1) / d->mcu_w;
+	d->mcu_y = (d->img_y + d->mcu_h - 1) / d->mcu_h;
+
+	for (i = 0; i < d->img_n; ++i) {
+		mjh_comp *cp = &d->comp[i];
+		cp->x = (d->img_x * cp->h + h_max - 1) / h_max;
+		cp->y = (d->img_y * cp->v + v_max - 1) / v_max;
+		cp->w2 = d->mcu_x * cp->h * 8;
+		cp->h2 = d->mcu_y * cp->v * 8;
+		cp->bw = cp->w2 >> 3;
+		cp->bh = cp->h2 >> 3;
+		cp->plane = NULL;
+		cp->touched = 0;
+		/* the reference mallocs w2*h2+15 bytes here (and 2x that for progressive) */
+		if (!mul_fits_int(cp->w2, cp->h2) || cp->w2 * cp->h2 > INT_MAX - 15)
+			return fail(d, "outofmem");
+		if (d->progressive && (!mul_fits_int(cp->w2 * cp->h2, 2) || cp->w2 * cp->h2 * 2 > INT_MAX - 15))
+			return fail(d, "outofmem");
+	}
+	return 1;
+}
+
+/* codec/jpeg.c:1670-1699 */
+int mjh_decode_header(mjh_decoder *d, mjh_reader *r, int mode)
+{
+	unsigned m;
+	init_tile_off();
+	d->r = r;
+	d->reason = NULL;
+	d->jfif = 0;
+	d->app14 = -1;
+	d->marker = MARKER_NONE;
+	d->restart_interval = 0;
+	d->max_block_l1 = 0;
+	m = get_marker(d);
+	if (m != 0xd8)
+		return fail(d, "no SOI");
+	if (mode == MJH_SCAN_TYPE)
+		return 1;
+	m = get_marker(d);
+	while (!(m == 0xc0 || m == 0xc1 || m == 0xc2)) {
+		if (!process_marker(d, m))
+			return 0;
+		m = get_marker(d);
+		while (m == MARKER_NONE) {
+			if (rd_eof(r))
+				return fail(d, "no SOF");
+			m = get_marker(d);
+		}
+	}
+	d->progressive = (m == 0xc2);
+	return process_frame_header(d, mode);
+}
+
+/* codec/jpeg.c:2241-2249 and the colour branches of :2320-2431 */
+int mjh_describe(const mjh_decoder *d, int req_comp, mij_image_desc *out)
+{
+	int n, is_rgb, i;
+	if (req_comp < 0 || req_comp > 4)
+		return 0;
+	memset(out, 0, sizeof(*out));
+	n = req_comp ? req_comp : (d->img_n >= 3 ? 3 : 1);
+	is_rgb = d->img_n == 3 && (d->rgb == 3 || (d->app14 == 0 && !d->jfif));
+	out->width = d->img_x;
+	out->height = d->img_y;
+	out->ncomp = d->img_n;
+	out->n_out = n;
+	if (d->img_n == 1)
+		out->color = MIJ_COLOR_GREY;
+	else if (d->img_n == 3)
+		out->color = is_rgb ? MIJ_COLOR_RGB : (n >= 3 ? MIJ_COLOR_YCBCR : MIJ_COLOR_GREY);
+	else
+		out->color = d->app14 == 0 ? MIJ_COLOR_CMYK : (d->app14 == 2 ? MIJ_COLOR_YCCK : MIJ_COLOR_YCBCRA);
+	out->flags = 0;
+	out->h_max = d->h_max;
+	out->v_max = d->v_max;
+	out->mcu_x = d->mcu_x;
+	out->mcu_y = d->mcu_y;
+	for (i = 0; i < d->img_n; ++i) {
+		out->comp[i].h = d->comp[i].h;
+		out->comp[i].v = d->comp[i].v;
+		out->comp[i].tq = d->comp[i].tq;
+		out->comp[i].x = d->comp[i].x;
+		out->comp[i].y = d->comp[i].y;
+		out->comp[i].bw = d->comp[i].bw;
+		out->comp[i].bh = d->comp[i].bh;
+	}
+	memcpy(out->dequant, d->dequant, sizeof(out->dequant));
+	return 1;
+}
+
+/* L1 of every de-quantised block of a finished progressive image (the reference multiplies at
+ * codec/jpeg.c:1319-1324; here only the bound for MIJ_FLAG_WIDE_IDCT is computed). */
+static void progressive_l1(mjh_decoder *d)
+{
+	int ci;
+	for (ci = 0; ci < d->img_n; ++ci) {
+		const mjh_comp *cp = &d->comp[ci];
+		const uint16_t *q = d->dequant[cp->tq];
+		uint16_t qp[64];
+		int nblk = cp->bw * cp->bh, ntile = (nblk + 63) >> 6, t, P, l;
+		for (P = 0; P < 64; ++P) {
+			int col = P >> 3, slot = P & 7, row = 0, rr;
+			for (rr = 0; rr < 8; ++rr)
+				if (mij_rowslot[rr] == slot)
+					row = rr;
+			qp[P] = q[8 * row + col];
+		}
+		for (t = 0; t < ntile; ++t) {
+			const int16_t *tile = cp->plane + ((size_t)t << 12);
+			int32_t acc[64];
+			memset(acc, 0, sizeof(acc));
+			for (P = 0; P < 64; ++P) {
+				const int16_t *src = tile + ((P >> 3) << 9) + (P & 7);
+				int qq = qp[P];
+				for (l = 0; l < 64; ++l) {
+					int v = (int16_t)((unsigned)src[l << 3] * (unsigned)qq);
+					acc[l] += v < 0 ? -v : v;
+				}
+			}
+			for (l = 0; l < 64; ++l)
+				if (acc[l] > d->max_block_l1)
+					d->max_block_l1 = acc[l];
+		}
+	}
+}
+
+/* codec/jpeg.c:1713-1755 */
+int mjh_decode_scans(mjh_decoder *d)
+{
+	unsigned m = get_marker(d);
+	while (m != 0xd9) {
+		if (m == 0xda) {
+			if (!process_scan_header(d))
+				return 0;
+			if (!parse_entropy_coded_data(d))
+				return 0;
+			if (d->marker == MARKER_NONE) {
+				/* tolerate zero padding after the entropy data: look for the next 0xff */
+				while (!rd_eof(d->r)) {
+					unsigned x = rd8(d->r);
+					if (x == 255) {
+						d->marker = (unsigned char)rd8(d->r);
+						break;
+					}
+				}
+			}
+		} else if (m == 0xdc) {
+			int Ld = rd16be(d->r);
+			int NL = rd16be(d->r);
+			if (Ld != 4)
+				return fail(d, "bad DNL len");
+			if (NL != d->img_y)
+				return fail(d, "bad DNL height");
+		} else {
+			if (!process_marker(d, m))
+				return 0;
+		}
+		m = get_marker(d);
+	}
+	if (d->progressive)
+		progressive_l1(d);
+	return 1;
+}
+
+int mjh_needs_wide_idct(const mjh_decoder *d) { return d->max_block_l1 > MIJ_BLOCK_L1_LIMIT; }
+
+/* ------------------------------------------------------------------ one-call memory forms */
+
+static int probe_common(mjh_decoder *d, mjh_reader *r, const uint8_t *buf, int len, int req_comp, mij_image_desc *desc, const char **reason)
+{
+	mjh_reader_mem(r, buf, len);
+	if (!mjh_decode_header(d, r, MJH_SCAN_TYPE)) {
+		*reason = "unknown image type";
+		return 0;
+	}
+	mjh_reader_rewind(r);
+	if (req_comp < 0 || req_comp > 4) {
+		*reason = "bad req_comp";
+		return 0;
+	}
+	if (!mjh_decode_header(d, r, MJH_SCAN_LOAD)) {
+		*reason = d->reason;
+		return 0;
+	}
+	if (!mjh_describe(d, req_comp, desc)) {
+		*reason = "bad req_comp";
+		return 0;
+	}
+	return 1;
+}
+
+int mjh_probe_memory(const uint8_t *buf, int len, int req_comp, mij_image_desc *desc, const char **reason)
+{
+	const char *why = NULL;
+	mjh_reader r;
+	mjh_decoder *d = (mjh_decoder *)calloc(1, sizeof(*d));
+	int ok;
+	if (!d) {
+		if (reason)
+			*reason = "outofmem";
+		return 0;
+	}
+	ok = probe_common(d, &r, buf, len, req_comp, desc, &why);
+	free(d);
+	if (reason)
+		*reason = why;
+	return ok;
+}
+
+int mjh_decode_memory(const uint8_t *buf, int len, int req_comp, mij_image_desc *desc, int16_t *arena, size_t arena_elems, const char **reason)
+{
+	const char *why = NULL;
+	mjh_reader r;
+	mjh_decoder *d = (mjh_decoder *)calloc(1, sizeof(*d));
+	int ok = 0, i;
+	size_t off = 0;
+	if (!d) {
+		if (reason)
+			*reason = "outofmem";
+		return 0;
+	}
+	if (probe_common(d, &r, buf, len, req_comp, desc, &why)) {
+		for (i = 0; i < desc->ncomp; ++i) {
+			size_t n = mij_plane_elems((uint32_t)(desc->comp[i].bw * desc->comp[i].bh));
+			if (off + n > arena_elems) {
+				why = "outofmem";
+				goto done;
+			}
+			d->comp[i].plane = arena + off;
+			off += n;
+		}
+		memset(arena, 0, off * sizeof(int16_t));
+		if (!mjh_decode_scans(d)) {
+			why = d->reason;
+			goto done;
+		}
+		if (mjh_needs_wide_idct(d))
+			desc->flags |= MIJ_FLAG_WIDE_IDCT;
+		ok = 1;
+	}
+done:
+	free(d);
+	if (reason)
+		*reason = why;
+	return ok;
+}

@@ -1,0 +1,127 @@
+/*
+ * jpeg_entropy.h -- host half of the JPEG decode path (product code, plain C).
+ *
+ * Marker parsing and the sequential Huffman bitstream walk stay on the CPU, as in the
+ * reference (codec/jpeg.c:88-558 tables/bit reader/block decoders, :1119-1756 markers, scans,
+ * frames).  What changes is where a decoded block goes: instead of being de-quantised and
+ * handed to idct_block_kernel (codec/jpeg.c:1178,:1217,:1342) its *quantised* coefficients are
+ * written into the tile-layout staging planes of mij.h, from where the GPU takes over.
+ *
+ * Byte-source semantics (EOF reads as 0, callback buffering, rewind) follow the reference's
+ * stbi__context (common.c:10-126) so that truncated and padded files behave identically.
+ */
+#ifndef MIJ_JPEG_ENTROPY_H
+#define MIJ_JPEG_ENTROPY_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "image_api.h"
+#include "mij.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- byte source: restates stbi__context (common.c:10-126, Appendix A of SURVEY.md) ---- */
+typedef struct {
+	const uint8_t *p, *end;
+	const uint8_t *orig, *orig_end;
+	stbi_io_callbacks io; /* io.read == NULL: memory source */
+	void *user;
+	int from_callbacks; /* still refilling through io.read */
+	int buflen;
+	int already_read;
+	uint8_t buf[128];
+} mjh_reader;
+
+void mjh_reader_mem(mjh_reader *r, const uint8_t *data, int len);
+void mjh_reader_callbacks(mjh_reader *r, const stbi_io_callbacks *io, void *user);
+void mjh_reader_file(mjh_reader *r, FILE *f);
+void mjh_reader_rewind(mjh_reader *r);
+/* bytes buffered but not consumed: what stbi_load_from_file seeks back (convert.c:208) */
+long mjh_reader_unread(const mjh_reader *r);
+
+/* ---- decoder state ---- */
+#define MJH_FAST_BITS 9
+
+typedef struct {
+	uint8_t fast[1 << MJH_FAST_BITS]; /* symbol index for codes <= 9 bits, 255 = take the slow path */
+	uint16_t code[256];
+	uint8_t values[256];
+	uint8_t size[257];
+	uint32_t maxcode[18];
+	int32_t delta[17];
+} mjh_huff;
+
+typedef struct {
+	int id, h, v, tq, hd, ha;
+	int dc_pred;
+	int x, y, w2, h2;
+	int bw, bh;       /* blocks per row / rows of the padded grid */
+	int16_t *plane;   /* tile-layout staging plane (mij.h), owned by the caller */
+	int touched;      /* a previous scan already wrote blocks of this component */
+} mjh_comp;
+
+enum { MJH_SCAN_LOAD = 0, MJH_SCAN_TYPE = 1, MJH_SCAN_HEADER = 2 };
+
+typedef struct {
+	mjh_reader *r;
+	mjh_huff huff_dc[4], huff_ac[4];
+	uint16_t dequant[4][64]; /* natural order (codec/jpeg.c:1376) */
+	int16_t fast_ac[4][1 << MJH_FAST_BITS];
+
+	int img_x, img_y, img_n;
+	int h_max, v_max, mcu_x, mcu_y, mcu_w, mcu_h;
+	mjh_comp comp[4];
+
+	/* bit reader (codec/jpeg.c:64-67) */
+	uint32_t code_buffer;
+	int code_bits;
+	unsigned char marker;
+	int nomore;
+
+	int progressive, spec_start, spec_end, succ_high, succ_low, eob_run;
+	int jfif, app14, rgb;
+	int scan_n, order[4];
+	int restart_interval, todo;
+
+	/* largest per-block sum of |de-quantised coefficient| seen (baseline), for MIJ_FLAG_WIDE_IDCT */
+	int32_t max_block_l1;
+	const char *reason; /* short failure reason, reference wording */
+} mjh_decoder;
+
+/* SOI + markers up to and including SOF (codec/jpeg.c:1670-1699).  mode = MJH_SCAN_*.
+ * Returns 1 / 0 (d->reason set). */
+int mjh_decode_header(mjh_decoder *d, mjh_reader *r, int mode);
+
+/* Fills an mij_image_desc from a parsed header and the caller's req_comp, following
+ * load_jpeg_image (codec/jpeg.c:2241-2249): n_out, colour mode, which components the GPU needs.
+ * Returns 1, or 0 for "bad req_comp". */
+int mjh_describe(const mjh_decoder *d, int req_comp, mij_image_desc *out);
+
+/* Everything after SOF until EOI (codec/jpeg.c:1713-1755): scans are entropy-decoded into
+ * d->comp[i].plane (which the caller must have pointed at zero-filled tile-layout planes).
+ * For progressive files every block's L1 is computed at the end.  Returns 1 / 0. */
+int mjh_decode_scans(mjh_decoder *d);
+
+/* Non-zero if the finished image needs MIJ_FLAG_WIDE_IDCT. */
+int mjh_needs_wide_idct(const mjh_decoder *d);
+
+/*
+ * One-call forms of the host stage for memory inputs (used by the batch decoder, tests, bench):
+ *   mjh_probe_memory   type test + header + describe (stbi__jpeg_test, then codec/jpeg.c:1670-1699,
+ *                      :2241-2249); fills *desc so the caller can size the coefficient planes.
+ *   mjh_decode_memory  the same plus the scans (codec/jpeg.c:1713-1755) into `arena`: the component
+ *                      planes in tile layout, back to back in component order, exactly the layout of
+ *                      the staging a mij batch hands out.  The callee zero-fills what it uses.
+ *                      desc->flags gets MIJ_FLAG_WIDE_IDCT when needed.
+ * Both return 1 on success, 0 on failure with *reason = the reference's short reason.
+ */
+int mjh_probe_memory(const uint8_t *buf, int len, int req_comp, mij_image_desc *desc, const char **reason);
+int mjh_decode_memory(const uint8_t *buf, int len, int req_comp, mij_image_desc *desc, int16_t *arena, size_t arena_elems, const char **reason);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

@@ -1,0 +1,382 @@
+/*
+ * jpeg_write_host.c -- baseline JFIF writer behind stbi_write_jpg / stbi_write_jpg_to_func.
+ *
+ * Restates the reference encoder (codec/jpeg_write.c:1-388) so that the produced byte stream is
+ * identical: same quality mapping and tables (:220-243), same headers (:245-268), the same
+ * float colour transform, edge replication and 2x2 chroma mean (:283-325 / :330-352), the same
+ * float AAN forward DCT operation order (:24-74, :96-105), the same round-to-nearest quantiser
+ * (:107-118) and the same Huffman emission (:120-169, :4-22).  Float results depend on the
+ * operation order, so this file must be compiled with -ffp-contract=off and without fast-math.
+ *
+ * The forward DCT + quantisation of this path (BASELINE config 5) still
+ * runs on the host in this round; the GPU kernel for it is the next step behind the same API.
+ * The benchmark uses this writer to synthesise its JPEG inputs on the GPU box.
+ *
+ * The Huffman code tables are derived from the Annex-K BITS/HUFFVAL lists (which the file has
+ * to carry anyway for its DHT segment) instead of being spelled out as literal code tables.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "image_api.h"
+
+static int g_flip_on_write = 0;
+void stbi_flip_vertically_on_write(int flag) { g_flip_on_write = flag; }
+
+/* natural index -> zigzag position (codec/jpeg_write.c:1-2) */
+static const unsigned char k_zigzag_of[64] = {0,  1,  5,  6,  14, 15, 27, 28, 2,  4,  7,  13, 16, 26, 29, 42, 3,  8,  12, 17, 25, 30,
+															 41, 43, 9,  11, 18, 24, 31, 40, 44, 53, 10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38,
+															 46, 51, 55, 60, 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
+
+/* Annex K.3 tables: BITS (index 0 unused) and HUFFVAL */
+static const unsigned char k_dc_lum_bits[17] = {0, 0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0};
+static const unsigned char k_dc_vals[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+static const unsigned char k_dc_chr_bits[17] = {0, 0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0};
+static const unsigned char k_ac_lum_bits[17] = {0, 0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 0x7d};
+static const unsigned char k_ac_lum_vals[162] = {
+	0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61, 0x07, 0x22, 0x71, 0x14, 0x32, 0x81, 0x91, 0xa1,
+	0x08, 0x23, 0x42, 0xb1, 0xc1, 0x15, 0x52, 0xd1, 0xf0, 0x24, 0x33, 0x62, 0x72, 0x82, 0x09, 0x0a, 0x16, 0x17, 0x18, 0x19, 0x1a, 0x25, 0x26,
+	0x27, 0x28, 0x29, 0x2a, 0x34, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56,
+	0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x83, 0x84, 0x85,
+	0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa,
+	0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6,
+	0xd7, 0xd8, 0xd9, 0xda, 0xe1, 0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf1, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9,
+	0xfa};
+static const unsigned char k_ac_chr_bits[17] = {0, 0, 2, 1, 2, 4, 4, 3, 4, 7, 5, 4, 4, 0, 1, 2, 0x77};
+static const unsigned char k_ac_chr_vals[162] = {
+	0x00, 0x01, 0x02, 0x03, 0x11, 0x04, 0x05, 0x21, 0x31, 0x06, 0x12, 0x41, 0x51, 0x07, 0x61, 0x71, 0x13, 0x22, 0x32, 0x81, 0x08, 0x14, 0x42,
+	0x91, 0xa1, 0xb1, 0xc1, 0x09, 0x23, 0x33, 0x52, 0xf0, 0x15, 0x62, 0x72, 0xd1, 0x0a, 0x16, 0x24, 0x34, 0xe1, 0x25, 0xf1, 0x17, 0x18, 0x19,
+	0x1a, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55,
+	0x56, 0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x82, 0x83,
+	0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8,
+	0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4,
+	0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9,
+	0xfa};
+
+/* base quantisation tables, natural order (codec/jpeg_write.c:204-207) */
+static const int k_qt_lum[64] = {16, 11, 10, 16, 24,  40,  51,  61,  12, 12, 14, 19, 26,  58,  60,  55,  14, 13, 16, 24, 40,  57,
+											69, 56, 14, 17, 22,  29,  51,  87,  80, 62, 18, 22, 37,  56,  68,  109, 103, 77, 24, 35, 55,  64,
+											81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99};
+static const int k_qt_chr[64] = {17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99,
+											99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99};
+
+typedef struct {
+	unsigned short code[256], len[256];
+} enc_table;
+
+/* canonical code assignment of Annex C: gives the reference's literal YDC_HT/UVDC_HT/YAC_HT/UVAC_HT */
+static void make_enc_table(enc_table *t, const unsigned char *bits, const unsigned char *vals)
+{
+	int l, i, k = 0;
+	unsigned code = 0;
+	memset(t, 0, sizeof(*t));
+	for (l = 1; l <= 16; ++l) {
+		for (i = 0; i < bits[l]; ++i, ++k) {
+			t->code[vals[k]] = (unsigned short)code++;
+			t->len[vals[k]] = (unsigned short)l;
+		}
+		code <<= 1;
+	}
+}
+
+typedef struct {
+	stbi_write_func *func;
+	void *context;
+	unsigned char buf[4096];
+	int used;
+	int bit_buf, bit_cnt;
+} jw_sink;
+
+static void sink_flush(jw_sink *s)
+{
+	if (s->used) {
+		s->func(s->context, s->buf, s->used);
+		s->used = 0;
+	}
+}
+static inline void sink_byte(jw_sink *s, unsigned char c)
+{
+	if (s->used == (int)sizeof(s->buf))
+		sink_flush(s);
+	s->buf[s->used++] = c;
+}
+static void sink_bytes(jw_sink *s, const void *p, int n)
+{
+	const unsigned char *b = (const unsigned char *)p;
+	int i;
+	for (i = 0; i < n; ++i)
+		sink_byte(s, b[i]);
+}
+
+/* codec/jpeg_write.c:4-22 */
+static inline void put_bits(jw_sink *s, unsigned code, int len)
+{
+	int cnt = s->bit_cnt + len;
+	int buf = s->bit_buf | (int)(code << (24 - cnt));
+	while (cnt >= 8) {
+		unsigned char c = (unsigned char)((buf >> 16) & 255);
+		sink_byte(s, c);
+		if (c == 255)
+			sink_byte(s, 0);
+		buf <<= 8;
+		cnt -= 8;
+	}
+	s->bit_buf = buf;
+	s->bit_cnt = cnt;
+}
+
+/* magnitude category and the bits that follow it (codec/jpeg_write.c:76-86) */
+static inline void magnitude_bits(int val, unsigned *bits, int *nbits)
+{
+	int a = val < 0 ? -val : val, n = 1;
+	int v = val < 0 ? val - 1 : val;
+	while (a >>= 1)
+		++n;
+	*nbits = n;
+	*bits = (unsigned)v & ((1u << n) - 1u);
+}
+
+/* one 8-point AAN pass over p[0], p[s], ... p[7s]; operation order of codec/jpeg_write.c:24-74 */
+static inline void fdct8(float *p, int s)
+{
+	float d0 = p[0], d1 = p[s], d2 = p[2 * s], d3 = p[3 * s], d4 = p[4 * s], d5 = p[5 * s], d6 = p[6 * s], d7 = p[7 * s];
+	float a0 = d0 + d7, a7 = d0 - d7;
+	float a1 = d1 + d6, a6 = d1 - d6;
+	float a2 = d2 + d5, a5 = d2 - d5;
+	float a3 = d3 + d4, a4 = d3 - d4;
+	/* even part */
+	float b0 = a0 + a3, b3 = a0 - a3;
+	float b1 = a1 + a2, b2 = a1 - a2;
+	float z1, z2, z3, z4, z5, z11, z13;
+	float o0 = b0 + b1, o4 = b0 - b1;
+	float o2, o6;
+	z1 = (b2 + b3) * 0.707106781f;
+	o2 = b3 + z1;
+	o6 = b3 - z1;
+	/* odd part */
+	b0 = a4 + a5;
+	b1 = a5 + a6;
+	b2 = a6 + a7;
+	z5 = (b0 - b2) * 0.382683433f;
+	z2 = b0 * 0.541196100f + z5;
+	z4 = b2 * 1.306562965f + z5;
+	z3 = b1 * 0.707106781f;
+	z11 = a7 + z3;
+	z13 = a7 - z3;
+	p[5 * s] = z13 + z2;
+	p[3 * s] = z13 - z2;
+	p[s] = z11 + z4;
+	p[7 * s] = z11 - z4;
+	p[0] = o0;
+	p[2 * s] = o2;
+	p[4 * s] = o4;
+	p[6 * s] = o6;
+}
+
+/* forward DCT + quantise one data unit into zigzag order (codec/jpeg_write.c:96-118) */
+static void transform_du(float *cdu, int stride, const float *fdtbl, int *du)
+{
+	int y, x, j;
+	for (y = 0; y < 8; ++y)
+		fdct8(cdu + y * stride, 1);
+	for (x = 0; x < 8; ++x)
+		fdct8(cdu + x, stride);
+	for (y = 0, j = 0; y < 8; ++y)
+		for (x = 0; x < 8; ++x, ++j) {
+			float v = cdu[y * stride + x] * fdtbl[j];
+			du[k_zigzag_of[j]] = (int)(v < 0 ? v - 0.5f : v + 0.5f);
+		}
+}
+
+/* Huffman-code one quantised data unit (codec/jpeg_write.c:120-169); returns its DC */
+static int emit_du(jw_sink *s, const int *du, int dc_pred, const enc_table *hdc, const enc_table *hac)
+{
+	int diff = du[0] - dc_pred, end0, i;
+	unsigned bits;
+	int nbits;
+	if (diff == 0) {
+		put_bits(s, hdc->code[0], hdc->len[0]);
+	} else {
+		magnitude_bits(diff, &bits, &nbits);
+		put_bits(s, hdc->code[nbits], hdc->len[nbits]);
+		put_bits(s, bits, nbits);
+	}
+	end0 = 63;
+	while (end0 > 0 && du[end0] == 0)
+		--end0;
+	if (end0 == 0) {
+		put_bits(s, hac->code[0x00], hac->len[0x00]);
+		return du[0];
+	}
+	for (i = 1; i <= end0; ++i) {
+		int start = i, run;
+		while (du[i] == 0 && i <= end0)
+			++i;
+		run = i - start;
+		if (run >= 16) {
+			int n16 = run >> 4, k;
+			for (k = 0; k < n16; ++k)
+				put_bits(s, hac->code[0xF0], hac->len[0xF0]);
+			run &= 15;
+		}
+		magnitude_bits(du[i], &bits, &nbits);
+		put_bits(s, hac->code[(run << 4) + nbits], hac->len[(run << 4) + nbits]);
+		put_bits(s, bits, nbits);
+	}
+	if (end0 != 63)
+		put_bits(s, hac->code[0x00], hac->len[0x00]);
+	return du[0];
+}
+
+/* codec/jpeg_write.c:172-366 */
+static int write_jpg_core(jw_sink *s, int width, int height, int comp, const void *data, int quality)
+{
+	static const float aasf[8] = {1.0f * 2.828427125f,         1.387039845f * 2.828427125f, 1.306562965f * 2.828427125f, 1.175875602f * 2.828427125f,
+											1.0f * 2.828427125f,         0.785694958f * 2.828427125f, 0.541196100f * 2.828427125f, 0.275899379f * 2.828427125f};
+	enc_table ydc, yac, cdc, cac;
+	float fdtbl_y[64], fdtbl_c[64];
+	unsigned char ytab[64], ctab[64];
+	int i, row, col, k, subsample;
+
+	if (!data || !width || !height || comp > 4 || comp < 1)
+		return 0;
+
+	quality = quality ? quality : 90;
+	subsample = quality <= 90 ? 1 : 0;
+	quality = quality < 1 ? 1 : (quality > 100 ? 100 : quality);
+	quality = quality < 50 ? 5000 / quality : 200 - quality * 2;
+
+	for (i = 0; i < 64; ++i) {
+		int yq = (k_qt_lum[i] * quality + 50) / 100;
+		int cq = (k_qt_chr[i] * quality + 50) / 100;
+		ytab[k_zigzag_of[i]] = (unsigned char)(yq < 1 ? 1 : (yq > 255 ? 255 : yq));
+		ctab[k_zigzag_of[i]] = (unsigned char)(cq < 1 ? 1 : (cq > 255 ? 255 : cq));
+	}
+	for (row = 0, k = 0; row < 8; ++row)
+		for (col = 0; col < 8; ++col, ++k) {
+			fdtbl_y[k] = 1 / (ytab[k_zigzag_of[k]] * aasf[row] * aasf[col]);
+			fdtbl_c[k] = 1 / (ctab[k_zigzag_of[k]] * aasf[row] * aasf[col]);
+		}
+	make_enc_table(&ydc, k_dc_lum_bits, k_dc_vals);
+	make_enc_table(&cdc, k_dc_chr_bits, k_dc_vals);
+	make_enc_table(&yac, k_ac_lum_bits, k_ac_lum_vals);
+	make_enc_table(&cac, k_ac_chr_bits, k_ac_chr_vals);
+
+	/* headers (codec/jpeg_write.c:245-268) */
+	{
+		static const unsigned char soi_app0_dqt[] = {0xFF, 0xD8, 0xFF, 0xE0, 0, 0x10, 'J', 'F', 'I', 'F', 0, 1, 1, 0, 0, 1, 0, 1, 0, 0, 0xFF, 0xDB, 0, 0x84, 0};
+		static const unsigned char sos[] = {0xFF, 0xDA, 0, 0xC, 3, 1, 0, 2, 0x11, 3, 0x11, 0, 0x3F, 0};
+		unsigned char sof_dht[24] = {0xFF, 0xC0, 0, 0x11, 8, 0, 0, 0, 0, 3, 1, 0, 0, 2, 0x11, 1, 3, 0x11, 1, 0xFF, 0xC4, 0x01, 0xA2, 0};
+		sof_dht[5] = (unsigned char)(height >> 8);
+		sof_dht[6] = (unsigned char)(height & 0xff);
+		sof_dht[7] = (unsigned char)(width >> 8);
+		sof_dht[8] = (unsigned char)(width & 0xff);
+		sof_dht[11] = (unsigned char)(subsample ? 0x22 : 0x11);
+		sink_bytes(s, soi_app0_dqt, (int)sizeof(soi_app0_dqt));
+		sink_bytes(s, ytab, 64);
+		sink_byte(s, 1);
+		sink_bytes(s, ctab, 64);
+		sink_bytes(s, sof_dht, (int)sizeof(sof_dht));
+		sink_bytes(s, k_dc_lum_bits + 1, 16);
+		sink_bytes(s, k_dc_vals, 12);
+		sink_byte(s, 0x10);
+		sink_bytes(s, k_ac_lum_bits + 1, 16);
+		sink_bytes(s, k_ac_lum_vals, 162);
+		sink_byte(s, 1);
+		sink_bytes(s, k_dc_chr_bits + 1, 16);
+		sink_bytes(s, k_dc_vals, 12);
+		sink_byte(s, 0x11);
+		sink_bytes(s, k_ac_chr_bits + 1, 16);
+		sink_bytes(s, k_ac_chr_vals, 162);
+		sink_bytes(s, sos, (int)sizeof(sos));
+	}
+
+	{
+		int dcy = 0, dcu = 0, dcv = 0;
+		const int og = comp > 2 ? 1 : 0, ob = comp > 2 ? 2 : 0; /* comp 1/2: grey replicated */
+		const unsigned char *px = (const unsigned char *)data;
+		const int mcu = subsample ? 16 : 8;
+		int x, y, pos, du[64];
+		float Y[256], U[256], V[256];
+		s->bit_buf = 0;
+		s->bit_cnt = 0;
+		for (y = 0; y < height; y += mcu)
+			for (x = 0; x < width; x += mcu) {
+				for (row = y, pos = 0; row < y + mcu; ++row) {
+					int crow = row < height ? row : height - 1; /* replicate the last row / column */
+					int base = (g_flip_on_write ? (height - 1 - crow) : crow) * width * comp;
+					for (col = x; col < x + mcu; ++col, ++pos) {
+						int p = base + (col < width ? col : width - 1) * comp;
+						float r = px[p], g = px[p + og], b = px[p + ob];
+						Y[pos] = +0.29900f * r + 0.58700f * g + 0.11400f * b - 128;
+						U[pos] = -0.16874f * r - 0.33126f * g + 0.50000f * b;
+						V[pos] = +0.50000f * r - 0.41869f * g - 0.08131f * b;
+					}
+				}
+				if (subsample) {
+					float su[64], sv[64];
+					int yy, xx;
+					transform_du(Y + 0, 16, fdtbl_y, du);
+					dcy = emit_du(s, du, dcy, &ydc, &yac);
+					transform_du(Y + 8, 16, fdtbl_y, du);
+					dcy = emit_du(s, du, dcy, &ydc, &yac);
+					transform_du(Y + 128, 16, fdtbl_y, du);
+					dcy = emit_du(s, du, dcy, &ydc, &yac);
+					transform_du(Y + 136, 16, fdtbl_y, du);
+					dcy = emit_du(s, du, dcy, &ydc, &yac);
+					for (yy = 0, pos = 0; yy < 8; ++yy)
+						for (xx = 0; xx < 8; ++xx, ++pos) {
+							int j = yy * 32 + xx * 2;
+							su[pos] = (U[j + 0] + U[j + 1] + U[j + 16] + U[j + 17]) * 0.25f;
+							sv[pos] = (V[j + 0] + V[j + 1] + V[j + 16] + V[j + 17]) * 0.25f;
+						}
+					transform_du(su, 8, fdtbl_c, du);
+					dcu = emit_du(s, du, dcu, &cdc, &cac);
+					transform_du(sv, 8, fdtbl_c, du);
+					dcv = emit_du(s, du, dcv, &cdc, &cac);
+				} else {
+					transform_du(Y, 8, fdtbl_y, du);
+					dcy = emit_du(s, du, dcy, &ydc, &yac);
+					transform_du(U, 8, fdtbl_c, du);
+					dcu = emit_du(s, du, dcu, &cdc, &cac);
+					transform_du(V, 8, fdtbl_c, du);
+					dcv = emit_du(s, du, dcv, &cdc, &cac);
+				}
+			}
+		put_bits(s, 0x7F, 7); /* pad to a byte boundary with ones */
+	}
+	sink_byte(s, 0xFF);
+	sink_byte(s, 0xD9);
+	sink_flush(s);
+	return 1;
+}
+
+int stbi_write_jpg_to_func(stbi_write_func *func, void *context, int x, int y, int comp, const void *data, int quality)
+{
+	jw_sink *s;
+	int ok;
+	if (!func)
+		return 0;
+	s = (jw_sink *)calloc(1, sizeof(*s));
+	if (!s)
+		return 0;
+	s->func = func;
+	s->context = context;
+	ok = write_jpg_core(s, x, y, comp, data, quality);
+	free(s);
+	return ok;
+}
+
+static void file_sink(void *context, void *data, int size) { fwrite(data, 1, (size_t)size, (FILE *)context); }
+
+int stbi_write_jpg(char const *filename, int x, int y, int comp, const void *data, int quality)
+{
+	FILE *f = fopen(filename, "wb");
+	int ok;
+	if (!f)
+		return 0;
+	ok = stbi_write_jpg_to_func(file_sink, f, x, y, comp, data, quality);
+	fclose(f);
+	return ok;
+}

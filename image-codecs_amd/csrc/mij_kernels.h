@@ -1,0 +1,707 @@
+/*
+ * mij_kernels.h -- gfx950 (CDNA4, wave64) device code of the JPEG back end.
+ *
+ * Everything the reference does after the Huffman walk, as integer HIP kernels:
+ *   de-quantisation        codec/jpeg.c:325,345,365 / :1319-1324     (int16 wrap, v_pk_mul_lo_u16)
+ *   8x8 integer IDCT       codec/jpeg.c:578-679                      (v_dot2_i32_i16 form, see idct_*)
+ *   chroma upsampling      codec/jpeg.c:1765-1840,1962-1971, rows :2301-2319
+ *   YCbCr->RGB + the other colour branches  codec/jpeg.c:1976-2018, :2320-2431
+ *
+ * Two families:
+ *   k_fused420   one pass, coefficients -> interleaved pixels, for 3-component h2v2 YCbCr
+ *                (the north-star configuration).  A 256-thread workgroup owns a band of MCU rows
+ *                of one image and marches down it; per MCU row: phase A = one 8x8 block per lane
+ *                (coefficients straight from HBM in the tile layout of mij.h, fully coalesced),
+ *                IDCT result to LDS planes; phase B = 4-pixel strips x row pairs, h2v2 filter as
+ *                one v_dot4_u32_u8 per sample, colour as v_dot2_i32_i16, 12-byte stores that are
+ *                contiguous across the wave.
+ *   k_idct_planes + k_resample_color   the general two-pass path for every other sampling /
+ *                colour layout the reference accepts (planar u8 intermediate in HBM).
+ *
+ * No MFMA (the butterflies are not a dense contraction), no CUDA-compat headers, no fallbacks.
+ */
+#ifndef MIJ_KERNELS_H
+#define MIJ_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mij.h"
+
+namespace mij {
+
+/* ------------------------------------------------------------------ device-side descriptors */
+
+struct DevComp {
+	int32_t h, v, x, y;   /* sampling factors, effective size in samples */
+	int32_t bw, bh;       /* padded size in blocks */
+	int32_t hs, vs;       /* h_max / h, v_max / v (integer division, codec/jpeg.c:2273-2274) */
+	uint64_t coef_off;    /* byte offset of the component's tile-layout plane in the coefficient arena */
+	uint64_t plane_off;   /* byte offset of its u8 sample plane in the scratch arena (two-pass path) */
+};
+
+struct DevImage {
+	int32_t width, height, n_out, color;
+	int32_t ncomp, flags, mcu_x, mcu_y;
+	uint64_t out_off; /* byte offset of the pixels in the output arena */
+	uint64_t plane_bytes_total;
+	DevComp comp[4];
+	uint32_t dq[4][32]; /* per component: quantisation table as u16 pairs in in-block position order P */
+};
+
+struct WorkBand { /* one workgroup of k_fused420 */
+	uint32_t img, m0, m1, pad;
+};
+struct WorkIdct { /* one workgroup of k_idct_planes: 256 consecutive blocks of one component */
+	uint32_t img, comp, first, pad;
+};
+
+/* ------------------------------------------------------------------ small helpers */
+
+typedef short v2s __attribute__((ext_vector_type(2)));
+typedef unsigned short v2u __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ constexpr uint32_t pk16(int lo, int hi) { return (uint32_t)(uint16_t)lo | ((uint32_t)(uint16_t)hi << 16); }
+
+/* a.lo*b.lo + a.hi*b.hi + acc in wrapping 32-bit (v_dot2_i32_i16, no clamp) */
+__device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int acc)
+{
+	return __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, a), __builtin_bit_cast(v2s, b), acc, false);
+}
+/* sum of four u8*u8 products + acc (v_dot4_u32_u8) */
+__device__ __forceinline__ uint32_t dot4(uint32_t a, uint32_t b, uint32_t acc) { return __builtin_amdgcn_udot4(a, b, acc, false); }
+/* two int16 wrapping multiplies (v_pk_mul_lo_u16): the reference's (short)(coef * dequant) */
+__device__ __forceinline__ uint32_t pkmul(uint32_t a, uint32_t b)
+{
+	return __builtin_bit_cast(uint32_t, (v2u)(__builtin_bit_cast(v2u, a) * __builtin_bit_cast(v2u, b)));
+}
+/* saturating pack of two i32 to i16 pairs (v_cvt_pk_i16_i32); exact whenever both fit */
+__device__ __forceinline__ uint32_t pack_i16(int lo, int hi) { return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(lo, hi)); }
+
+__device__ __forceinline__ int clamp255(int x) { return x < 0 ? 0 : (x > 255 ? 255 : x); }
+
+/* ------------------------------------------------------------------ IDCT (codec/jpeg.c:578-679)
+ *
+ * STBI__IDCT_1D is linear over the ring Z/2^32, so its eight outputs are fixed integer
+ * combinations of the inputs (derived from the macro, verified exhaustively in tests):
+ *     x0 = 4096 s0 + 5352 s2 + 4096 s4 + 2217 s6          t3 = 5683 s1 + 4816 s3 + 3219 s5 + 1131 s7
+ *     x1 = 4096 s0 + 2217 s2 - 4096 s4 - 5350 s6          t2 = 4816 s1 - 1129 s3 - 5681 s5 - 3218 s7
+ *     x2 = 4096 s0 - 2217 s2 - 4096 s4 + 5350 s6          t1 = 3219 s1 - 5681 s3 + 1132 s5 + 4816 s7
+ *     x3 = 4096 s0 - 5352 s2 + 4096 s4 - 2217 s6          t0 = 1131 s1 - 3218 s3 + 4816 s5 - 5680 s7
+ * out = (x0+t3, x1+t2, x2+t1, x3+t0, x3-t0, x2-t1, x1-t2, x0-t3) + bias, then >> shift.
+ * With the inputs paired as (s0,s4) (s2,s6) (s1,s3) (s5,s7) -- exactly how the tile layout stores
+ * a column -- that is 14 v_dot2 + 8 add/sub + 8 shifts per 1-D transform.
+ */
+struct Idct1D {
+	int o[8];
+};
+
+template <int BIAS, int SHIFT>
+__device__ __forceinline__ Idct1D idct1d_packed(uint32_t d04, uint32_t d26, uint32_t d13, uint32_t d57)
+{
+	int e0 = dot2(d04, pk16(4096, 4096), BIAS);
+	int e1 = dot2(d04, pk16(4096, -4096), BIAS);
+	int x0 = dot2(d26, pk16(5352, 2217), e0);
+	int x3 = dot2(d26, pk16(-5352, -2217), e0);
+	int x1 = dot2(d26, pk16(2217, -5350), e1);
+	int x2 = dot2(d26, pk16(-2217, 5350), e1);
+	int t3 = dot2(d13, pk16(5683, 4816), dot2(d57, pk16(3219, 1131), 0));
+	int t2 = dot2(d13, pk16(4816, -1129), dot2(d57, pk16(-5681, -3218), 0));
+	int t1 = dot2(d13, pk16(3219, -5681), dot2(d57, pk16(1132, 4816), 0));
+	int t0 = dot2(d13, pk16(1131, -3218), dot2(d57, pk16(4816, -5680), 0));
+	Idct1D r;
+	r.o[0] = (int)((uint32_t)x0 + (uint32_t)t3) >> SHIFT;
+	r.o[7] = (int)((uint32_t)x0 - (uint32_t)t3) >> SHIFT;
+	r.o[1] = (int)((uint32_t)x1 + (uint32_t)t2) >> SHIFT;
+	r.o[6] = (int)((uint32_t)x1 - (uint32_t)t2) >> SHIFT;
+	r.o[2] = (int)((uint32_t)x2 + (uint32_t)t1) >> SHIFT;
+	r.o[5] = (int)((uint32_t)x2 - (uint32_t)t1) >> SHIFT;
+	r.o[3] = (int)((uint32_t)x3 + (uint32_t)t0) >> SHIFT;
+	r.o[4] = (int)((uint32_t)x3 - (uint32_t)t0) >> SHIFT;
+	return r;
+}
+
+/* the same transform on full 32-bit inputs, all arithmetic wrapping (unsigned) like the
+ * reference's int math on out-of-range streams */
+template <int BIAS, int SHIFT>
+__device__ __forceinline__ Idct1D idct1d_wide(int s0, int s1, int s2, int s3, int s4, int s5, int s6, int s7)
+{
+	uint32_t u0 = s0, u1 = s1, u2 = s2, u3 = s3, u4 = s4, u5 = s5, u6 = s6, u7 = s7;
+	uint32_t x0 = 4096u * u0 + 5352u * u2 + 4096u * u4 + 2217u * u6 + (uint32_t)BIAS;
+	uint32_t x1 = 4096u * u0 + 2217u * u2 - 4096u * u4 - 5350u * u6 + (uint32_t)BIAS;
+	uint32_t x2 = 4096u * u0 - 2217u * u2 - 4096u * u4 + 5350u * u6 + (uint32_t)BIAS;
+	uint32_t x3 = 4096u * u0 - 5352u * u2 + 4096u * u4 - 2217u * u6 + (uint32_t)BIAS;
+	uint32_t t3 = 5683u * u1 + 4816u * u3 + 3219u * u5 + 1131u * u7;
+	uint32_t t2 = 4816u * u1 - 1129u * u3 - 5681u * u5 - 3218u * u7;
+	uint32_t t1 = 3219u * u1 - 5681u * u3 + 1132u * u5 + 4816u * u7;
+	uint32_t t0 = 1131u * u1 - 3218u * u3 + 4816u * u5 - 5680u * u7;
+	Idct1D r;
+	r.o[0] = (int)(x0 + t3) >> SHIFT;
+	r.o[7] = (int)(x0 - t3) >> SHIFT;
+	r.o[1] = (int)(x1 + t2) >> SHIFT;
+	r.o[6] = (int)(x1 - t2) >> SHIFT;
+	r.o[2] = (int)(x2 + t1) >> SHIFT;
+	r.o[5] = (int)(x2 - t1) >> SHIFT;
+	r.o[3] = (int)(x3 + t0) >> SHIFT;
+	r.o[4] = (int)(x3 - t0) >> SHIFT;
+	return r;
+}
+
+#define MIJ_PASS2_BIAS (65536 + (128 << 17)) /* codec/jpeg.c:664 */
+
+__device__ __forceinline__ void pack_row(const Idct1D &r, uint32_t &lo, uint32_t &hi)
+{
+	lo = (uint32_t)clamp255(r.o[0]) | ((uint32_t)clamp255(r.o[1]) << 8) | ((uint32_t)clamp255(r.o[2]) << 16) | ((uint32_t)clamp255(r.o[3]) << 24);
+	hi = (uint32_t)clamp255(r.o[4]) | ((uint32_t)clamp255(r.o[5]) << 8) | ((uint32_t)clamp255(r.o[6]) << 16) | ((uint32_t)clamp255(r.o[7]) << 24);
+}
+
+/*
+ * One 8x8 block per lane.  c[k] = column k of the quantised block as stored in the tile layout
+ * (.x=(r0,r4) .y=(r2,r6) .z=(r1,r3) .w=(r5,r7)); dq = the component's table in the same order
+ * (32 dwords, wave-uniform -> scalar registers).  rows[i] = the 8 output samples of row i.
+ * WIDE = false requires every first-pass output to fit int16 (host guarantee, mij.h).
+ */
+template <bool WIDE>
+__device__ __forceinline__ void idct_block(const uint4 (&c)[8], const uint32_t *__restrict__ dq, uint2 (&rows)[8])
+{
+	if constexpr (!WIDE) {
+		/* pk[i][g]: row i, column pair g = (0,4) (2,6) (1,3) (5,7) */
+		uint32_t pk[8][4];
+		const int ca[4] = {0, 2, 1, 5}, cb[4] = {4, 6, 3, 7};
+#pragma unroll
+		for (int g = 0; g < 4; ++g) {
+			const int a = ca[g], b = cb[g];
+			Idct1D va = idct1d_packed<512, 10>(pkmul(c[a].x, dq[4 * a + 0]), pkmul(c[a].y, dq[4 * a + 1]), pkmul(c[a].z, dq[4 * a + 2]),
+														  pkmul(c[a].w, dq[4 * a + 3]));
+			Idct1D vb = idct1d_packed<512, 10>(pkmul(c[b].x, dq[4 * b + 0]), pkmul(c[b].y, dq[4 * b + 1]), pkmul(c[b].z, dq[4 * b + 2]),
+														  pkmul(c[b].w, dq[4 * b + 3]));
+#pragma unroll
+			for (int i = 0; i < 8; ++i)
+				pk[i][g] = pack_i16(va.o[i], vb.o[i]);
+		}
+#pragma unroll
+		for (int i = 0; i < 8; ++i) {
+			Idct1D r = idct1d_packed<MIJ_PASS2_BIAS, 17>(pk[i][0], pk[i][1], pk[i][2], pk[i][3]);
+			pack_row(r, rows[i].x, rows[i].y);
+		}
+	} else {
+		int v[8][8]; /* v[row][col] */
+#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+			Idct1D col = idct1d_packed<512, 10>(pkmul(c[k].x, dq[4 * k + 0]), pkmul(c[k].y, dq[4 * k + 1]), pkmul(c[k].z, dq[4 * k + 2]),
+															pkmul(c[k].w, dq[4 * k + 3]));
+#pragma unroll
+			for (int i = 0; i < 8; ++i)
+				v[i][k] = col.o[i];
+		}
+#pragma unroll
+		for (int i = 0; i < 8; ++i) {
+			Idct1D r = idct1d_wide<MIJ_PASS2_BIAS, 17>(v[i][0], v[i][1], v[i][2], v[i][3], v[i][4], v[i][5], v[i][6], v[i][7]);
+			pack_row(r, rows[i].x, rows[i].y);
+		}
+	}
+}
+
+/* coefficient chunk address of block L, chunk k, in a tile-layout plane (bytes) */
+__device__ __forceinline__ size_t tile_chunk_off(uint32_t L, int k) { return ((size_t)(L >> 6) << 13) + ((size_t)k << 10) + ((size_t)(L & 63u) << 4); }
+
+__device__ __forceinline__ void load_block(const uint8_t *__restrict__ plane, uint32_t L, uint4 (&c)[8])
+{
+#pragma unroll
+	for (int k = 0; k < 8; ++k)
+		c[k] = *reinterpret_cast<const uint4 *>(plane + tile_chunk_off(L, k));
+}
+
+/* ------------------------------------------------------------------ colour (codec/jpeg.c:1976-2018)
+ * All four stbi__float2fixed constants are multiples of 256, so the >>20 of the reference equals
+ * >>12 of the same sum divided by 256:  r = (4096 y + 2048 + 5743 cr') >> 12, etc. with
+ * cr' = cr - 128; the green channel's "& 0xffff0000" becomes "& ~255" on the cb term.
+ */
+__device__ __forceinline__ void ycbcr_to_rgb(int y, int cb, int cr, int &r, int &g, int &b)
+{
+	int yf = (y << 12) + 2048;
+	int crc = cr - 128, cbc = cb - 128;
+	r = clamp255((yf + crc * 5743) >> 12);
+	g = clamp255((yf + crc * -2925 + ((cbc * -1410) & ~255)) >> 12);
+	b = clamp255((yf + cbc * 7258) >> 12);
+}
+
+__device__ __forceinline__ int compute_y(int r, int g, int b) { return ((r * 77) + (g * 150) + (29 * b)) >> 8 & 255; } /* common.c:173 */
+__device__ __forceinline__ int blinn8(int x, int y)                                                                  /* codec/jpeg.c:2218 */
+{
+	unsigned t = (unsigned)(x * y + 128);
+	return (int)((t + (t >> 8)) >> 8) & 255;
+}
+
+/* ------------------------------------------------------------------ generic sampling (two-pass path)
+ *
+ * Row scheduling of load_jpeg_image (codec/jpeg.c:2273-2318) in closed form, for any vs in 1..4:
+ *   g = (r + (vs>>1)) / vs, phase = (r + (vs>>1)) % vs, y_bot = phase >= (vs>>1)
+ *   line1 = min(g, y-1), line0 = g ? min(g-1, y-1) : 0;  near = y_bot ? line1 : line0, far = the other.
+ */
+struct RowSel {
+	int near, far;
+};
+__device__ __forceinline__ RowSel select_rows(int r, int vs, int ycomp)
+{
+	int half = vs >> 1;
+	int q = r + half;
+	int g = q / vs, phase = q - g * vs;
+	int l1 = min(g, ycomp - 1);
+	int l0 = g ? min(g - 1, ycomp - 1) : 0;
+	RowSel s;
+	if (phase >= half) {
+		s.near = l1;
+		s.far = l0;
+	} else {
+		s.near = l0;
+		s.far = l1;
+	}
+	return s;
+}
+
+/* one up-sampled component sample at output pixel (r, col); P = u8 plane with row pitch w2.
+ * Follows resample_row_1 / _v_2 / _h_2 / _hv_2 / _generic (codec/jpeg.c:1765-1840,1962-1971). */
+template <typename Fetch>
+__device__ __forceinline__ int upsample_at(Fetch P, int hs, int vs, int ycomp, int width, int r, int col)
+{
+	RowSel rs = select_rows(r, vs, ycomp);
+	int w = (width + hs - 1) / hs; /* w_lores, :2276 */
+	if (hs == 1 && vs == 1)
+		return P(rs.near, col);
+	if (hs == 1 && vs == 2)
+		return (3 * P(rs.near, col) + P(rs.far, col) + 2) >> 2;
+	if (hs == 2 && vs == 1) {
+		int i = col >> 1;
+		if (w == 1 || col == 0)
+			return P(rs.near, 0);
+		if (col == 2 * w - 1)
+			return P(rs.near, w - 1);
+		if (col == 2 * w - 2) /* the reference's right-edge form, :1805 */
+			return (3 * P(rs.near, w - 2) + P(rs.near, w - 1) + 2) >> 2;
+		if (col & 1)
+			return (3 * P(rs.near, i) + P(rs.near, i + 1) + 2) >> 2;
+		return (3 * P(rs.near, i) + P(rs.near, i - 1) + 2) >> 2;
+	}
+	if (hs == 2 && vs == 2) {
+		int i = col >> 1;
+		int j = (col & 1) ? min(i + 1, w - 1) : max(i - 1, 0);
+		int ti = 3 * P(rs.near, i) + P(rs.far, i);
+		int tj = 3 * P(rs.near, j) + P(rs.far, j);
+		return (3 * ti + tj + 8) >> 4; /* == (t+2)>>2 at both ends and for w == 1, :1820-1835 */
+	}
+	return P(rs.near, col / hs);
+}
+
+/* the colour branches of load_jpeg_image (codec/jpeg.c:2320-2431); s[] = up-sampled components */
+__device__ __forceinline__ void store_pixel(uint8_t *__restrict__ out, int n, int color, const int (&s)[4])
+{
+	int r, g, b;
+	if (n >= 3) {
+		switch (color) {
+		case MIJ_COLOR_YCBCR:
+		case MIJ_COLOR_YCBCRA:
+			ycbcr_to_rgb(s[0], s[1], s[2], r, g, b);
+			break;
+		case MIJ_COLOR_RGB:
+			r = s[0], g = s[1], b = s[2];
+			break;
+		case MIJ_COLOR_CMYK:
+			r = blinn8(s[0], s[3]), g = blinn8(s[1], s[3]), b = blinn8(s[2], s[3]);
+			break;
+		case MIJ_COLOR_YCCK:
+			ycbcr_to_rgb(s[0], s[1], s[2], r, g, b);
+			r = blinn8(255 - r, s[3]), g = blinn8(255 - g, s[3]), b = blinn8(255 - b, s[3]);
+			break;
+		default: /* grey */
+			r = g = b = s[0];
+			break;
+		}
+		out[0] = (uint8_t)r;
+		out[1] = (uint8_t)g;
+		out[2] = (uint8_t)b;
+		if (n == 4)
+			out[3] = 255;
+	} else {
+		int y;
+		switch (color) {
+		case MIJ_COLOR_RGB:
+			y = compute_y(s[0], s[1], s[2]);
+			break;
+		case MIJ_COLOR_CMYK:
+			y = compute_y(blinn8(s[0], s[3]), blinn8(s[1], s[3]), blinn8(s[2], s[3]));
+			break;
+		case MIJ_COLOR_YCCK:
+			y = blinn8(255 - s[0], s[3]);
+			break;
+		default: /* grey, YCbCr luma-only, YCbCr+A */
+			y = s[0];
+			break;
+		}
+		out[0] = (uint8_t)y;
+		if (n == 2)
+			out[1] = 255;
+	}
+}
+
+/* which components a colour mode reads */
+__device__ __forceinline__ int comps_needed(int color, int n, int ncomp)
+{
+	if (color == MIJ_COLOR_GREY)
+		return 1;
+	if (n < 3 && color == MIJ_COLOR_YCBCRA)
+		return 1;
+	if (color == MIJ_COLOR_YCBCRA && n >= 3)
+		return 3;
+	return ncomp;
+}
+
+/* ------------------------------------------------------------------ two-pass path, pass 1 */
+
+template <bool WIDE>
+__global__ __launch_bounds__(256) void k_idct_planes(const DevImage *__restrict__ imgs, const WorkIdct *__restrict__ work, const uint8_t *__restrict__ coef,
+																	  uint8_t *__restrict__ planes)
+{
+	const WorkIdct wk = work[blockIdx.x];
+	const DevImage &im = imgs[wk.img];
+	const DevComp &cp = im.comp[wk.comp];
+	const uint32_t nblk = (uint32_t)(cp.bw * cp.bh);
+	const uint32_t L = wk.first + threadIdx.x;
+	if (L >= nblk)
+		return;
+	uint4 c[8];
+	load_block(coef + cp.coef_off, L, c);
+	uint2 rows[8];
+	idct_block<WIDE>(c, im.dq[wk.comp], rows);
+	const uint32_t by = L / (uint32_t)cp.bw, bx = L - by * (uint32_t)cp.bw;
+	const size_t w2 = (size_t)cp.bw * 8;
+	uint8_t *dst = planes + cp.plane_off + (size_t)by * 8 * w2 + (size_t)bx * 8;
+#pragma unroll
+	for (int i = 0; i < 8; ++i)
+		*reinterpret_cast<uint2 *>(dst + (size_t)i * w2) = rows[i];
+}
+
+/* ------------------------------------------------------------------ two-pass path, pass 2 */
+
+struct PlaneFetch {
+	const uint8_t *p;
+	int w2;
+	long limit; /* last valid byte index (fractional sampling ratios read past a row, as the reference does) */
+	__device__ __forceinline__ int operator()(int row, int col) const
+	{
+		long idx = (long)row * w2 + col;
+		idx = idx < 0 ? 0 : (idx > limit ? limit : idx);
+		return p[idx];
+	}
+};
+
+__global__ __launch_bounds__(256) void k_resample_color(const DevImage *__restrict__ imgs, uint32_t img, const uint8_t *__restrict__ planes,
+																		  uint8_t *__restrict__ outbase)
+{
+	const DevImage &im = imgs[img];
+	const int col = blockIdx.x * 256 + threadIdx.x;
+	const int r = blockIdx.y;
+	if (col >= im.width)
+		return;
+	const int need = comps_needed(im.color, im.n_out, im.ncomp);
+	int s[4] = {0, 0, 0, 0};
+	for (int k = 0; k < need; ++k) {
+		const DevComp &cp = im.comp[k];
+		PlaneFetch P;
+		P.p = planes + cp.plane_off;
+		P.w2 = cp.bw * 8;
+		P.limit = (long)cp.bw * 8 * cp.bh * 8 - 1;
+		s[k] = upsample_at(P, cp.hs, cp.vs, cp.y, im.width, r, col);
+	}
+	uint8_t *out = outbase + im.out_off + ((size_t)r * im.width + col) * im.n_out;
+	store_pixel(out, im.n_out, im.color, s);
+}
+
+/* ------------------------------------------------------------------ fused h2v2 YCbCr kernel
+ *
+ * LDS (dynamic, bytes; YP = 16*mcu_x, CP = 8*mcu_x):
+ *   Y[16][YP]  Cb[8][CP]  Cr[8][CP]            samples of the current MCU row
+ *   saveY[2][YP] saveCb[2][CP] saveCr[2][CP]   last Y / chroma row of the previous MCU row (ping-pong)
+ * Chroma rows are addressed by absolute row C: rows of the current MCU row come from the planes,
+ * row 8m-1 from the save buffer; row pairs (2C-1, 2C) only ever need chroma rows C-1 and C.
+ */
+struct Fused420Lds {
+	uint8_t *Y, *Cb, *Cr, *saveY[2], *saveCb[2], *saveCr[2];
+	int YP, CP;
+};
+
+__device__ __forceinline__ size_t fused420_lds_bytes(int mcu_x) { return (size_t)mcu_x * (16 * 16 + 2 * 8 * 8 + 2 * 16 + 4 * 8); }
+
+template <int NOUT>
+__device__ __forceinline__ void store_rgb_px(uint8_t *__restrict__ p, int r, int g, int b)
+{
+	p[0] = (uint8_t)r;
+	p[1] = (uint8_t)g;
+	p[2] = (uint8_t)b;
+	if (NOUT == 4)
+		p[3] = 255;
+}
+
+/* careful per-pixel path for the image's left/right edge strips and unaligned widths:
+ * the same closed form as upsample_at(hs=2,vs=2) with the chroma rows already resolved */
+template <int NOUT>
+__device__ __forceinline__ void fused420_pixel(const uint8_t *yrow, const uint8_t *cbA, const uint8_t *cbB, const uint8_t *crA, const uint8_t *crB, int nearIsB,
+															  int wc, int x, uint8_t *__restrict__ dst)
+{
+	int i = x >> 1;
+	int j = (x & 1) ? min(i + 1, wc - 1) : max(i - 1, 0);
+	const uint8_t *cbN = nearIsB ? cbB : cbA, *cbF = nearIsB ? cbA : cbB;
+	const uint8_t *crN = nearIsB ? crB : crA, *crF = nearIsB ? crA : crB;
+	int tbi = 3 * cbN[i] + cbF[i], tbj = 3 * cbN[j] + cbF[j];
+	int tri = 3 * crN[i] + crF[i], trj = 3 * crN[j] + crF[j];
+	int cb = (3 * tbi + tbj + 8) >> 4, cr = (3 * tri + trj + 8) >> 4;
+	int r, g, b;
+	ycbcr_to_rgb(yrow[x], cb, cr, r, g, b);
+	store_rgb_px<NOUT>(dst + (size_t)x * NOUT, r, g, b);
+}
+
+/* colour for one pixel from packed operands: pcr = (cr | y << 16), pcb = (cb | y << 16) */
+__device__ __forceinline__ uint32_t color_px(uint32_t pcr, uint32_t pcb)
+{
+	/* r = (4096 y + 2048 + 5743 (cr-128)) >> 12 and friends, constants folded into the accumulator */
+	int r = dot2(pcr, pk16(5743, 4096), 2048 - 128 * 5743) >> 12;
+	int b = dot2(pcb, pk16(7258, 4096), 2048 - 128 * 7258) >> 12;
+	/* ((cb-128) * -1410) & ~255, plus 2048 + 128*2925 = 0x5BE80 split as 0x5BE00 (commutes with the mask) | 0x80 */
+	int t = dot2(pcb, pk16(-1410, 0), 128 * 1410 + 0x5BE00);
+	int g = dot2(pcr, pk16(-2925, 4096), (t & ~255) | 0x80) >> 12;
+	return (uint32_t)clamp255(r) | ((uint32_t)clamp255(g) << 8) | ((uint32_t)clamp255(b) << 16);
+}
+
+template <int NOUT, bool WIDE>
+__global__ __launch_bounds__(256) void k_fused420(const DevImage *__restrict__ imgs, const WorkBand *__restrict__ work, const uint8_t *__restrict__ coef,
+																  uint8_t *__restrict__ outbase)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	const WorkBand wk = work[blockIdx.x];
+	const DevImage &im = imgs[wk.img];
+	const int tid = threadIdx.x;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+
+	const int mcu_x = im.mcu_x;
+	const int W = im.width, H = im.height;
+	const int YP = 16 * mcu_x, CP = 8 * mcu_x;
+	const int wc = (W + 1) >> 1;    /* w_lores of the chroma planes, codec/jpeg.c:2276 */
+	const int hc = im.comp[1].y;    /* effective chroma rows */
+	const int bwY = 2 * mcu_x, bwC = mcu_x;
+
+	uint8_t *const sY = lds;
+	uint8_t *const sCb = sY + 16 * YP;
+	uint8_t *const sCr = sCb + 8 * CP;
+	uint8_t *const saveY = sCr + 8 * CP;  /* [2][YP] */
+	uint8_t *const saveCb = saveY + 2 * YP; /* [2][CP] */
+	uint8_t *const saveCr = saveCb + 2 * CP;
+
+	const uint8_t *const coefY = coef + im.comp[0].coef_off;
+	const uint8_t *const coefCb = coef + im.comp[1].coef_off;
+	const uint8_t *const coefCr = coef + im.comp[2].coef_off;
+	uint8_t *const out = outbase + im.out_off;
+	const size_t opitch = (size_t)W * NOUT;
+
+	const int m0 = (int)wk.m0, m1 = (int)wk.m1;
+	const int row_lo = 16 * m0, row_hi = min(16 * m1, H); /* rows this band emits */
+	const int nYw = (4 * mcu_x + 63) >> 6, nCw = (mcu_x + 63) >> 6;
+	const int nstrip = (W + 3) >> 2;
+	const bool aligned = (NOUT == 4) || ((W & 3) == 0);
+	int sv = 0; /* which save buffer holds the previous MCU row's last rows */
+
+	/* ---- chroma-only IDCT of block row mc, keeping sample row `keep` in dstCb/dstCr (halo rows) */
+	auto chroma_halo = [&](int mc, int keep, uint8_t *dstCb, uint8_t *dstCr) {
+		for (int ww = wave; ww < 2 * nCw; ww += 4) {
+			const int comp = ww < nCw ? 1 : 2;
+			const int bx = (comp == 1 ? ww : ww - nCw) * 64 + lane;
+			if (bx < bwC) {
+				uint4 c[8];
+				uint2 rows[8];
+				load_block(comp == 1 ? coefCb : coefCr, (uint32_t)(mc * bwC + bx), c);
+				idct_block<WIDE>(c, im.dq[comp], rows);
+				*reinterpret_cast<uint2 *>((comp == 1 ? dstCb : dstCr) + 8 * bx) = keep ? rows[7] : rows[0];
+			}
+		}
+	};
+
+	/* ---- phase B for chroma row C: emits output rows 2C-1 and 2C (those inside the band) */
+	auto emit_pair = [&](int C, const uint8_t *cbA, const uint8_t *cbB, const uint8_t *crA, const uint8_t *crB, const uint8_t *yA, const uint8_t *yB) {
+		const int ra = 2 * C - 1, rb = 2 * C;
+		const bool doA = ra >= row_lo && ra < row_hi, doB = rb >= row_lo && rb < row_hi;
+		if (!doA && !doB)
+			return;
+		for (int s = tid; s < nstrip; s += 256) {
+			const int x0 = 4 * s, i0 = 2 * s;
+			const bool interior = aligned && s >= 1 && (i0 + 2 <= wc - 1) && (x0 + 3 <= W - 1);
+			if (interior) {
+				/* bytes (c[i0-1], c[i0], c[i0+1], c[i0+2]) of each chroma row */
+				const int d0 = (i0 - 1) >> 2, sh = (i0 - 1) & 3;
+				const uint32_t *pbA = reinterpret_cast<const uint32_t *>(cbA), *pbB = reinterpret_cast<const uint32_t *>(cbB);
+				const uint32_t *prA = reinterpret_cast<const uint32_t *>(crA), *prB = reinterpret_cast<const uint32_t *>(crB);
+				uint32_t bA, bB, rA, rB;
+				if (sh == 3) {
+					bA = __builtin_amdgcn_alignbyte(pbA[d0 + 1], pbA[d0], 3);
+					bB = __builtin_amdgcn_alignbyte(pbB[d0 + 1], pbB[d0], 3);
+					rA = __builtin_amdgcn_alignbyte(prA[d0 + 1], prA[d0], 3);
+					rB = __builtin_amdgcn_alignbyte(prB[d0 + 1], prB[d0], 3);
+				} else {
+					bA = __builtin_amdgcn_alignbyte(pbA[d0 + 1], pbA[d0], 1);
+					bB = __builtin_amdgcn_alignbyte(pbB[d0 + 1], pbB[d0], 1);
+					rA = __builtin_amdgcn_alignbyte(prA[d0 + 1], prA[d0], 1);
+					rB = __builtin_amdgcn_alignbyte(prB[d0 + 1], prB[d0], 1);
+				}
+				/* V_k = (B[k], A[k], B[k+1], A[k+1]) for k = 0,1,2 (columns i0-1+k, i0+k) */
+				const uint32_t vb0 = __builtin_amdgcn_perm(bA, bB, 0x05010400), vb1 = __builtin_amdgcn_perm(bA, bB, 0x06020501),
+									vb2 = __builtin_amdgcn_perm(bA, bB, 0x07030602);
+				const uint32_t vr0 = __builtin_amdgcn_perm(rA, rB, 0x05010400), vr1 = __builtin_amdgcn_perm(rA, rB, 0x06020501),
+									vr2 = __builtin_amdgcn_perm(rA, rB, 0x07030602);
+				/* weights x16 so that the filtered sample is byte 1 of the dot product:
+				 * (3*(3n+f) + (3n'+f') + 8) >> 4  ==  (16*(9n+3f+3n'+f') + 128) >> 8 */
+				/* row 2C (near = B): pixel x0 uses columns (i0, i0-1), x0+1: (i0, i0+1), x0+2: (i0+1, i0), x0+3: (i0+1, i0+2) */
+				/* weight tables: byte order in V is (B_k, A_k, B_k+1, A_k+1) = (b0,b1,b2,b3) */
+				const uint32_t wBk = 0x10303090u;  /* near=B centre=k   : 9B_k +3A_k +3B_k1 + A_k1 -> b0=144,b1=48,b2=48,b3=16 */
+				const uint32_t wBk1 = 0x30901030u; /* near=B centre=k+1 : 3B_k + A_k +9B_k1 +3A_k1 -> b0=48,b1=16,b2=144,b3=48 */
+				const uint32_t wAk = 0x30109030u;  /* near=A centre=k   : 3B_k +9A_k + B_k1 +3A_k1 -> b0=48,b1=144,b2=16,b3=48 */
+				const uint32_t wAk1 = 0x90303010u; /* near=A centre=k+1 : B_k +3A_k +3B_k1 +9A_k1 -> b0=16,b1=48,b2=48,b3=144 */
+				uint8_t *dA = out + (size_t)ra * opitch + (size_t)x0 * NOUT;
+				uint8_t *dB = out + (size_t)rb * opitch + (size_t)x0 * NOUT;
+				if (doB) {
+					const uint32_t yv = *reinterpret_cast<const uint32_t *>(yB + x0);
+					const uint32_t cb0 = dot4(vb0, wBk1, 128), cb1 = dot4(vb1, wBk, 128), cb2 = dot4(vb1, wBk1, 128), cb3 = dot4(vb2, wBk, 128);
+					const uint32_t cr0 = dot4(vr0, wBk1, 128), cr1 = dot4(vr1, wBk, 128), cr2 = dot4(vr1, wBk1, 128), cr3 = dot4(vr2, wBk, 128);
+					const uint32_t p0 = color_px(__builtin_amdgcn_perm(cr0, yv, 0x0c000c05), __builtin_amdgcn_perm(cb0, yv, 0x0c000c05));
+					const uint32_t p1 = color_px(__builtin_amdgcn_perm(cr1, yv, 0x0c010c05), __builtin_amdgcn_perm(cb1, yv, 0x0c010c05));
+					const uint32_t p2 = color_px(__builtin_amdgcn_perm(cr2, yv, 0x0c020c05), __builtin_amdgcn_perm(cb2, yv, 0x0c020c05));
+					const uint32_t p3 = color_px(__builtin_amdgcn_perm(cr3, yv, 0x0c030c05), __builtin_amdgcn_perm(cb3, yv, 0x0c030c05));
+					if (NOUT == 4) {
+						*reinterpret_cast<uint4 *>(dB) = make_uint4(p0 | 0xff000000u, p1 | 0xff000000u, p2 | 0xff000000u, p3 | 0xff000000u);
+					} else {
+						uint32_t *q = reinterpret_cast<uint32_t *>(dB);
+						q[0] = p0 | (p1 << 24);
+						q[1] = (p1 >> 8) | (p2 << 16);
+						q[2] = (p2 >> 16) | (p3 << 8);
+					}
+				}
+				if (doA) {
+					const uint32_t yv = *reinterpret_cast<const uint32_t *>(yA + x0);
+					const uint32_t cb0 = dot4(vb0, wAk1, 128), cb1 = dot4(vb1, wAk, 128), cb2 = dot4(vb1, wAk1, 128), cb3 = dot4(vb2, wAk, 128);
+					const uint32_t cr0 = dot4(vr0, wAk1, 128), cr1 = dot4(vr1, wAk, 128), cr2 = dot4(vr1, wAk1, 128), cr3 = dot4(vr2, wAk, 128);
+					const uint32_t p0 = color_px(__builtin_amdgcn_perm(cr0, yv, 0x0c000c05), __builtin_amdgcn_perm(cb0, yv, 0x0c000c05));
+					const uint32_t p1 = color_px(__builtin_amdgcn_perm(cr1, yv, 0x0c010c05), __builtin_amdgcn_perm(cb1, yv, 0x0c010c05));
+					const uint32_t p2 = color_px(__builtin_amdgcn_perm(cr2, yv, 0x0c020c05), __builtin_amdgcn_perm(cb2, yv, 0x0c020c05));
+					const uint32_t p3 = color_px(__builtin_amdgcn_perm(cr3, yv, 0x0c030c05), __builtin_amdgcn_perm(cb3, yv, 0x0c030c05));
+					if (NOUT == 4) {
+						*reinterpret_cast<uint4 *>(dA) = make_uint4(p0 | 0xff000000u, p1 | 0xff000000u, p2 | 0xff000000u, p3 | 0xff000000u);
+					} else {
+						uint32_t *q = reinterpret_cast<uint32_t *>(dA);
+						q[0] = p0 | (p1 << 24);
+						q[1] = (p1 >> 8) | (p2 << 16);
+						q[2] = (p2 >> 16) | (p3 << 8);
+					}
+				}
+			} else {
+				const int xe = min(x0 + 4, W);
+				for (int x = x0; x < xe; ++x) {
+					if (doA)
+						fused420_pixel<NOUT>(yA, cbA, cbB, crA, crB, 0, wc, x, out + (size_t)ra * opitch);
+					if (doB)
+						fused420_pixel<NOUT>(yB, cbA, cbB, crA, crB, 1, wc, x, out + (size_t)rb * opitch);
+				}
+			}
+		}
+	};
+
+	/* ---- prologue: chroma row 8*m0-1 from the block row above the band */
+	if (m0 > 0) {
+		chroma_halo(m0 - 1, 7, saveCb + sv * CP, saveCr + sv * CP);
+	}
+
+	for (int m = m0; m < m1; ++m) {
+		__syncthreads(); /* previous phase B (and the prologue) done with the planes / save buffers */
+		/* ---- phase A: IDCT of MCU row m, one block per lane, component uniform per wave */
+		for (int ww = wave; ww < nYw + 2 * nCw; ww += 4) {
+			uint4 c[8];
+			uint2 rows[8];
+			if (ww < nYw) {
+				const int i = ww * 64 + lane; /* block of the two luma block rows 2m, 2m+1 (contiguous in L) */
+				if (i < 2 * bwY) {
+					load_block(coefY, (uint32_t)(2 * m * bwY + i), c);
+					idct_block<WIDE>(c, im.dq[0], rows);
+					const int by = i >= bwY ? 1 : 0, bx = i - by * bwY;
+					uint8_t *dst = sY + (8 * by) * YP + 8 * bx;
+#pragma unroll
+					for (int r = 0; r < 8; ++r)
+						*reinterpret_cast<uint2 *>(dst + r * YP) = rows[r];
+				}
+			} else {
+				const int comp = (ww - nYw) < nCw ? 1 : 2;
+				const int bx = ((ww - nYw) - (comp == 2 ? nCw : 0)) * 64 + lane;
+				if (bx < bwC) {
+					load_block(comp == 1 ? coefCb : coefCr, (uint32_t)(m * bwC + bx), c);
+					idct_block<WIDE>(c, im.dq[comp], rows);
+					uint8_t *dst = (comp == 1 ? sCb : sCr) + 8 * bx;
+#pragma unroll
+					for (int r = 0; r < 8; ++r)
+						*reinterpret_cast<uint2 *>(dst + r * CP) = rows[r];
+				}
+			}
+		}
+		__syncthreads();
+
+		/* ---- phase B: chroma rows C = 8m .. 8m+7 -> output rows 2C-1, 2C */
+		for (int cc = 0; cc < 8; ++cc) {
+			const int C = 8 * m + cc;
+			/* row C-1: previous plane row, or the saved row, or (image top) row 0 itself */
+			const uint8_t *cbA, *crA, *yA;
+			if (cc > 0) {
+				cbA = sCb + (cc - 1) * CP;
+				crA = sCr + (cc - 1) * CP;
+				yA = sY + (2 * cc - 1) * YP;
+			} else if (C > 0) {
+				cbA = saveCb + sv * CP;
+				crA = saveCr + sv * CP;
+				yA = saveY + sv * YP;
+			} else {
+				cbA = sCb;
+				crA = sCr;
+				yA = sY; /* row -1 is never emitted */
+			}
+			/* row C, clamped to the last effective chroma row (then equal to row C-1) */
+			const uint8_t *cbB = C <= hc - 1 ? sCb + cc * CP : cbA;
+			const uint8_t *crB = C <= hc - 1 ? sCr + cc * CP : crA;
+			emit_pair(C, cbA, cbB, crA, crB, yA, sY + (2 * cc) * YP);
+		}
+		/* keep the last rows of this MCU row for the next step (other save buffer: no extra barrier) */
+		{
+			const int nv = sv ^ 1;
+			for (int i = tid; i < YP / 4; i += 256)
+				reinterpret_cast<uint32_t *>(saveY + nv * YP)[i] = reinterpret_cast<const uint32_t *>(sY + 15 * YP)[i];
+			for (int i = tid; i < CP / 4; i += 256) {
+				reinterpret_cast<uint32_t *>(saveCb + nv * CP)[i] = reinterpret_cast<const uint32_t *>(sCb + 7 * CP)[i];
+				reinterpret_cast<uint32_t *>(saveCr + nv * CP)[i] = reinterpret_cast<const uint32_t *>(sCr + 7 * CP)[i];
+			}
+			sv = nv;
+		}
+	}
+
+	/* ---- epilogue: the band's last row 16*m1-1 pairs chroma row 8*m1-1 (saved) with row 8*m1 */
+	{
+		const int C = 8 * m1, ra = 2 * C - 1;
+		if (ra >= row_lo && ra < row_hi) {
+			__syncthreads(); /* planes free, save buffers written */
+			const uint8_t *cbA = saveCb + sv * CP, *crA = saveCr + sv * CP;
+			const uint8_t *cbB = cbA, *crB = crA;
+			if (C <= hc - 1) { /* there is a block row below: its first sample row */
+				chroma_halo(m1, 0, sCb, sCr);
+				__syncthreads();
+				cbB = sCb;
+				crB = sCr;
+			}
+			emit_pair(C, cbA, cbB, crA, crB, saveY + sv * YP, saveY + sv * YP);
+		}
+	}
+}
+
+} /* namespace mij */
+
+#endif

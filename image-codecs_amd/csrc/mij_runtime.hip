@@ -1,0 +1,775 @@
+/*
+ * mij_runtime.hip -- host side of the C-ABI in include/mij.h: contexts, batches (pinned staging,
+ * device arenas, one HIP stream each), upload / launch / fetch, measurement hooks.
+ * The kernels are in mij_kernels.h.  No exceptions and no C++ types cross the ABI.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "mij.h"
+#include "mij_kernels.h"
+
+using namespace mij;
+
+/* ------------------------------------------------------------------ errors */
+
+static thread_local char g_err[256] = "";
+
+static int set_err(int code, const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof(g_err), fmt, ap);
+	va_end(ap);
+	return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+	do {                                                                                       \
+		hipError_t e_ = (expr);                                                                 \
+		if (e_ != hipSuccess)                                                                   \
+			return set_err(MIJ_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));            \
+	} while (0)
+
+extern "C" const char *mij_last_error(void) { return g_err; }
+extern "C" int mij_abi_version(void) { return MIJ_ABI_VERSION; }
+
+extern "C" int mij_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess)
+		return 0;
+	return n;
+}
+
+/* ------------------------------------------------------------------ context */
+
+struct mij_ctx {
+	int device;
+	hipDeviceProp_t prop;
+	int max_dyn_lds;
+};
+
+extern "C" int mij_ctx_create(int device, mij_ctx **out)
+{
+	if (!out)
+		return set_err(MIJ_E_ARG, "mij_ctx_create: out is NULL");
+	*out = nullptr;
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess || n <= 0)
+		return set_err(MIJ_E_NODEVICE, "no gpu device (%s)", e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+	if (device < 0) {
+		if (hipGetDevice(&device) != hipSuccess)
+			device = 0;
+	}
+	if (device >= n)
+		return set_err(MIJ_E_ARG, "device %d out of range (%d devices)", device, n);
+	mij_ctx *c = new (std::nothrow) mij_ctx();
+	if (!c)
+		return set_err(MIJ_E_NOMEM, "out of host memory");
+	c->device = device;
+	if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&c->prop, device) != hipSuccess) {
+		delete c;
+		return set_err(MIJ_E_NODEVICE, "cannot open device %d", device);
+	}
+	if (strncmp(c->prop.gcnArchName, "gfx950", 6) != 0) {
+		/* the kernels are built for gfx950 only; any other device cannot load the code object */
+		set_err(MIJ_E_NODEVICE, "device %d is %s, this library is built for gfx950 only", device, c->prop.gcnArchName);
+		delete c;
+		return MIJ_E_NODEVICE;
+	}
+	c->max_dyn_lds = 160 * 1024;
+	/* allow the fused kernel to use the whole 160 KiB of LDS for wide images */
+	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused420<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused420<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused420<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused420<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+	(void)hipGetLastError();
+	*out = c;
+	return MIJ_OK;
+}
+
+extern "C" void mij_ctx_destroy(mij_ctx *ctx) { delete ctx; }
+extern "C" int mij_ctx_device(const mij_ctx *ctx) { return ctx ? ctx->device : -1; }
+
+extern "C" int mij_ctx_info(const mij_ctx *ctx, char *arch, size_t arch_len, int *cu_count, size_t *total_mem)
+{
+	if (!ctx)
+		return set_err(MIJ_E_ARG, "ctx is NULL");
+	if (arch && arch_len) {
+		strncpy(arch, ctx->prop.gcnArchName, arch_len - 1);
+		arch[arch_len - 1] = 0;
+	}
+	if (cu_count)
+		*cu_count = ctx->prop.multiProcessorCount;
+	if (total_mem)
+		*total_mem = ctx->prop.totalGlobalMem;
+	return MIJ_OK;
+}
+
+/* ------------------------------------------------------------------ batch */
+
+struct Slot {
+	mij_image_desc desc;
+	DevImage dev;
+	size_t stage_off;  /* byte offset in the staging arena (clones: the source's) */
+	size_t coef_bytes; /* bytes of this image's coefficient planes */
+	int clone_of;      /* -1: own staging */
+	int path;          /* 0 none, 1 fused 4:2:0, 2 two-pass */
+};
+
+struct mij_batch {
+	mij_ctx *ctx;
+	hipStream_t stream;
+	hipEvent_t ev_begin, ev_end;
+	int max_images;
+	/* arenas */
+	uint8_t *stage;
+	size_t stage_cap, stage_used;
+	uint8_t *d_coef;
+	size_t coef_cap, coef_used;
+	uint8_t *d_out;
+	size_t out_cap, out_used;
+	uint8_t *d_planes;
+	size_t planes_cap;
+	/* descriptors + work lists (pinned host mirror + device copy) */
+	DevImage *h_imgs, *d_imgs;
+	WorkBand *h_bands, *d_bands;
+	size_t bands_cap;
+	WorkIdct *h_idct, *d_idct;
+	size_t idct_cap;
+	std::vector<Slot> slots;
+	/* launch plan built by upload */
+	struct BandLaunch {
+		int nout, wide;
+		size_t first, count;
+		size_t lds;
+	};
+	std::vector<BandLaunch> band_launches;
+	struct IdctLaunch {
+		int wide;
+		size_t first, count;
+	};
+	std::vector<IdctLaunch> idct_launches;
+	std::vector<int> twopass_slots;
+	bool uploaded, launched, force_generic;
+	int band_rows; /* MCU rows per fused workgroup; 0 = automatic */
+};
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+extern "C" size_t mij_image_coef_bytes(const mij_image_desc *d)
+{
+	size_t total = 0;
+	for (int c = 0; c < d->ncomp; ++c)
+		total += mij_plane_elems((uint32_t)(d->comp[c].bw * d->comp[c].bh)) * sizeof(int16_t);
+	return total;
+}
+
+extern "C" size_t mij_image_out_bytes(const mij_image_desc *d) { return align_up((size_t)d->n_out * d->width * d->height, 256); }
+
+extern "C" int mij_batch_create(mij_ctx *ctx, int max_images, size_t stage_bytes, size_t coef_bytes, size_t out_bytes, mij_batch **out)
+{
+	if (!ctx || !out || max_images <= 0)
+		return set_err(MIJ_E_ARG, "mij_batch_create: bad argument");
+	*out = nullptr;
+	HIP_TRY(hipSetDevice(ctx->device));
+	mij_batch *b = new (std::nothrow) mij_batch();
+	if (!b)
+		return set_err(MIJ_E_NOMEM, "out of host memory");
+	b->ctx = ctx;
+	b->max_images = max_images;
+	b->stage = nullptr;
+	b->d_coef = b->d_out = b->d_planes = nullptr;
+	b->h_imgs = b->d_imgs = nullptr;
+	b->h_bands = b->d_bands = nullptr;
+	b->h_idct = b->d_idct = nullptr;
+	b->stage_cap = stage_bytes;
+	b->coef_cap = coef_bytes;
+	b->out_cap = out_bytes;
+	b->stage_used = b->coef_used = b->out_used = 0;
+	b->planes_cap = 0;
+	b->bands_cap = b->idct_cap = 0;
+	b->uploaded = b->launched = b->force_generic = false;
+	b->band_rows = 0;
+	b->stream = nullptr;
+	b->ev_begin = b->ev_end = nullptr;
+	const char *env = getenv("MIJ_BAND_ROWS");
+	if (env)
+		b->band_rows = atoi(env);
+
+	hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+	if (e == hipSuccess)
+		e = hipEventCreate(&b->ev_begin);
+	if (e == hipSuccess)
+		e = hipEventCreate(&b->ev_end);
+	if (e == hipSuccess && stage_bytes)
+		e = hipHostMalloc(reinterpret_cast<void **>(&b->stage), stage_bytes, hipHostMallocDefault);
+	if (e == hipSuccess && coef_bytes)
+		e = hipMalloc(reinterpret_cast<void **>(&b->d_coef), coef_bytes);
+	if (e == hipSuccess && out_bytes)
+		e = hipMalloc(reinterpret_cast<void **>(&b->d_out), out_bytes);
+	if (e == hipSuccess)
+		e = hipHostMalloc(reinterpret_cast<void **>(&b->h_imgs), sizeof(DevImage) * (size_t)max_images, hipHostMallocDefault);
+	if (e == hipSuccess)
+		e = hipMalloc(reinterpret_cast<void **>(&b->d_imgs), sizeof(DevImage) * (size_t)max_images);
+	if (e != hipSuccess) {
+		int code = (e == hipErrorOutOfMemory) ? MIJ_E_NOMEM : MIJ_E_HIP;
+		set_err(code, "mij_batch_create: %s", hipGetErrorString(e));
+		mij_batch_destroy(b);
+		return code;
+	}
+	b->slots.reserve((size_t)max_images);
+	*out = b;
+	return MIJ_OK;
+}
+
+extern "C" void mij_batch_destroy(mij_batch *b)
+{
+	if (!b)
+		return;
+	(void)hipSetDevice(b->ctx->device);
+	if (b->stream)
+		(void)hipStreamSynchronize(b->stream);
+	if (b->stage)
+		(void)hipHostFree(b->stage);
+	if (b->d_coef)
+		(void)hipFree(b->d_coef);
+	if (b->d_out)
+		(void)hipFree(b->d_out);
+	if (b->d_planes)
+		(void)hipFree(b->d_planes);
+	if (b->h_imgs)
+		(void)hipHostFree(b->h_imgs);
+	if (b->d_imgs)
+		(void)hipFree(b->d_imgs);
+	if (b->h_bands)
+		(void)hipHostFree(b->h_bands);
+	if (b->d_bands)
+		(void)hipFree(b->d_bands);
+	if (b->h_idct)
+		(void)hipHostFree(b->h_idct);
+	if (b->d_idct)
+		(void)hipFree(b->d_idct);
+	if (b->ev_begin)
+		(void)hipEventDestroy(b->ev_begin);
+	if (b->ev_end)
+		(void)hipEventDestroy(b->ev_end);
+	if (b->stream)
+		(void)hipStreamDestroy(b->stream);
+	delete b;
+}
+
+extern "C" int mij_batch_reset(mij_batch *b)
+{
+	if (!b)
+		return set_err(MIJ_E_ARG, "batch is NULL");
+	HIP_TRY(hipSetDevice(b->ctx->device));
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	b->slots.clear();
+	b->stage_used = b->coef_used = b->out_used = 0;
+	b->uploaded = b->launched = false;
+	b->band_launches.clear();
+	b->idct_launches.clear();
+	b->twopass_slots.clear();
+	return MIJ_OK;
+}
+
+static int check_desc(const mij_image_desc *d)
+{
+	if (!d)
+		return set_err(MIJ_E_ARG, "descriptor is NULL");
+	if (d->width <= 0 || d->height <= 0 || d->width > 65535 || d->height > 65535)
+		return set_err(MIJ_E_ARG, "bad image size %dx%d", d->width, d->height);
+	if (!(d->ncomp == 1 || d->ncomp == 3 || d->ncomp == 4))
+		return set_err(MIJ_E_ARG, "bad component count %d", d->ncomp);
+	if (d->n_out < 1 || d->n_out > 4)
+		return set_err(MIJ_E_ARG, "bad n_out %d", d->n_out);
+	if (d->color < MIJ_COLOR_GREY || d->color > MIJ_COLOR_YCBCRA)
+		return set_err(MIJ_E_ARG, "bad colour mode %d", d->color);
+	if ((d->color == MIJ_COLOR_YCBCR || d->color == MIJ_COLOR_RGB) && d->ncomp != 3)
+		return set_err(MIJ_E_ARG, "colour mode %d needs 3 components", d->color);
+	if (d->color >= MIJ_COLOR_CMYK && d->ncomp != 4)
+		return set_err(MIJ_E_ARG, "colour mode %d needs 4 components", d->color);
+	if (d->h_max < 1 || d->h_max > 4 || d->v_max < 1 || d->v_max > 4 || d->mcu_x <= 0 || d->mcu_y <= 0)
+		return set_err(MIJ_E_ARG, "bad MCU geometry");
+	for (int c = 0; c < d->ncomp; ++c) {
+		const mij_comp_desc &cp = d->comp[c];
+		if (cp.h < 1 || cp.h > 4 || cp.v < 1 || cp.v > 4 || cp.tq < 0 || cp.tq > 3)
+			return set_err(MIJ_E_ARG, "bad sampling/table for component %d", c);
+		if (cp.h > d->h_max || cp.v > d->v_max)
+			return set_err(MIJ_E_ARG, "component %d sampling exceeds h_max/v_max", c);
+		if (cp.bw != d->mcu_x * cp.h || cp.bh != d->mcu_y * cp.v)
+			return set_err(MIJ_E_ARG, "component %d block grid does not match the MCU grid", c);
+		if (cp.x <= 0 || cp.y <= 0 || cp.x > cp.bw * 8 || cp.y > cp.bh * 8)
+			return set_err(MIJ_E_ARG, "component %d effective size out of range", c);
+	}
+	return MIJ_OK;
+}
+
+static void fill_dev_image(Slot &s, size_t coef_off, size_t out_off)
+{
+	const mij_image_desc &d = s.desc;
+	DevImage &v = s.dev;
+	memset(&v, 0, sizeof(v));
+	v.width = d.width;
+	v.height = d.height;
+	v.n_out = d.n_out;
+	v.color = d.color;
+	v.ncomp = d.ncomp;
+	v.flags = (int32_t)d.flags;
+	v.mcu_x = d.mcu_x;
+	v.mcu_y = d.mcu_y;
+	v.out_off = out_off;
+	size_t plane_off = 0;
+	for (int c = 0; c < d.ncomp; ++c) {
+		DevComp &dc = v.comp[c];
+		const mij_comp_desc &cp = d.comp[c];
+		dc.h = cp.h;
+		dc.v = cp.v;
+		dc.x = cp.x;
+		dc.y = cp.y;
+		dc.bw = cp.bw;
+		dc.bh = cp.bh;
+		dc.hs = d.h_max / cp.h;
+		dc.vs = d.v_max / cp.v;
+		dc.coef_off = coef_off;
+		coef_off += mij_plane_elems((uint32_t)(cp.bw * cp.bh)) * sizeof(int16_t);
+		dc.plane_off = plane_off; /* relative; rebased at launch */
+		plane_off += align_up((size_t)cp.bw * 8 * cp.bh * 8, 256);
+		/* quantisation table, natural order -> in-block position order P = 8*col + rowslot[row] */
+		uint16_t q[64];
+		for (int row = 0; row < 8; ++row)
+			for (int col = 0; col < 8; ++col)
+				q[8 * col + mij_rowslot[row]] = d.dequant[cp.tq][8 * row + col];
+		for (int i = 0; i < 32; ++i)
+			v.dq[c][i] = (uint32_t)q[2 * i] | ((uint32_t)q[2 * i + 1] << 16);
+	}
+	v.plane_bytes_total = plane_off;
+}
+
+static int add_common(mij_batch *b, const mij_image_desc *d, int clone_of)
+{
+	if ((int)b->slots.size() >= b->max_images)
+		return set_err(MIJ_E_NOMEM, "batch is full (%d images)", b->max_images);
+	const size_t cbytes = mij_image_coef_bytes(d), obytes = mij_image_out_bytes(d);
+	if (b->coef_used + cbytes > b->coef_cap)
+		return set_err(MIJ_E_NOMEM, "coefficient arena exhausted");
+	if (b->out_used + obytes > b->out_cap)
+		return set_err(MIJ_E_NOMEM, "output arena exhausted");
+	Slot s;
+	s.desc = *d;
+	s.clone_of = clone_of;
+	s.coef_bytes = cbytes;
+	s.path = 0;
+	if (clone_of < 0) {
+		if (b->stage_used + cbytes > b->stage_cap)
+			return set_err(MIJ_E_NOMEM, "staging arena exhausted");
+		s.stage_off = b->stage_used;
+		memset(b->stage + s.stage_off, 0, cbytes);
+		b->stage_used += cbytes;
+	} else {
+		s.stage_off = b->slots[(size_t)clone_of].stage_off;
+	}
+	fill_dev_image(s, b->coef_used, b->out_used);
+	b->coef_used += cbytes;
+	b->out_used += obytes;
+	b->slots.push_back(s);
+	b->uploaded = b->launched = false;
+	return (int)b->slots.size() - 1;
+}
+
+extern "C" int mij_batch_add(mij_batch *b, const mij_image_desc *d)
+{
+	if (!b)
+		return set_err(MIJ_E_ARG, "batch is NULL");
+	int rc = check_desc(d);
+	if (rc != MIJ_OK)
+		return rc;
+	return add_common(b, d, -1);
+}
+
+extern "C" int mij_batch_add_clone(mij_batch *b, int src_slot)
+{
+	if (!b || src_slot < 0 || src_slot >= (int)b->slots.size())
+		return set_err(MIJ_E_ARG, "bad source slot");
+	int root = b->slots[(size_t)src_slot].clone_of >= 0 ? b->slots[(size_t)src_slot].clone_of : src_slot;
+	mij_image_desc d = b->slots[(size_t)root].desc;
+	return add_common(b, &d, root);
+}
+
+extern "C" int16_t *mij_batch_coef(mij_batch *b, int slot, int comp)
+{
+	if (!b || slot < 0 || slot >= (int)b->slots.size()) {
+		set_err(MIJ_E_ARG, "bad slot");
+		return nullptr;
+	}
+	const Slot &s = b->slots[(size_t)slot];
+	if (comp < 0 || comp >= s.desc.ncomp || s.clone_of >= 0 || !b->stage) {
+		set_err(MIJ_E_ARG, "bad component, or slot has no staging of its own");
+		return nullptr;
+	}
+	size_t off = s.stage_off;
+	for (int c = 0; c < comp; ++c)
+		off += mij_plane_elems((uint32_t)(s.desc.comp[c].bw * s.desc.comp[c].bh)) * sizeof(int16_t);
+	return reinterpret_cast<int16_t *>(b->stage + off);
+}
+
+extern "C" int mij_batch_set_flags(mij_batch *b, int slot, uint32_t flags)
+{
+	if (!b || slot < 0 || slot >= (int)b->slots.size())
+		return set_err(MIJ_E_ARG, "bad slot");
+	b->slots[(size_t)slot].desc.flags = flags;
+	b->slots[(size_t)slot].dev.flags = (int32_t)flags;
+	b->uploaded = b->launched = false;
+	return MIJ_OK;
+}
+
+extern "C" int mij_batch_image_count(const mij_batch *b) { return b ? (int)b->slots.size() : 0; }
+extern "C" int mij_batch_slot_path(const mij_batch *b, int slot)
+{
+	if (!b || slot < 0 || slot >= (int)b->slots.size())
+		return 0;
+	return b->slots[(size_t)slot].path;
+}
+extern "C" int mij_batch_force_generic(mij_batch *b, int on)
+{
+	if (!b)
+		return set_err(MIJ_E_ARG, "batch is NULL");
+	b->force_generic = on != 0;
+	b->uploaded = b->launched = false;
+	return MIJ_OK;
+}
+
+/* can the fused h2v2 kernel take this image? */
+static bool fused420_ok(const mij_batch *b, const mij_image_desc &d)
+{
+	if (b->force_generic)
+		return false;
+	if (d.ncomp != 3 || d.color != MIJ_COLOR_YCBCR || (d.n_out != 3 && d.n_out != 4))
+		return false;
+	if (d.comp[0].h != 2 || d.comp[0].v != 2)
+		return false;
+	for (int c = 1; c < 3; ++c)
+		if (d.comp[c].h != 1 || d.comp[c].v != 1)
+			return false;
+	size_t lds = (size_t)d.mcu_x * (16 * 16 + 2 * 8 * 8 + 2 * 16 + 4 * 8);
+	return lds <= (size_t)b->ctx->max_dyn_lds;
+}
+
+template <typename T>
+static int grow_pair(T *&h, T *&d, size_t &cap, size_t need)
+{
+	if (need <= cap)
+		return MIJ_OK;
+	size_t ncap = need + need / 2 + 64;
+	if (h)
+		(void)hipHostFree(h);
+	if (d)
+		(void)hipFree(d);
+	h = nullptr;
+	d = nullptr;
+	cap = 0;
+	HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h), sizeof(T) * ncap, hipHostMallocDefault));
+	HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), sizeof(T) * ncap));
+	cap = ncap;
+	return MIJ_OK;
+}
+
+extern "C" int mij_batch_upload(mij_batch *b)
+{
+	if (!b)
+		return set_err(MIJ_E_ARG, "batch is NULL");
+	HIP_TRY(hipSetDevice(b->ctx->device));
+	const size_t n = b->slots.size();
+	if (n == 0)
+		return set_err(MIJ_E_STATE, "batch is empty");
+
+	/* ---- plan: group fused images by (n_out, wide); everything else goes two-pass */
+	std::vector<WorkBand> bands[4];
+	std::vector<WorkIdct> idct[2];
+	size_t band_lds[4] = {0, 0, 0, 0};
+	b->twopass_slots.clear();
+	size_t planes_need = 0, planes_off = 0;
+	const int cu = b->ctx->prop.multiProcessorCount > 0 ? b->ctx->prop.multiProcessorCount : 256;
+	/* automatic band height: enough workgroups to fill the chip several times over, but no
+	 * shorter than needed (each band re-does two chroma block rows of IDCT as halo) */
+	size_t total_mcu_rows = 0;
+	for (size_t i = 0; i < n; ++i)
+		if (fused420_ok(b, b->slots[i].desc))
+			total_mcu_rows += (size_t)b->slots[i].desc.mcu_y;
+	int auto_rows = 17;
+	if (total_mcu_rows) {
+		size_t want_wg = (size_t)cu * 16;
+		size_t r = total_mcu_rows / want_wg;
+		auto_rows = (int)(r < 1 ? 1 : (r > 17 ? 17 : r));
+	}
+	const int band_rows = b->band_rows > 0 ? b->band_rows : auto_rows;
+
+	for (size_t i = 0; i < n; ++i) {
+		Slot &s = b->slots[i];
+		const mij_image_desc &d = s.desc;
+		const int wide = (d.flags & MIJ_FLAG_WIDE_IDCT) ? 1 : 0;
+		if (fused420_ok(b, d)) {
+			s.path = 1;
+			const int g = (d.n_out == 4 ? 2 : 0) + wide;
+			/* split mcu_y into equal-ish bands of at most band_rows */
+			const int nb = (d.mcu_y + band_rows - 1) / band_rows;
+			for (int k = 0; k < nb; ++k) {
+				WorkBand w;
+				w.img = (uint32_t)i;
+				w.m0 = (uint32_t)((long)d.mcu_y * k / nb);
+				w.m1 = (uint32_t)((long)d.mcu_y * (k + 1) / nb);
+				w.pad = 0;
+				bands[g].push_back(w);
+			}
+			size_t lds = (size_t)d.mcu_x * (16 * 16 + 2 * 8 * 8 + 2 * 16 + 4 * 8);
+			if (lds > band_lds[g])
+				band_lds[g] = lds;
+		} else {
+			s.path = 2;
+			b->twopass_slots.push_back((int)i);
+			for (int c = 0; c < d.ncomp; ++c) {
+				const uint32_t nblk = (uint32_t)(d.comp[c].bw * d.comp[c].bh);
+				for (uint32_t f = 0; f < nblk; f += 256) {
+					WorkIdct w;
+					w.img = (uint32_t)i;
+					w.comp = (uint32_t)c;
+					w.first = f;
+					w.pad = 0;
+					idct[wide].push_back(w);
+				}
+			}
+			/* rebase this image's sample planes into the scratch arena */
+			size_t rel0 = 0;
+			for (int c = 0; c < d.ncomp; ++c) {
+				s.dev.comp[c].plane_off = planes_off + rel0;
+				rel0 += align_up((size_t)d.comp[c].bw * 8 * d.comp[c].bh * 8, 256);
+			}
+			planes_off += rel0;
+			planes_need = planes_off;
+		}
+	}
+
+	/* ---- scratch planes for the two-pass path */
+	if (planes_need > b->planes_cap) {
+		HIP_TRY(hipStreamSynchronize(b->stream));
+		if (b->d_planes)
+			(void)hipFree(b->d_planes);
+		b->d_planes = nullptr;
+		b->planes_cap = 0;
+		hipError_t e = hipMalloc(reinterpret_cast<void **>(&b->d_planes), planes_need);
+		if (e != hipSuccess)
+			return set_err(e == hipErrorOutOfMemory ? MIJ_E_NOMEM : MIJ_E_HIP, "scratch planes: %s", hipGetErrorString(e));
+		b->planes_cap = planes_need;
+	}
+
+	/* ---- work lists */
+	size_t nb_total = 0, ni_total = 0;
+	for (int g = 0; g < 4; ++g)
+		nb_total += bands[g].size();
+	for (int g = 0; g < 2; ++g)
+		ni_total += idct[g].size();
+	int rc;
+	if ((nb_total > b->bands_cap || ni_total > b->idct_cap))
+		HIP_TRY(hipStreamSynchronize(b->stream));
+	if ((rc = grow_pair(b->h_bands, b->d_bands, b->bands_cap, nb_total)) != MIJ_OK)
+		return rc;
+	if ((rc = grow_pair(b->h_idct, b->d_idct, b->idct_cap, ni_total)) != MIJ_OK)
+		return rc;
+	b->band_launches.clear();
+	b->idct_launches.clear();
+	size_t pos = 0;
+	for (int g = 0; g < 4; ++g) {
+		if (bands[g].empty())
+			continue;
+		memcpy(b->h_bands + pos, bands[g].data(), bands[g].size() * sizeof(WorkBand));
+		mij_batch::BandLaunch L;
+		L.nout = (g & 2) ? 4 : 3;
+		L.wide = g & 1;
+		L.first = pos;
+		L.count = bands[g].size();
+		L.lds = band_lds[g];
+		b->band_launches.push_back(L);
+		pos += bands[g].size();
+	}
+	pos = 0;
+	for (int g = 0; g < 2; ++g) {
+		if (idct[g].empty())
+			continue;
+		memcpy(b->h_idct + pos, idct[g].data(), idct[g].size() * sizeof(WorkIdct));
+		mij_batch::IdctLaunch L;
+		L.wide = g;
+		L.first = pos;
+		L.count = idct[g].size();
+		b->idct_launches.push_back(L);
+		pos += idct[g].size();
+	}
+	for (size_t i = 0; i < n; ++i)
+		b->h_imgs[i] = b->slots[i].dev;
+
+	/* ---- copies, all on the batch stream */
+	HIP_TRY(hipMemcpyAsync(b->d_imgs, b->h_imgs, sizeof(DevImage) * n, hipMemcpyHostToDevice, b->stream));
+	if (nb_total)
+		HIP_TRY(hipMemcpyAsync(b->d_bands, b->h_bands, sizeof(WorkBand) * nb_total, hipMemcpyHostToDevice, b->stream));
+	if (ni_total)
+		HIP_TRY(hipMemcpyAsync(b->d_idct, b->h_idct, sizeof(WorkIdct) * ni_total, hipMemcpyHostToDevice, b->stream));
+	/* staged coefficients: own-staging slots are contiguous in both arenas in add order, so runs of
+	 * them go up in one copy each */
+	size_t i = 0;
+	while (i < n) {
+		if (b->slots[i].clone_of >= 0) {
+			++i;
+			continue;
+		}
+		size_t j = i, bytes = 0;
+		const size_t s0 = b->slots[i].stage_off, c0 = b->slots[i].dev.comp[0].coef_off;
+		while (j < n && b->slots[j].clone_of < 0 && b->slots[j].stage_off == s0 + bytes && b->slots[j].dev.comp[0].coef_off == c0 + bytes) {
+			bytes += b->slots[j].coef_bytes;
+			++j;
+		}
+		HIP_TRY(hipMemcpyAsync(b->d_coef + c0, b->stage + s0, bytes, hipMemcpyHostToDevice, b->stream));
+		i = j;
+	}
+	for (size_t k = 0; k < n; ++k) {
+		const Slot &s = b->slots[k];
+		if (s.clone_of < 0)
+			continue;
+		const Slot &src = b->slots[(size_t)s.clone_of];
+		HIP_TRY(hipMemcpyAsync(b->d_coef + s.dev.comp[0].coef_off, b->d_coef + src.dev.comp[0].coef_off, s.coef_bytes, hipMemcpyDeviceToDevice, b->stream));
+	}
+	b->uploaded = true;
+	b->launched = false;
+	return MIJ_OK;
+}
+
+extern "C" int mij_batch_launch(mij_batch *b)
+{
+	if (!b)
+		return set_err(MIJ_E_ARG, "batch is NULL");
+	if (!b->uploaded)
+		return set_err(MIJ_E_STATE, "mij_batch_launch before mij_batch_upload");
+	HIP_TRY(hipSetDevice(b->ctx->device));
+	for (const auto &L : b->band_launches) {
+		const dim3 grid((unsigned)L.count), block(256);
+		const WorkBand *wk = b->d_bands + L.first;
+		if (L.nout == 3 && !L.wide)
+			hipLaunchKernelGGL((k_fused420<3, false>), grid, block, L.lds, b->stream, b->d_imgs, wk, b->d_coef, b->d_out);
+		else if (L.nout == 3)
+			hipLaunchKernelGGL((k_fused420<3, true>), grid, block, L.lds, b->stream, b->d_imgs, wk, b->d_coef, b->d_out);
+		else if (!L.wide)
+			hipLaunchKernelGGL((k_fused420<4, false>), grid, block, L.lds, b->stream, b->d_imgs, wk, b->d_coef, b->d_out);
+		else
+			hipLaunchKernelGGL((k_fused420<4, true>), grid, block, L.lds, b->stream, b->d_imgs, wk, b->d_coef, b->d_out);
+		HIP_TRY(hipGetLastError());
+	}
+	for (const auto &L : b->idct_launches) {
+		const dim3 grid((unsigned)L.count), block(256);
+		const WorkIdct *wk = b->d_idct + L.first;
+		if (L.wide)
+			hipLaunchKernelGGL((k_idct_planes<true>), grid, block, 0, b->stream, b->d_imgs, wk, b->d_coef, b->d_planes);
+		else
+			hipLaunchKernelGGL((k_idct_planes<false>), grid, block, 0, b->stream, b->d_imgs, wk, b->d_coef, b->d_planes);
+		HIP_TRY(hipGetLastError());
+	}
+	for (int slot : b->twopass_slots) {
+		const mij_image_desc &d = b->slots[(size_t)slot].desc;
+		const dim3 grid((unsigned)((d.width + 255) / 256), (unsigned)d.height), block(256);
+		hipLaunchKernelGGL(k_resample_color, grid, block, 0, b->stream, b->d_imgs, (uint32_t)slot, b->d_planes, b->d_out);
+		HIP_TRY(hipGetLastError());
+	}
+	b->launched = true;
+	return MIJ_OK;
+}
+
+extern "C" int mij_batch_submit(mij_batch *b)
+{
+	int rc = mij_batch_upload(b);
+	if (rc != MIJ_OK)
+		return rc;
+	return mij_batch_launch(b);
+}
+
+extern "C" int mij_batch_wait(mij_batch *b)
+{
+	if (!b)
+		return set_err(MIJ_E_ARG, "batch is NULL");
+	HIP_TRY(hipSetDevice(b->ctx->device));
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	return MIJ_OK;
+}
+
+extern "C" int mij_batch_fetch(mij_batch *b, int slot, uint8_t *dst, size_t dst_bytes)
+{
+	if (!b || slot < 0 || slot >= (int)b->slots.size() || !dst)
+		return set_err(MIJ_E_ARG, "bad slot or destination");
+	if (!b->launched)
+		return set_err(MIJ_E_STATE, "mij_batch_fetch before launch");
+	const Slot &s = b->slots[(size_t)slot];
+	const size_t bytes = (size_t)s.desc.n_out * s.desc.width * s.desc.height;
+	if (dst_bytes < bytes)
+		return set_err(MIJ_E_ARG, "destination too small (%zu < %zu)", dst_bytes, bytes);
+	HIP_TRY(hipSetDevice(b->ctx->device));
+	HIP_TRY(hipMemcpyAsync(dst, b->d_out + s.dev.out_off, bytes, hipMemcpyDeviceToHost, b->stream));
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	return MIJ_OK;
+}
+
+extern "C" void *mij_batch_device_out(mij_batch *b, int slot)
+{
+	if (!b || slot < 0 || slot >= (int)b->slots.size())
+		return nullptr;
+	return b->d_out + b->slots[(size_t)slot].dev.out_off;
+}
+
+extern "C" int mij_batch_timer_begin(mij_batch *b)
+{
+	if (!b)
+		return set_err(MIJ_E_ARG, "batch is NULL");
+	HIP_TRY(hipSetDevice(b->ctx->device));
+	HIP_TRY(hipEventRecord(b->ev_begin, b->stream));
+	return MIJ_OK;
+}
+extern "C" int mij_batch_timer_end(mij_batch *b)
+{
+	if (!b)
+		return set_err(MIJ_E_ARG, "batch is NULL");
+	HIP_TRY(hipSetDevice(b->ctx->device));
+	HIP_TRY(hipEventRecord(b->ev_end, b->stream));
+	return MIJ_OK;
+}
+extern "C" int mij_batch_timer_elapsed_ms(mij_batch *b, float *ms)
+{
+	if (!b || !ms)
+		return set_err(MIJ_E_ARG, "bad argument");
+	HIP_TRY(hipSetDevice(b->ctx->device));
+	HIP_TRY(hipEventSynchronize(b->ev_end));
+	HIP_TRY(hipEventElapsedTime(ms, b->ev_begin, b->ev_end));
+	return MIJ_OK;
+}
+
+extern "C" int mij_batch_hash_out(mij_batch *b, int slot, uint64_t *hash)
+{
+	if (!b || slot < 0 || slot >= (int)b->slots.size() || !hash)
+		return set_err(MIJ_E_ARG, "bad argument");
+	const Slot &s = b->slots[(size_t)slot];
+	const size_t bytes = (size_t)s.desc.n_out * s.desc.width * s.desc.height;
+	std::vector<uint8_t> tmp(bytes);
+	int rc = mij_batch_fetch(b, slot, tmp.data(), bytes);
+	if (rc != MIJ_OK)
+		return rc;
+	uint64_t h = 1469598103934665603ull;
+	for (size_t i = 0; i < bytes; ++i) {
+		h ^= tmp[i];
+		h *= 1099511628211ull;
+	}
+	*hash = h;
+	return MIJ_OK;
+}

@@ -1,0 +1,189 @@
+/*
+ * mij.h -- C-ABI of the MI355X (gfx950) JPEG back end: "MI JPEG".
+ *
+ * This is the drop-in boundary for the reference's per-block / per-row kernel seam
+ *     stbi__jpeg::idct_block_kernel        (codec/jpeg.c:83, called :1178 :1217 :1342)
+ *     stbi__jpeg::resample_row_hv_2_kernel (codec/jpeg.c:85, called :2287/:2308)
+ *     stbi__jpeg::YCbCr_to_RGB_kernel      (codec/jpeg.c:84, called :2338 :2357 :2369)
+ * coarsened from "one block / one row per call" to "one batch of images per submit":
+ * the host entropy decoder (the part of codec/jpeg.c:1155-1317 that stays on the CPU) writes
+ * the *quantised* coefficients of every block straight into pinned staging memory owned by a
+ * batch; one submit then runs, on the GPU, for every image of the batch
+ *     de-quantisation   codec/jpeg.c:325,345,365 (baseline) / :1319-1324 (progressive)
+ *     8x8 integer IDCT  codec/jpeg.c:615-679
+ *     chroma upsample   codec/jpeg.c:1765-1840,1962-1971 chosen as :2280-2289, rows as :2301-2319
+ *     colour + output   codec/jpeg.c:1976-2018 and the branches of :2320-2431
+ * and leaves n_out*width*height interleaved bytes per image in device memory (fetch = D2H).
+ *
+ * Plain C: no HIP, C++ or torch types cross this boundary.  All functions return 0 on
+ * success or a negative MIJ_E_* code; mij_last_error() gives a thread-local message.
+ * A batch is owned by one host thread at a time; different batches may be driven from
+ * different threads concurrently (each batch has its own HIP stream).
+ */
+#ifndef MIJ_H
+#define MIJ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIJ_ABI_VERSION 1
+
+enum {
+	MIJ_OK = 0,
+	MIJ_E_NODEVICE = -1, /* no usable HIP device / HIP runtime error at init */
+	MIJ_E_ARG = -2,      /* bad argument or descriptor */
+	MIJ_E_NOMEM = -3,    /* batch arenas exhausted or allocation failed */
+	MIJ_E_HIP = -4,      /* HIP runtime error (message has the HIP string) */
+	MIJ_E_STATE = -5     /* call out of order (e.g. fetch before submit) */
+};
+
+/* how the decoded components map to output pixels: the branches of codec/jpeg.c:2320-2431 */
+enum {
+	MIJ_COLOR_GREY = 0,  /* 1 component (or luma-only decode of YCbCr when n_out < 3, :2246) */
+	MIJ_COLOR_YCBCR = 1, /* 3 components, stbi__YCbCr_to_RGB_row (:2338) */
+	MIJ_COLOR_RGB = 2,   /* 3 components tagged RGB: copy (:2325-2335), luma via stbi__compute_y for n_out<3 (:2382-2395) */
+	MIJ_COLOR_CMYK = 3,  /* 4 components, Adobe transform 0 (:2343-2354, :2396-2408) */
+	MIJ_COLOR_YCCK = 4,  /* 4 components, Adobe transform 2 (:2355-2366, :2409-2417) */
+	MIJ_COLOR_YCBCRA = 5 /* 4 components, other transform: YCbCr, 4th ignored (:2367-2370); n_out<3: luma (:2418-2430) */
+};
+
+/* descriptor flags */
+#define MIJ_FLAG_WIDE_IDCT 1u /* host could not prove that every first-pass IDCT output fits int16:
+                                 run the exact 32-bit second pass (see mij_block_l1_limit) */
+
+/* per component geometry, exactly the reference's img_comp[] fields (codec/jpeg.c:48-62, :1624-1655) */
+typedef struct {
+	int32_t h, v;   /* sampling factors 1..4 */
+	int32_t tq;     /* quantisation table index 0..3 */
+	int32_t x, y;   /* effective size in samples (:1627-1628) */
+	int32_t bw, bh; /* padded size in 8x8 blocks: w2/8, h2/8 (:1636-1637, = coeff_w, coeff_h :1649-1650) */
+} mij_comp_desc;
+
+typedef struct {
+	int32_t width, height; /* img_x, img_y */
+	int32_t ncomp;         /* components decoded by the entropy stage: 1, 3 or 4 */
+	int32_t n_out;         /* output bytes per pixel, 1..4 (:2241) */
+	int32_t color;         /* MIJ_COLOR_* */
+	uint32_t flags;        /* MIJ_FLAG_* */
+	int32_t h_max, v_max;  /* img_h_max, img_v_max (:1616-1617) */
+	int32_t mcu_x, mcu_y;  /* img_mcu_x, img_mcu_y (:1621-1622) */
+	mij_comp_desc comp[4];
+	uint16_t dequant[4][64]; /* natural (de-zigzagged) order, as stored at codec/jpeg.c:1376 */
+} mij_image_desc;
+
+/*
+ * Coefficient staging layout ("tile layout").  Per component the blocks are numbered
+ * L = bx + by*bw (the reference's coefficient indexing, codec/jpeg.c:1252,:1296,:1340); 64
+ * consecutive blocks form one 8 KiB tile, and inside a tile the 16-byte chunk c (0..7) of
+ * block lane l (= L & 63) sits at byte (c*64 + l)*16, so a 64-lane wavefront that owns one
+ * block per lane reads each chunk as one fully coalesced 1 KiB access.  Chunk c holds
+ * column c of the block as the four int16 pairs (r0,r4) (r2,r6) (r1,r3) (r5,r7) -- the
+ * operand pairs of the first (column) IDCT pass -- so coefficient (row,col) has in-block
+ * position P = 8*col + mij_rowslot[row].
+ *
+ * mij_coef_index(L, P) is the int16 index of that coefficient inside its component plane;
+ * mij_zigzag_pos[k] is P for the k-th coefficient in zigzag (bitstream) order.
+ */
+static const uint8_t mij_rowslot[8] = {0, 4, 2, 5, 1, 6, 3, 7};
+
+static const uint8_t mij_zigzag_pos[64] = {
+	/* P of natural index dezigzag[k]; natural = 8*row+col -> 8*col + rowslot[row] */
+	0, 8, 4, 2, 12, 16, 24, 20,
+	10, 5, 1, 13, 18, 28, 32, 40,
+	36, 26, 21, 9, 6, 3, 14, 17,
+	29, 34, 44, 48, 56, 52, 42, 37,
+	25, 22, 11, 7, 15, 19, 30, 33,
+	45, 50, 60, 58, 53, 41, 38, 27,
+	23, 31, 35, 46, 49, 61, 57, 54,
+	43, 39, 47, 51, 62, 59, 55, 63};
+
+static inline size_t mij_coef_index(uint32_t L, uint32_t P)
+{
+	return ((size_t)(L >> 6) << 12) + ((size_t)(P >> 3) << 9) + ((size_t)(L & 63u) << 3) + (P & 7u);
+}
+/* int16 elements in the plane of a component with nblocks blocks (whole tiles) */
+static inline size_t mij_plane_elems(uint32_t nblocks) { return ((size_t)(nblocks + 63u) >> 6) << 12; }
+
+/*
+ * Fast/exact IDCT contract.  The second IDCT pass runs on packed int16 first-pass outputs
+ * (v_dot2_i32_i16) when the host guarantees they fit; a sufficient condition is that for every
+ * block the sum of |de-quantised coefficient| is <= MIJ_BLOCK_L1_LIMIT (max |weight| of the
+ * first pass is 5683, so |sum| + 512 < 2^25 and (..)>>10 fits int16).  Otherwise the host sets
+ * MIJ_FLAG_WIDE_IDCT and the kernel computes the second pass in full 32-bit (wrapping)
+ * arithmetic, like the reference's int math on such streams.
+ */
+#define MIJ_BLOCK_L1_LIMIT 5903
+
+typedef struct mij_ctx mij_ctx;     /* one per (process, device) */
+typedef struct mij_batch mij_batch; /* staging + device arenas + one HIP stream */
+
+const char *mij_last_error(void);
+int mij_abi_version(void);
+int mij_device_count(void);
+
+/* device < 0: use the HIP current device.  Fails with MIJ_E_NODEVICE when no GPU is present. */
+int mij_ctx_create(int device, mij_ctx **out);
+void mij_ctx_destroy(mij_ctx *ctx);
+int mij_ctx_device(const mij_ctx *ctx);
+/* "gfx950", CU count, bytes of device memory -- for logs and the bench header */
+int mij_ctx_info(const mij_ctx *ctx, char *arch, size_t arch_len, int *cu_count, size_t *total_mem);
+
+/*
+ * A batch holds up to max_images images.  stage_bytes = pinned host staging for coefficients
+ * (0: none, images can then only be added as clones or filled on the device), coef_bytes /
+ * out_bytes = device arenas.  mij_image_coef_bytes / mij_image_out_bytes give an image's needs.
+ */
+int mij_batch_create(mij_ctx *ctx, int max_images, size_t stage_bytes, size_t coef_bytes, size_t out_bytes, mij_batch **out);
+void mij_batch_destroy(mij_batch *b);
+int mij_batch_reset(mij_batch *b); /* forget all images; arenas are reused */
+
+size_t mij_image_coef_bytes(const mij_image_desc *d); /* sum over components of whole tiles */
+size_t mij_image_out_bytes(const mij_image_desc *d);  /* n_out*width*height, rounded up to 256 */
+
+/* Adds an image; returns its slot (>= 0) or a negative error.  Its staging planes are zeroed. */
+int mij_batch_add(mij_batch *b, const mij_image_desc *d);
+/* Adds an image that shares descriptor and coefficients with slot src but gets its own device
+ * coefficient and output buffers (filled device-to-device at upload).  For benchmarks that need
+ * many resident images from a few distinct inputs. */
+int mij_batch_add_clone(mij_batch *b, int src_slot);
+/* Pinned host plane of component c of a slot (tile layout, int16, zero-filled). */
+int16_t *mij_batch_coef(mij_batch *b, int slot, int comp);
+/* May be called after the entropy stage to raise flags it only knows late (e.g. WIDE_IDCT). */
+int mij_batch_set_flags(mij_batch *b, int slot, uint32_t flags);
+
+/* submit = upload + launch.  All asynchronous on the batch's stream; wait blocks. */
+int mij_batch_upload(mij_batch *b); /* H2D of staged coefficients (+ D2D for clones) + descriptors */
+int mij_batch_launch(mij_batch *b); /* the decode kernels over every image of the batch */
+int mij_batch_submit(mij_batch *b);
+int mij_batch_wait(mij_batch *b);
+
+/* D2H of one image's pixels into dst (dst_bytes >= n_out*width*height); waits for the batch. */
+int mij_batch_fetch(mij_batch *b, int slot, uint8_t *dst, size_t dst_bytes);
+/* Device address of an image's pixels (valid until reset/destroy) for device-resident consumers. */
+void *mij_batch_device_out(mij_batch *b, int slot);
+int mij_batch_image_count(const mij_batch *b);
+
+/*
+ * Measurement hooks (used by bench.py): HIP events recorded on the batch's own stream.
+ * begin/end bracket whatever was enqueued between them; elapsed waits for the end event.
+ */
+int mij_batch_timer_begin(mij_batch *b);
+int mij_batch_timer_end(mij_batch *b);
+int mij_batch_timer_elapsed_ms(mij_batch *b, float *ms);
+/* FNV-1a 64 of an image's output computed on the device copy (D2H + hash on host); for parity checks of big batches */
+int mij_batch_hash_out(mij_batch *b, int slot, uint64_t *hash);
+
+/* which kernel family the last launch used for a slot: 0 none, 1 fused 4:2:0, 2 generic two-pass, ... */
+int mij_batch_slot_path(const mij_batch *b, int slot);
+/* force the generic (unfused) path for every image of a batch: parity tests compare both */
+int mij_batch_force_generic(mij_batch *b, int on);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* MIJ_H */
