@@ -80,6 +80,30 @@ __device__ __forceinline__ uint32_t pack_i16(int lo, int hi) { return __builtin_
 
 __device__ __forceinline__ int clamp255(int x) { return x < 0 ? 0 : (x > 255 ? 255 : x); }
 
+/*
+ * v_ashr_pk_u8_i32 (new on gfx950): byte0 = sat_u8(a >> S), byte1 = sat_u8(b >> S).  The
+ * instruction writes only the low half of its destination (the other half keeps whatever the
+ * register held; ROCm 7.2's own pattern for it assumes zeros there and mis-compiles
+ * "clamp(x>>n) | clamp(y>>n) << 8 | ..." chains), so it is used through asm and only bytes 0..1
+ * of the result are ever consumed (join16).  This one instruction is the reference's
+ * ">> 17, stbi__clamp" (codec/jpeg.c:670-677) and ">> 20, clamp" (:1988-2011) for two samples.
+ */
+template <int S>
+__device__ __forceinline__ uint32_t ashr_sat_pk2(int a, int b)
+{
+	uint32_t d;
+	asm("v_ashr_pk_u8_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "n"(S));
+	return d;
+}
+/* bytes (lo.0, lo.1, hi.0, hi.1) */
+__device__ __forceinline__ uint32_t join16(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x05040100); }
+/* keeps the compiler from fusing a preceding shift with a following clamp into the pattern above */
+__device__ __forceinline__ int opaque(int x)
+{
+	asm("" : "+v"(x));
+	return x;
+}
+
 /* ------------------------------------------------------------------ IDCT (codec/jpeg.c:578-679)
  *
  * STBI__IDCT_1D is linear over the ring Z/2^32, so its eight outputs are fixed integer
@@ -88,7 +112,7 @@ __device__ __forceinline__ int clamp255(int x) { return x < 0 ? 0 : (x > 255 ? 2
  *     x1 = 4096 s0 + 2217 s2 - 4096 s4 - 5350 s6          t2 = 4816 s1 - 1129 s3 - 5681 s5 - 3218 s7
  *     x2 = 4096 s0 - 2217 s2 - 4096 s4 + 5350 s6          t1 = 3219 s1 - 5681 s3 + 1132 s5 + 4816 s7
  *     x3 = 4096 s0 - 5352 s2 + 4096 s4 - 2217 s6          t0 = 1131 s1 - 3218 s3 + 4816 s5 - 5680 s7
- * out = (x0+t3, x1+t2, x2+t1, x3+t0, x3-t0, x2-t1, x1-t2, x0-t3) + bias, then >> shift.
+ * out = (x0+t3, x1+t2, x2+t1, x3+t0, x3-t0, x2-t1, x1-t2, x0-t3) + bias; the callers shift (>>10, >>17).
  * With the inputs paired as (s0,s4) (s2,s6) (s1,s3) (s5,s7) -- exactly how the tile layout stores
  * a column -- that is 14 v_dot2 + 8 add/sub + 8 shifts per 1-D transform.
  */
@@ -96,7 +120,7 @@ struct Idct1D {
 	int o[8];
 };
 
-template <int BIAS, int SHIFT>
+template <int BIAS>
 __device__ __forceinline__ Idct1D idct1d_packed(uint32_t d04, uint32_t d26, uint32_t d13, uint32_t d57)
 {
 	int e0 = dot2(d04, pk16(4096, 4096), BIAS);
@@ -110,20 +134,20 @@ __device__ __forceinline__ Idct1D idct1d_packed(uint32_t d04, uint32_t d26, uint
 	int t1 = dot2(d13, pk16(3219, -5681), dot2(d57, pk16(1132, 4816), 0));
 	int t0 = dot2(d13, pk16(1131, -3218), dot2(d57, pk16(4816, -5680), 0));
 	Idct1D r;
-	r.o[0] = (int)((uint32_t)x0 + (uint32_t)t3) >> SHIFT;
-	r.o[7] = (int)((uint32_t)x0 - (uint32_t)t3) >> SHIFT;
-	r.o[1] = (int)((uint32_t)x1 + (uint32_t)t2) >> SHIFT;
-	r.o[6] = (int)((uint32_t)x1 - (uint32_t)t2) >> SHIFT;
-	r.o[2] = (int)((uint32_t)x2 + (uint32_t)t1) >> SHIFT;
-	r.o[5] = (int)((uint32_t)x2 - (uint32_t)t1) >> SHIFT;
-	r.o[3] = (int)((uint32_t)x3 + (uint32_t)t0) >> SHIFT;
-	r.o[4] = (int)((uint32_t)x3 - (uint32_t)t0) >> SHIFT;
+	r.o[0] = (int)((uint32_t)x0 + (uint32_t)t3);
+	r.o[7] = (int)((uint32_t)x0 - (uint32_t)t3);
+	r.o[1] = (int)((uint32_t)x1 + (uint32_t)t2);
+	r.o[6] = (int)((uint32_t)x1 - (uint32_t)t2);
+	r.o[2] = (int)((uint32_t)x2 + (uint32_t)t1);
+	r.o[5] = (int)((uint32_t)x2 - (uint32_t)t1);
+	r.o[3] = (int)((uint32_t)x3 + (uint32_t)t0);
+	r.o[4] = (int)((uint32_t)x3 - (uint32_t)t0);
 	return r;
 }
 
 /* the same transform on full 32-bit inputs, all arithmetic wrapping (unsigned) like the
  * reference's int math on out-of-range streams */
-template <int BIAS, int SHIFT>
+template <int BIAS>
 __device__ __forceinline__ Idct1D idct1d_wide(int s0, int s1, int s2, int s3, int s4, int s5, int s6, int s7)
 {
 	uint32_t u0 = s0, u1 = s1, u2 = s2, u3 = s3, u4 = s4, u5 = s5, u6 = s6, u7 = s7;
@@ -136,23 +160,24 @@ __device__ __forceinline__ Idct1D idct1d_wide(int s0, int s1, int s2, int s3, in
 	uint32_t t1 = 3219u * u1 - 5681u * u3 + 1132u * u5 + 4816u * u7;
 	uint32_t t0 = 1131u * u1 - 3218u * u3 + 4816u * u5 - 5680u * u7;
 	Idct1D r;
-	r.o[0] = (int)(x0 + t3) >> SHIFT;
-	r.o[7] = (int)(x0 - t3) >> SHIFT;
-	r.o[1] = (int)(x1 + t2) >> SHIFT;
-	r.o[6] = (int)(x1 - t2) >> SHIFT;
-	r.o[2] = (int)(x2 + t1) >> SHIFT;
-	r.o[5] = (int)(x2 - t1) >> SHIFT;
-	r.o[3] = (int)(x3 + t0) >> SHIFT;
-	r.o[4] = (int)(x3 - t0) >> SHIFT;
+	r.o[0] = (int)(x0 + t3);
+	r.o[7] = (int)(x0 - t3);
+	r.o[1] = (int)(x1 + t2);
+	r.o[6] = (int)(x1 - t2);
+	r.o[2] = (int)(x2 + t1);
+	r.o[5] = (int)(x2 - t1);
+	r.o[3] = (int)(x3 + t0);
+	r.o[4] = (int)(x3 - t0);
 	return r;
 }
 
 #define MIJ_PASS2_BIAS (65536 + (128 << 17)) /* codec/jpeg.c:664 */
 
+/* second-pass sums -> eight clamped samples: (x >> 17) saturated to 0..255 (codec/jpeg.c:670-677) */
 __device__ __forceinline__ void pack_row(const Idct1D &r, uint32_t &lo, uint32_t &hi)
 {
-	lo = (uint32_t)clamp255(r.o[0]) | ((uint32_t)clamp255(r.o[1]) << 8) | ((uint32_t)clamp255(r.o[2]) << 16) | ((uint32_t)clamp255(r.o[3]) << 24);
-	hi = (uint32_t)clamp255(r.o[4]) | ((uint32_t)clamp255(r.o[5]) << 8) | ((uint32_t)clamp255(r.o[6]) << 16) | ((uint32_t)clamp255(r.o[7]) << 24);
+	lo = join16(ashr_sat_pk2<17>(r.o[0], r.o[1]), ashr_sat_pk2<17>(r.o[2], r.o[3]));
+	hi = join16(ashr_sat_pk2<17>(r.o[4], r.o[5]), ashr_sat_pk2<17>(r.o[6], r.o[7]));
 }
 
 /*
@@ -171,32 +196,32 @@ __device__ __forceinline__ void idct_block(const uint4 (&c)[8], const uint32_t *
 #pragma unroll
 		for (int g = 0; g < 4; ++g) {
 			const int a = ca[g], b = cb[g];
-			Idct1D va = idct1d_packed<512, 10>(pkmul(c[a].x, dq[4 * a + 0]), pkmul(c[a].y, dq[4 * a + 1]), pkmul(c[a].z, dq[4 * a + 2]),
+			Idct1D va = idct1d_packed<512>(pkmul(c[a].x, dq[4 * a + 0]), pkmul(c[a].y, dq[4 * a + 1]), pkmul(c[a].z, dq[4 * a + 2]),
 														  pkmul(c[a].w, dq[4 * a + 3]));
-			Idct1D vb = idct1d_packed<512, 10>(pkmul(c[b].x, dq[4 * b + 0]), pkmul(c[b].y, dq[4 * b + 1]), pkmul(c[b].z, dq[4 * b + 2]),
+			Idct1D vb = idct1d_packed<512>(pkmul(c[b].x, dq[4 * b + 0]), pkmul(c[b].y, dq[4 * b + 1]), pkmul(c[b].z, dq[4 * b + 2]),
 														  pkmul(c[b].w, dq[4 * b + 3]));
 #pragma unroll
 			for (int i = 0; i < 8; ++i)
-				pk[i][g] = pack_i16(va.o[i], vb.o[i]);
+				pk[i][g] = pack_i16(va.o[i] >> 10, vb.o[i] >> 10);
 		}
 #pragma unroll
 		for (int i = 0; i < 8; ++i) {
-			Idct1D r = idct1d_packed<MIJ_PASS2_BIAS, 17>(pk[i][0], pk[i][1], pk[i][2], pk[i][3]);
+			Idct1D r = idct1d_packed<MIJ_PASS2_BIAS>(pk[i][0], pk[i][1], pk[i][2], pk[i][3]);
 			pack_row(r, rows[i].x, rows[i].y);
 		}
 	} else {
 		int v[8][8]; /* v[row][col] */
 #pragma unroll
 		for (int k = 0; k < 8; ++k) {
-			Idct1D col = idct1d_packed<512, 10>(pkmul(c[k].x, dq[4 * k + 0]), pkmul(c[k].y, dq[4 * k + 1]), pkmul(c[k].z, dq[4 * k + 2]),
+			Idct1D col = idct1d_packed<512>(pkmul(c[k].x, dq[4 * k + 0]), pkmul(c[k].y, dq[4 * k + 1]), pkmul(c[k].z, dq[4 * k + 2]),
 															pkmul(c[k].w, dq[4 * k + 3]));
 #pragma unroll
 			for (int i = 0; i < 8; ++i)
-				v[i][k] = col.o[i];
+				v[i][k] = col.o[i] >> 10;
 		}
 #pragma unroll
 		for (int i = 0; i < 8; ++i) {
-			Idct1D r = idct1d_wide<MIJ_PASS2_BIAS, 17>(v[i][0], v[i][1], v[i][2], v[i][3], v[i][4], v[i][5], v[i][6], v[i][7]);
+			Idct1D r = idct1d_wide<MIJ_PASS2_BIAS>(v[i][0], v[i][1], v[i][2], v[i][3], v[i][4], v[i][5], v[i][6], v[i][7]);
 			pack_row(r, rows[i].x, rows[i].y);
 		}
 	}
@@ -221,9 +246,9 @@ __device__ __forceinline__ void ycbcr_to_rgb(int y, int cb, int cr, int &r, int 
 {
 	int yf = (y << 12) + 2048;
 	int crc = cr - 128, cbc = cb - 128;
-	r = clamp255((yf + crc * 5743) >> 12);
-	g = clamp255((yf + crc * -2925 + ((cbc * -1410) & ~255)) >> 12);
-	b = clamp255((yf + cbc * 7258) >> 12);
+	r = clamp255(opaque((yf + crc * 5743) >> 12));
+	g = clamp255(opaque((yf + crc * -2925 + ((cbc * -1410) & ~255)) >> 12));
+	b = clamp255(opaque((yf + cbc * 7258) >> 12));
 }
 
 __device__ __forceinline__ int compute_y(int r, int g, int b) { return ((r * 77) + (g * 150) + (29 * b)) >> 8 & 255; } /* common.c:173 */
@@ -460,16 +485,40 @@ __device__ __forceinline__ void fused420_pixel(const uint8_t *yrow, const uint8_
 	store_rgb_px<NOUT>(dst + (size_t)x * NOUT, r, g, b);
 }
 
-/* colour for one pixel from packed operands: pcr = (cr | y << 16), pcb = (cb | y << 16) */
-__device__ __forceinline__ uint32_t color_px(uint32_t pcr, uint32_t pcb)
+/* colour sums (before the >> 12) for one pixel from packed operands pcr = (cr | y << 16), pcb = (cb | y << 16):
+ * r = 4096 y + 2048 + 5743 (cr-128), etc., constants folded into the accumulators */
+struct Rgb12 {
+	int r, g, b;
+};
+__device__ __forceinline__ Rgb12 color_px(uint32_t pcr, uint32_t pcb)
 {
-	/* r = (4096 y + 2048 + 5743 (cr-128)) >> 12 and friends, constants folded into the accumulator */
-	int r = dot2(pcr, pk16(5743, 4096), 2048 - 128 * 5743) >> 12;
-	int b = dot2(pcb, pk16(7258, 4096), 2048 - 128 * 7258) >> 12;
+	Rgb12 c;
+	c.r = dot2(pcr, pk16(5743, 4096), 2048 - 128 * 5743);
+	c.b = dot2(pcb, pk16(7258, 4096), 2048 - 128 * 7258);
 	/* ((cb-128) * -1410) & ~255, plus 2048 + 128*2925 = 0x5BE80 split as 0x5BE00 (commutes with the mask) | 0x80 */
 	int t = dot2(pcb, pk16(-1410, 0), 128 * 1410 + 0x5BE00);
-	int g = dot2(pcr, pk16(-2925, 4096), (t & ~255) | 0x80) >> 12;
-	return (uint32_t)clamp255(r) | ((uint32_t)clamp255(g) << 8) | ((uint32_t)clamp255(b) << 16);
+	c.g = dot2(pcr, pk16(-2925, 4096), (t & ~255) | 0x80);
+	return c;
+}
+
+/* four pixels -> 12 (RGB) or 16 (RGBA) bytes, ">> 12 then clamp" done two samples per instruction */
+template <int NOUT>
+__device__ __forceinline__ void store_px4(uint8_t *__restrict__ dst, const Rgb12 &p0, const Rgb12 &p1, const Rgb12 &p2, const Rgb12 &p3)
+{
+	if (NOUT == 4) {
+		const int opaque_a = 0x7fffffff; /* saturates to 255 */
+		uint4 v;
+		v.x = join16(ashr_sat_pk2<12>(p0.r, p0.g), ashr_sat_pk2<12>(p0.b, opaque_a));
+		v.y = join16(ashr_sat_pk2<12>(p1.r, p1.g), ashr_sat_pk2<12>(p1.b, opaque_a));
+		v.z = join16(ashr_sat_pk2<12>(p2.r, p2.g), ashr_sat_pk2<12>(p2.b, opaque_a));
+		v.w = join16(ashr_sat_pk2<12>(p3.r, p3.g), ashr_sat_pk2<12>(p3.b, opaque_a));
+		*reinterpret_cast<uint4 *>(dst) = v;
+	} else {
+		uint32_t *q = reinterpret_cast<uint32_t *>(dst);
+		q[0] = join16(ashr_sat_pk2<12>(p0.r, p0.g), ashr_sat_pk2<12>(p0.b, p1.r));
+		q[1] = join16(ashr_sat_pk2<12>(p1.g, p1.b), ashr_sat_pk2<12>(p2.r, p2.g));
+		q[2] = join16(ashr_sat_pk2<12>(p2.b, p3.r), ashr_sat_pk2<12>(p3.g, p3.b));
+	}
 }
 
 template <int NOUT, bool WIDE>
@@ -569,35 +618,21 @@ __global__ __launch_bounds__(256) void k_fused420(const DevImage *__restrict__ i
 					const uint32_t yv = *reinterpret_cast<const uint32_t *>(yB + x0);
 					const uint32_t cb0 = dot4(vb0, wBk1, 128), cb1 = dot4(vb1, wBk, 128), cb2 = dot4(vb1, wBk1, 128), cb3 = dot4(vb2, wBk, 128);
 					const uint32_t cr0 = dot4(vr0, wBk1, 128), cr1 = dot4(vr1, wBk, 128), cr2 = dot4(vr1, wBk1, 128), cr3 = dot4(vr2, wBk, 128);
-					const uint32_t p0 = color_px(__builtin_amdgcn_perm(cr0, yv, 0x0c000c05), __builtin_amdgcn_perm(cb0, yv, 0x0c000c05));
-					const uint32_t p1 = color_px(__builtin_amdgcn_perm(cr1, yv, 0x0c010c05), __builtin_amdgcn_perm(cb1, yv, 0x0c010c05));
-					const uint32_t p2 = color_px(__builtin_amdgcn_perm(cr2, yv, 0x0c020c05), __builtin_amdgcn_perm(cb2, yv, 0x0c020c05));
-					const uint32_t p3 = color_px(__builtin_amdgcn_perm(cr3, yv, 0x0c030c05), __builtin_amdgcn_perm(cb3, yv, 0x0c030c05));
-					if (NOUT == 4) {
-						*reinterpret_cast<uint4 *>(dB) = make_uint4(p0 | 0xff000000u, p1 | 0xff000000u, p2 | 0xff000000u, p3 | 0xff000000u);
-					} else {
-						uint32_t *q = reinterpret_cast<uint32_t *>(dB);
-						q[0] = p0 | (p1 << 24);
-						q[1] = (p1 >> 8) | (p2 << 16);
-						q[2] = (p2 >> 16) | (p3 << 8);
-					}
+					const Rgb12 p0 = color_px(__builtin_amdgcn_perm(cr0, yv, 0x0c000c05), __builtin_amdgcn_perm(cb0, yv, 0x0c000c05));
+					const Rgb12 p1 = color_px(__builtin_amdgcn_perm(cr1, yv, 0x0c010c05), __builtin_amdgcn_perm(cb1, yv, 0x0c010c05));
+					const Rgb12 p2 = color_px(__builtin_amdgcn_perm(cr2, yv, 0x0c020c05), __builtin_amdgcn_perm(cb2, yv, 0x0c020c05));
+					const Rgb12 p3 = color_px(__builtin_amdgcn_perm(cr3, yv, 0x0c030c05), __builtin_amdgcn_perm(cb3, yv, 0x0c030c05));
+					store_px4<NOUT>(dB, p0, p1, p2, p3);
 				}
 				if (doA) {
 					const uint32_t yv = *reinterpret_cast<const uint32_t *>(yA + x0);
 					const uint32_t cb0 = dot4(vb0, wAk1, 128), cb1 = dot4(vb1, wAk, 128), cb2 = dot4(vb1, wAk1, 128), cb3 = dot4(vb2, wAk, 128);
 					const uint32_t cr0 = dot4(vr0, wAk1, 128), cr1 = dot4(vr1, wAk, 128), cr2 = dot4(vr1, wAk1, 128), cr3 = dot4(vr2, wAk, 128);
-					const uint32_t p0 = color_px(__builtin_amdgcn_perm(cr0, yv, 0x0c000c05), __builtin_amdgcn_perm(cb0, yv, 0x0c000c05));
-					const uint32_t p1 = color_px(__builtin_amdgcn_perm(cr1, yv, 0x0c010c05), __builtin_amdgcn_perm(cb1, yv, 0x0c010c05));
-					const uint32_t p2 = color_px(__builtin_amdgcn_perm(cr2, yv, 0x0c020c05), __builtin_amdgcn_perm(cb2, yv, 0x0c020c05));
-					const uint32_t p3 = color_px(__builtin_amdgcn_perm(cr3, yv, 0x0c030c05), __builtin_amdgcn_perm(cb3, yv, 0x0c030c05));
-					if (NOUT == 4) {
-						*reinterpret_cast<uint4 *>(dA) = make_uint4(p0 | 0xff000000u, p1 | 0xff000000u, p2 | 0xff000000u, p3 | 0xff000000u);
-					} else {
-						uint32_t *q = reinterpret_cast<uint32_t *>(dA);
-						q[0] = p0 | (p1 << 24);
-						q[1] = (p1 >> 8) | (p2 << 16);
-						q[2] = (p2 >> 16) | (p3 << 8);
-					}
+					const Rgb12 p0 = color_px(__builtin_amdgcn_perm(cr0, yv, 0x0c000c05), __builtin_amdgcn_perm(cb0, yv, 0x0c000c05));
+					const Rgb12 p1 = color_px(__builtin_amdgcn_perm(cr1, yv, 0x0c010c05), __builtin_amdgcn_perm(cb1, yv, 0x0c010c05));
+					const Rgb12 p2 = color_px(__builtin_amdgcn_perm(cr2, yv, 0x0c020c05), __builtin_amdgcn_perm(cb2, yv, 0x0c020c05));
+					const Rgb12 p3 = color_px(__builtin_amdgcn_perm(cr3, yv, 0x0c030c05), __builtin_amdgcn_perm(cb3, yv, 0x0c030c05));
+					store_px4<NOUT>(dA, p0, p1, p2, p3);
 				}
 			} else {
 				const int xe = min(x0 + 4, W);
