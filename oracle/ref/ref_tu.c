@@ -137,3 +137,62 @@ long ref_encode(unsigned char *dst, long cap, int w, int h, int comp, const void
 		return -1;
 	return k.n;
 }
+
+/* cpu_baseline helper (bench.py): decode n JPEGs `reps` times on `threads` pthreads with the
+ * reference's own stbi_load_from_memory, one image per task, discarding the pixels.  The only
+ * shared mutable state in the reference on this path is the failure-reason pointer (a benign
+ * race).  Returns decoded pixels; *secs = wall time. */
+#include <pthread.h>
+#include <time.h>
+
+typedef struct {
+	const unsigned char *const *bufs;
+	const int *lens;
+	int n, reps, req_comp;
+	long next, pixels;
+	pthread_mutex_t lock;
+} ref__many;
+
+static void *ref__many_worker(void *arg)
+{
+	ref__many *m = (ref__many *)arg;
+	long total = (long)m->n * m->reps, mine = 0;
+	for (;;) {
+		long i;
+		int x = 0, y = 0, c = 0;
+		unsigned char *p;
+		pthread_mutex_lock(&m->lock);
+		i = m->next++;
+		pthread_mutex_unlock(&m->lock);
+		if (i >= total)
+			break;
+		p = stbi_load_from_memory(m->bufs[i % m->n], m->lens[i % m->n], &x, &y, &c, m->req_comp);
+		if (p) {
+			mine += (long)x * y;
+			stbi_image_free(p);
+		}
+	}
+	pthread_mutex_lock(&m->lock);
+	m->pixels += mine;
+	pthread_mutex_unlock(&m->lock);
+	return NULL;
+}
+
+long ref_decode_many(const unsigned char *const *bufs, const int *lens, int n, int reps, int threads, int req_comp, double *secs)
+{
+	ref__many m;
+	pthread_t tid[256];
+	struct timespec t0, t1;
+	int i;
+	if (threads < 1) threads = 1;
+	if (threads > 256) threads = 256;
+	m.bufs = bufs; m.lens = lens; m.n = n; m.reps = reps; m.req_comp = req_comp; m.next = 0; m.pixels = 0;
+	pthread_mutex_init(&m.lock, NULL);
+	clock_gettime(CLOCK_MONOTONIC, &t0);
+	for (i = 0; i < threads; ++i) pthread_create(&tid[i], NULL, ref__many_worker, &m);
+	for (i = 0; i < threads; ++i) pthread_join(tid[i], NULL);
+	clock_gettime(CLOCK_MONOTONIC, &t1);
+	pthread_mutex_destroy(&m.lock);
+	if (secs) *secs = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+	return m.pixels;
+}

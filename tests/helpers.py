@@ -1,0 +1,218 @@
+"""Shared test plumbing: golden-vector access and ctypes views of the checkers under oracle/.
+
+Only tests (and smoke / bench's cpu_baseline leg) may touch oracle/; the product never does."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden", "jpeg_golden.npz")
+ORACLE_SO = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libstbref.so")
+
+P_INT = C.POINTER(C.c_int)
+
+
+class Golden:
+    def __init__(self, z):
+        self.z = z
+        self.names = bytes(z["names"]).decode().split("\n")
+        self.enc_names = bytes(z["enc_names"]).decode().split("\n")
+
+    def jpg(self, name):
+        return bytes(self.z[name + "/jpg"])
+
+    def expect(self, name, req):
+        """-> ('ok', pixels) or ('fail', reason)"""
+        k = "%s/out%d" % (name, req)
+        if k in self.z:
+            return "ok", self.z[k]
+        return "fail", bytes(self.z["%s/fail%d" % (name, req)]).decode()
+
+    def has(self, key):
+        return key in self.z
+
+    def __getitem__(self, key):
+        return self.z[key]
+
+
+def load_golden():
+    return Golden(np.load(GOLDEN, allow_pickle=False))
+
+
+def build_oracle():
+    if not os.path.exists(ORACLE_SO):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "port"], check=True)
+    return ORACLE_SO
+
+
+class Oracle:
+    """oracle/_build/liboracle.so -- our CPU restatement (the checker)."""
+
+    def __init__(self):
+        L = C.CDLL(build_oracle())
+        L.orc_load_from_memory.restype = C.POINTER(C.c_ubyte)
+        L.orc_load_from_memory.argtypes = [C.c_char_p, C.c_int, P_INT, P_INT, P_INT, C.c_int, C.POINTER(C.c_char_p)]
+        L.orc_free.argtypes = [C.c_void_p]
+        L.orc_info_from_memory.argtypes = [C.c_char_p, C.c_int, P_INT, P_INT, P_INT]
+        L.orc_idct_block.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_resample_row.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.orc_ycbcr_to_rgb_row.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.orc_decode_capture.restype = C.POINTER(C.c_ubyte)
+        L.orc_decode_capture.argtypes = [C.c_char_p, C.c_int, P_INT, P_INT, P_INT, C.c_int, C.c_void_p, C.c_long, C.POINTER(C.c_long)]
+        L.orc_encode.restype = C.c_long
+        L.orc_encode.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        self.L = L
+
+    def load(self, data, req=0):
+        """-> ('ok', pixels, comp) or ('fail', reason, None)"""
+        x, y, c = C.c_int(), C.c_int(), C.c_int()
+        why = C.c_char_p()
+        p = self.L.orc_load_from_memory(bytes(data), len(data), x, y, c, req, C.byref(why))
+        if not p:
+            return "fail", (why.value.decode() if why.value else None), None
+        n = req if req else c.value
+        a = np.ctypeslib.as_array(p, shape=(y.value * x.value * n,)).reshape(y.value, x.value, n).copy()
+        self.L.orc_free(p)
+        return "ok", a, c.value
+
+    def info(self, data):
+        x, y, c = C.c_int(), C.c_int(), C.c_int()
+        ok = self.L.orc_info_from_memory(bytes(data), len(data), x, y, c)
+        return ok, x.value, y.value, c.value
+
+    def idct(self, block):
+        b = np.ascontiguousarray(block, dtype=np.int16)
+        o = np.zeros(64, np.uint8)
+        self.L.orc_idct_block(o.ctypes.data, 8, b.ctypes.data)
+        return o
+
+    def resample(self, kind, near, far, hs):
+        near = np.ascontiguousarray(near, np.uint8)
+        far = np.ascontiguousarray(far, np.uint8)
+        o = np.zeros(len(near) * 4 + 8, np.uint8)
+        n = self.L.orc_resample_row(kind, o.ctypes.data, near.ctypes.data, far.ctypes.data, len(near), hs)
+        return o[:n].copy()
+
+    def ycc(self, y, cb, cr, step):
+        y, cb, cr = [np.ascontiguousarray(a, np.uint8) for a in (y, cb, cr)]
+        o = np.zeros(len(y) * step + 4, np.uint8)
+        self.L.orc_ycbcr_to_rgb_row(o.ctypes.data, y.ctypes.data, cb.ctypes.data, cr.ctypes.data, len(y), step)
+        return o[: len(y) * step].reshape(-1, step).copy()
+
+    def coef(self, data, req=0):
+        cap = np.zeros(1 << 22, dtype=np.int16)
+        n = C.c_long()
+        x, y, c = C.c_int(), C.c_int(), C.c_int()
+        p = self.L.orc_decode_capture(bytes(data), len(data), x, y, c, req, cap.ctypes.data, cap.size, C.byref(n))
+        if p:
+            self.L.orc_free(p)
+        return cap[: n.value].copy()
+
+    def encode(self, img, q):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w, c = img.shape
+        buf = np.zeros(w * h * 4 + 8192, np.uint8)
+        n = self.L.orc_encode(buf.ctypes.data, buf.size, w, h, c, img.ctypes.data, q)
+        if n < 0:
+            return None
+        return bytes(buf[:n])
+
+
+class Reference:
+    """oracle/_ref/libstbref.so -- the real reference compiled in place (build container only)."""
+
+    @staticmethod
+    def available():
+        return os.path.exists(REF_SO)
+
+    def __init__(self):
+        L = C.CDLL(REF_SO)
+        L.stbi_load_from_memory.restype = C.POINTER(C.c_ubyte)
+        L.stbi_load_from_memory.argtypes = [C.c_char_p, C.c_int, P_INT, P_INT, P_INT, C.c_int]
+        L.stbi_failure_reason.restype = C.c_char_p
+        L.stbi_image_free.argtypes = [C.c_void_p]
+        L.ref_encode.restype = C.c_long
+        L.ref_encode.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.ref_idct_block.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        self.L = L
+
+    def load(self, data, req=0):
+        x, y, c = C.c_int(), C.c_int(), C.c_int()
+        p = self.L.stbi_load_from_memory(bytes(data), len(data), x, y, c, req)
+        if not p:
+            return "fail", self.L.stbi_failure_reason().decode(), None
+        n = req if req else c.value
+        a = np.ctypeslib.as_array(p, shape=(y.value * x.value * n,)).reshape(y.value, x.value, n).copy()
+        self.L.stbi_image_free(p)
+        return "ok", a, c.value
+
+    def encode(self, img, q):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w, c = img.shape
+        buf = np.zeros(w * h * 4 + 8192, np.uint8)
+        n = self.L.ref_encode(buf.ctypes.data, buf.size, w, h, c, img.ctypes.data, q)
+        return None if n < 0 else bytes(buf[:n])
+
+    def idct(self, block):
+        b = np.ascontiguousarray(block, dtype=np.int16)
+        o = np.zeros(64, np.uint8)
+        self.L.ref_idct_block(o.ctypes.data, 8, b.ctypes.data)
+        return o
+
+
+def entropy_ranges(data):
+    """[(start, end)) byte ranges of the entropy-coded segments of a JPEG (after each SOS header)."""
+    out = []
+    i = 2
+    n = len(data)
+    while i + 4 <= n:
+        if data[i] != 0xFF:
+            i += 1
+            continue
+        m = data[i + 1]
+        if m == 0xFF:
+            i += 1
+            continue
+        if m == 0xD9:
+            break
+        if m == 0x01 or 0xD0 <= m <= 0xD7:
+            i += 2
+            continue
+        seglen = (data[i + 2] << 8) + data[i + 3]
+        i += 2 + seglen
+        if m == 0xDA:
+            start = i
+            while i + 1 < n and not (data[i] == 0xFF and data[i + 1] != 0x00 and not (0xD0 <= data[i + 1] <= 0xD7)):
+                i += 1
+            out.append((start, i))
+    return out
+
+
+def mutate(data, seed, n_mut=3, allow_markers=False):
+    """Deterministic in-place byte mutations confined to the entropy-coded segments: the headers and
+    tables stay intact, so both decoders always work from defined tables (the reference reads
+    uninitialised tables otherwise -- undefined behaviour no restatement can match).  Unless
+    allow_markers, no 0xFF byte is created or destroyed, so the marker structure is preserved too."""
+    rng = np.random.default_rng(seed)
+    b = bytearray(data)
+    ranges = [r for r in entropy_ranges(data) if r[1] - r[0] > 4]
+    if not ranges:
+        return bytes(b)
+    for _ in range(n_mut):
+        s, e = ranges[int(rng.integers(0, len(ranges)))]
+        for _try in range(32):
+            pos = int(rng.integers(s, e))
+            new = int(rng.integers(0, 256)) if rng.integers(0, 2) else b[pos] ^ (1 << int(rng.integers(0, 8)))
+            if allow_markers:
+                if pos + 1 < e:
+                    b[pos] = new
+                    break
+                continue
+            if b[pos] == 0xFF or new == 0xFF or (pos > s and b[pos - 1] == 0xFF):
+                continue
+            b[pos] = new
+            break
+    return bytes(b)

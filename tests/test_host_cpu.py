@@ -1,0 +1,215 @@
+"""CPU-side tests of the product: C-ABI surface, host entropy stage, JPEG writer, loud failure
+without a GPU.  No GPU compute calls here (-m "not gpu")."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import helpers
+
+ROOT = helpers.ROOT
+
+
+def _declared_functions(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = set()
+    for m in re.finditer(r"^[A-Za-z_][\w\s\*]*?\b(stbi_\w+|mij_\w+)\s*\(", src, flags=re.M):
+        names.add(m.group(1))
+    # static inline helpers are not exported
+    for m in re.finditer(r"static\s+inline\s+[\w\s\*]*?\b(\w+)\s*\(", src):
+        names.discard(m.group(1))
+    for m in re.finditer(r"typedef\s+[\w\s\*]*?\b(\w+)\s*\(", src):  # function typedefs (stbi_write_func)
+        names.discard(m.group(1))
+    return sorted(names)
+
+
+def test_library_exports_every_declared_symbol(ica):
+    L = ica.lib()
+    declared = _declared_functions("image_api.h") + _declared_functions("mij.h")
+    assert len(declared) >= 45
+    missing = [n for n in declared if not hasattr(L, n)]
+    assert not missing, missing
+    assert L.mij_abi_version() == 1
+
+
+def test_info_matches_reference(golden, ica):
+    for name in golden.names:
+        ok, w, h, c = ica.stbi_info_from_memory(golden.jpg(name))
+        want = golden[name + "/info"]
+        assert bool(ok) == bool(want[0]), name
+        if ok:
+            assert (w, h, c) == tuple(int(v) for v in want[1:]), name
+        else:
+            assert ica.stbi_failure_reason() == "unknown image type"
+
+
+def _dequantised_in_call_order(ica, desc, arena, progressive_order=False):
+    """tile-layout planes -> the reference's IDCT call order (MCU-interleaved for multi-component
+    baseline files; plane order for single-component and progressive files), de-quantised."""
+    planes = ica.detile_coefficients(desc, arena)
+    dq = [np.array(desc.dequant[desc.comp[i].tq][:], dtype=np.int32).reshape(8, 8) for i in range(desc.ncomp)]
+    blocks = []
+    if progressive_order or desc.ncomp == 1:
+        for ci in range(desc.ncomp):
+            cp = desc.comp[ci]
+            for j in range((cp.y + 7) >> 3):
+                for i in range((cp.x + 7) >> 3):
+                    blocks.append((planes[ci][j, i].astype(np.int32) * dq[ci]).astype(np.int16))
+    else:
+        for my in range(desc.mcu_y):
+            for mx in range(desc.mcu_x):
+                for ci in range(desc.ncomp):
+                    cp = desc.comp[ci]
+                    for y in range(cp.v):
+                        for x in range(cp.h):
+                            blocks.append((planes[ci][my * cp.v + y, mx * cp.h + x].astype(np.int32) * dq[ci]).astype(np.int16))
+    return np.stack(blocks).reshape(-1)
+
+
+def test_host_entropy_stage_matches_reference_coefficients(golden, ica, oracle):
+    n = 0
+    for name in golden.names:
+        if not golden.has(name + "/coef"):
+            continue
+        data = golden.jpg(name)
+        desc, arena = ica.HostDecoder.decode(data, 0)
+        prog = name.startswith("prog")
+        if name == "pil_base_30x22":
+            prog = False
+        got = _dequantised_in_call_order(ica, desc, arena, progressive_order=prog)
+        want = golden[name + "/coef"]
+        assert got.shape == want.shape, (name, got.shape, want.shape)
+        assert np.array_equal(got, want), name
+        n += 1
+    assert n >= 8
+
+
+def test_host_stage_failure_reasons_match_reference(golden, ica):
+    for name in golden.names:
+        kind, want = golden.expect(name, 3)
+        data = golden.jpg(name)
+        if kind == "fail":
+            with pytest.raises(ica.MijError) as e:
+                ica.HostDecoder.decode(data, 3)
+            assert str(e.value) == want, (name, str(e.value), want)
+        else:
+            ica.HostDecoder.decode(data, 3)
+    with pytest.raises(ica.MijError) as e:
+        ica.HostDecoder.decode(golden.jpg("b420_64x64_q90"), 5)
+    assert str(e.value) == "bad req_comp"
+
+
+def test_describe_follows_load_jpeg_image(golden, ica):
+    # codec/jpeg.c:2241-2249 and the colour branches :2320-2431
+    d = ica.HostDecoder.probe(golden.jpg("b420_64x64_q90"), 0)
+    assert (d.ncomp, d.n_out, d.color) == (3, 3, 1)
+    assert (d.comp[0].h, d.comp[0].v, d.comp[1].h, d.comp[1].v) == (2, 2, 1, 1)
+    assert (d.mcu_x, d.mcu_y, d.comp[0].bw, d.comp[1].bw) == (4, 4, 8, 4)
+    d = ica.HostDecoder.probe(golden.jpg("b420_64x64_q90"), 1)
+    assert (d.n_out, d.color) == (1, 0)  # luma only
+    d = ica.HostDecoder.probe(golden.jpg("grey_33x20"), 4)
+    assert (d.ncomp, d.n_out, d.color) == (1, 4, 0)
+    d = ica.HostDecoder.probe(golden.jpg("rgb_tagged_24x24"), 0)
+    assert d.color == 2
+    d = ica.HostDecoder.probe(golden.jpg("adobe_rgb_20x12"), 2)
+    assert (d.color, d.n_out) == (2, 2)
+    assert ica.HostDecoder.probe(golden.jpg("cmyk_transform0_40x30"), 0).color == 3
+    assert ica.HostDecoder.probe(golden.jpg("cmyk_transform2_40x30"), 0).color == 4
+    assert ica.HostDecoder.probe(golden.jpg("cmyk_transform1_40x30"), 0).color == 5
+    d = ica.HostDecoder.probe(golden.jpg("s41_35x19"), 0)
+    assert (d.h_max, d.v_max, d.comp[0].h, d.comp[1].h) == (4, 1, 4, 1)
+    d = ica.HostDecoder.probe(golden.jpg("s12_35x19"), 0)
+    assert (d.h_max, d.v_max, d.comp[0].v, d.comp[1].v) == (1, 2, 2, 1)
+
+
+def test_tile_layout_index_math(ica):
+    # include/mij.h: P = 8*col + rowslot[row]; plane index = (L>>6)<<12 | (P>>3)<<9 | (L&63)<<3 | P&7
+    d = ica.ImageDesc()
+    d.ncomp = 1
+    d.comp[0].bw, d.comp[0].bh = 9, 9  # 81 blocks -> 2 tiles
+    n = d.plane_elems(0)
+    assert n == 2 * 4096
+    arena = np.arange(n, dtype=np.int16)
+    nat = ica.detile_coefficients(d, arena)[0]
+    for (L, row, col) in [(0, 0, 0), (0, 4, 0), (5, 2, 3), (63, 7, 7), (64, 0, 0), (80, 1, 6)]:
+        P = 8 * col + (0, 4, 2, 5, 1, 6, 3, 7)[row]
+        idx = ((L >> 6) << 12) + ((P >> 3) << 9) + ((L & 63) << 3) + (P & 7)
+        assert nat[L // 9, L % 9, row, col] == arena[idx]
+
+
+def test_wide_idct_flag(golden, ica):
+    # ordinary images never need the exact 32-bit second pass
+    for name in ("b420_64x64_q90", "b444_64x64_q92", "prog_420_64x64", "grey_33x20"):
+        d, _ = ica.HostDecoder.decode(golden.jpg(name), 3)
+        assert d.flags == 0, name
+    # a stream whose quantisation table is blown up to 65535 per step must raise it
+    data = bytearray(golden.jpg("b420_64x64_q90"))
+    i = bytes(data).index(b"\xff\xdb")
+    for k in range(64):
+        data[i + 5 + k] = 255
+    d, _ = ica.HostDecoder.decode(bytes(data), 3)
+    assert d.flags & 1
+
+
+def test_writer_matches_reference_bytes(golden, ica):
+    for nm in golden.enc_names:
+        got = ica.stbi_write_jpg_to_memory(golden[nm + "/rgb"], int(golden[nm + "/q"][0]))
+        assert got == bytes(golden[nm + "/jpg"]), nm
+    assert ica.stbi_write_jpg_to_memory(np.zeros((0, 4, 3), np.uint8), 90) is None
+
+
+def test_writer_vs_oracle_seeded(ica, oracle):
+    rng = np.random.default_rng(7)
+    for i in range(25):
+        w, h, c = int(rng.integers(1, 70)), int(rng.integers(1, 50)), int(rng.choice([1, 2, 3, 4]))
+        q = int(rng.choice([1, 25, 50, 90, 91, 100]))
+        img = rng.integers(0, 256, (h, w, c)).astype(np.uint8)
+        assert ica.stbi_write_jpg_to_memory(img, q) == oracle.encode(img, q), (w, h, c, q)
+
+
+def test_host_stage_vs_oracle_fuzz(golden, ica, oracle):
+    """Mutated entropy data: the product's host stage and the oracle agree on accept/reject, on the
+    failure reason and on every de-quantised coefficient block."""
+    n_ok = n_fail = 0
+    for name in ("b420_64x64_q90", "b444_40x24_q95", "grey_33x20", "b422_37x21", "s41_35x19"):
+        base = golden.jpg(name)
+        for seed in range(40):
+            data = helpers.mutate(base, seed * 104729 + len(name), allow_markers=(seed % 4 == 0))
+            o = oracle.load(data, 0)
+            if o[0] == "fail":
+                with pytest.raises(ica.MijError) as e:
+                    ica.HostDecoder.decode(data, 0)
+                assert str(e.value) == o[1], (name, seed)
+                n_fail += 1
+            else:
+                desc, arena = ica.HostDecoder.decode(data, 0)
+                got = _dequantised_in_call_order(ica, desc, arena)
+                assert np.array_equal(got, oracle.coef(data)), (name, seed)
+                n_ok += 1
+    assert n_ok > 50 and n_fail > 5
+
+
+def test_synthetic_generator_is_deterministic(ica):
+    a = ica.synth_rgb(37, 21, seed=3)
+    # direct evaluation of the SURVEY 8d definition
+    state = (12345 + 3) & 0xFFFFFFFF
+    ref = np.zeros((21, 37, 3), np.uint8)
+    for y in range(21):
+        for x in range(37):
+            state = (state * 1664525 + 1013904223) & 0xFFFFFFFF
+            n = (state >> 24) & 15
+            ref[y, x] = (min(255, x * 255 // 37 + n), min(255, y * 255 // 21 + n), min(255, (x + y) * 255 // 58 + n))
+    assert np.array_equal(a, ref)
+    assert ica.synth_jpeg(64, 48, 1) == ica.synth_jpeg(64, 48, 1)
+
+
+def test_decode_fails_loudly_without_gpu(golden, ica):
+    if ica.gpu_available():
+        pytest.skip("a GPU is present: the no-device behaviour is covered on the CPU box")
+    assert ica.stbi_load_from_memory(golden.jpg("b420_64x64_q90"), 3) is None
+    assert ica.stbi_failure_reason() == "no gpu device"
+    with pytest.raises(ica.MijError):
+        ica.Context()

@@ -1,0 +1,123 @@
+"""The oracle (our CPU restatement under oracle/) against the golden vectors the REAL reference
+produced (tests/golden/make_golden.py).  This is what pins the oracle; everything on the GPU is
+then checked against the oracle and, directly, against the same golden vectors."""
+import numpy as np
+import pytest
+
+import helpers
+
+
+def test_golden_file_is_data_only(golden):
+    # numpy arrays only, loadable without pickle
+    assert len(golden.names) >= 50
+    assert len(golden.enc_names) >= 8
+
+
+def test_oracle_decode_matches_reference_outputs(golden, oracle):
+    checked = 0
+    for name in golden.names:
+        data = golden.jpg(name)
+        for req in range(5):
+            kind, want = golden.expect(name, req)
+            got = oracle.load(data, req)
+            if kind == "fail":
+                assert got[0] == "fail", (name, req)
+                assert got[1] == want, (name, req, got[1], want)
+            else:
+                assert got[0] == "ok", (name, req, got[1])
+                if name == "dri_without_rst":
+                    continue  # the reference reads uninitialised planes here (codec/jpeg.c:1184-1187, :1641)
+                assert got[1].shape == want.shape, (name, req)
+                assert np.array_equal(got[1], want), (name, req, int((got[1] != want).sum()))
+            checked += 1
+    assert checked >= 250
+
+
+def test_oracle_info(golden, oracle):
+    for name in golden.names:
+        ok, w, h, c = oracle.info(golden.jpg(name))
+        want = golden[name + "/info"]
+        assert bool(ok) == bool(want[0]), name
+        if ok:
+            assert (w, h, c) == tuple(int(v) for v in want[1:]), name
+
+
+def test_oracle_coefficients(golden, oracle):
+    n = 0
+    for name in golden.names:
+        if golden.has(name + "/coef"):
+            assert np.array_equal(oracle.coef(golden.jpg(name)), golden[name + "/coef"]), name
+            n += 1
+    assert n >= 8
+
+
+def test_oracle_idct_known_answers(golden, oracle):
+    blocks, outs = golden["idct/in"], golden["idct/out"]
+    for i in range(len(blocks)):
+        assert np.array_equal(oracle.idct(blocks[i]), outs[i]), i
+
+
+def test_oracle_resamplers(golden, oracle):
+    for kind, kname, hs in ((1, "v2", 2), (2, "h2", 2), (3, "hv2", 2), (4, "generic3", 3)):
+        for w in (1, 2, 3, 8, 17):
+            near = golden["resample/%s/%d/near" % (kname, w)]
+            far = golden["resample/%s/%d/far" % (kname, w)]
+            assert np.array_equal(oracle.resample(kind, near, far, hs), golden["resample/%s/%d/out" % (kname, w)]), (kname, w)
+
+
+def test_oracle_colour(golden, oracle):
+    t = golden["ycc/in"]
+    assert np.array_equal(oracle.ycc(t[:, 0], t[:, 1], t[:, 2], 3), golden["ycc/out3"])
+    assert np.array_equal(oracle.ycc(t[:, 0], t[:, 1], t[:, 2], 4)[:, :3], golden["ycc/out4"][:, :3])
+
+
+def test_oracle_encoder(golden, oracle):
+    for nm in golden.enc_names:
+        got = oracle.encode(golden[nm + "/rgb"], int(golden[nm + "/q"][0]))
+        assert got == bytes(golden[nm + "/jpg"]), nm
+
+
+@pytest.mark.skipif(not helpers.Reference.available(), reason="oracle/_ref not built (reference absent on this box)")
+def test_oracle_vs_live_reference_seeded(oracle):
+    """Beyond the committed vectors: seeded inputs through the reference library itself."""
+    ref = helpers.Reference()
+    rng = np.random.default_rng(2024)
+    for i in range(40):
+        w, h = int(rng.integers(1, 90)), int(rng.integers(1, 70))
+        q = int(rng.choice([5, 30, 50, 75, 90, 91, 100]))
+        img = rng.integers(0, 256, (h, w, 3)).astype(np.uint8) if i % 2 else np.tile(np.arange(w, dtype=np.uint8)[None, :, None] * 3, (h, 1, 3))
+        jr, jo = ref.encode(img, q), oracle.encode(img, q)
+        assert jr == jo, (w, h, q)
+        for req in (0, 1, 2, 3, 4):
+            a, b = ref.load(jr, req), oracle.load(jr, req)
+            assert a[0] == b[0] == "ok"
+            assert np.array_equal(a[1], b[1]), (w, h, q, req)
+    # IDCT on adversarial blocks
+    for amp in (100, 2000, 32767):
+        for _ in range(200):
+            blk = rng.integers(-amp, amp + 1, 64).astype(np.int16)
+            assert np.array_equal(ref.idct(blk), oracle.idct(blk))
+
+
+@pytest.mark.skipif(not helpers.Reference.available(), reason="oracle/_ref not built (reference absent on this box)")
+def test_oracle_vs_live_reference_fuzz(golden, oracle):
+    """Mutated streams: same accept/reject decision and reason; same pixels whenever both decode.
+    (Streams on which the reference consumes uninitialised memory are skipped: those are the ones
+    that bail out of a scan early, which only happens with a restart interval defined.)"""
+    ref = helpers.Reference()
+    agree = 0
+    for name in ("b420_64x64_q90", "b444_40x24_q95", "prog_420_64x64", "prog_444_64x64", "rst_blocks_64x48", "grey_33x20", "b422_37x21"):
+        base = golden.jpg(name)
+        for seed in range(60):
+            # marker-creating mutations only on plain baseline files (a marker inside a progressive or
+            # restart-interval scan makes the reference read never-written planes)
+            markers = (seed % 3 == 0) and name.startswith(("b4", "grey"))
+            data = helpers.mutate(base, seed * 7919 + len(name), allow_markers=markers)
+            a, b = ref.load(data, 3), oracle.load(data, 3)
+            assert a[0] == b[0], (name, seed, a[1] if a[0] == "fail" else "ok", b[1] if b[0] == "fail" else "ok")
+            if a[0] == "fail":
+                assert a[1] == b[1], (name, seed)
+            elif not name.startswith("rst"):
+                assert np.array_equal(a[1], b[1]), (name, seed)
+            agree += 1
+    assert agree == 420
