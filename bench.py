@@ -39,6 +39,28 @@ ALGO_BYTES_PER_IMAGE = 2 * 64 * 48960 + 3 * W * H  # 6 266 880 +
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def usable_cores():
+    """Host threads this process may really use: the affinity mask, capped by the cgroup CPU quota
+    (a GPU box shows every core of the host in the mask but grants a 1-GPU job only a share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, (q + p // 2) // p))
+        except (OSError, ValueError):
+            pass
+    env = os.environ.get("BENCH_CPU_THREADS")
+    if env:
+        n = max(1, int(env))
+    return n
+
+
 def cpu_baseline(datas, want_seconds=12.0):
     """Times the CPU checker on a bounded sample (all host cores, one image per task)."""
     ref_so = os.path.join(ROOT, "oracle", "_ref", "libstbref.so")
@@ -57,14 +79,15 @@ def cpu_baseline(datas, want_seconds=12.0):
     bufs = (C.c_char_p * n)(*datas)
     lens = (C.c_int * n)(*[len(d) for d in datas])
     secs = C.c_double()
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = usable_cores()
     # single thread, one pass over the sample
     px1 = f(bufs, lens, n, 1, 1, 3, C.byref(secs))
     t1 = secs.value
     single = px1 / t1 / 1e6
-    # all cores: size the repetition count for ~want_seconds of wall time
-    reps = max(1, int(want_seconds * cores / max(t1, 1e-3)))
-    reps = min(reps, 64 * cores)
+    # all usable cores: calibrate with a short run, then size the real one for ~want_seconds of wall time
+    cal_reps = max(1, (2 * cores + n - 1) // n)
+    f(bufs, lens, n, cal_reps, cores, 3, C.byref(secs))
+    reps = max(cal_reps, min(int(want_seconds / max(secs.value, 1e-3) * cal_reps), 4096))
     px = f(bufs, lens, n, reps, cores, 3, C.byref(secs))
     return {
         "value": round(px / secs.value / 1e6, 1),
