@@ -63,10 +63,32 @@ typedef unsigned short v2u __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ constexpr uint32_t pk16(int lo, int hi) { return (uint32_t)(uint16_t)lo | ((uint32_t)(uint16_t)hi << 16); }
 
-/* a.lo*b.lo + a.hi*b.hi + acc in wrapping 32-bit (v_dot2_i32_i16, no clamp) */
+/*
+ * Measured on MI355X (profiles/r01_isa_probe*.txt): every 8-byte VALU encoding (VOP3, VOP3P, SDWA:
+ * v_dot2, v_dot4, v_perm, v_pk_mul, v_and_or ...) issues at one rate, 4-byte VOP1/VOP2 forms a
+ * bit faster, v_ashr_pk_u8_i32 at half rate -- so the kernels are tuned for instruction COUNT.
+ */
+
+/* a.lo*b.lo + a.hi*b.hi + acc in wrapping 32-bit: the three-address VOP3P form of v_dot2_i32_i16
+ * (the compiler only picks the tied v_dot2c form, which costs a v_mov per accumulator seed).
+ * The constant operand lives in a VGPR (see vreg). */
 __device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int acc)
 {
-	return __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, a), __builtin_bit_cast(v2s, b), acc, false);
+	int d;
+	asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(acc));
+	return d;
+}
+__device__ __forceinline__ int dot2z(uint32_t a, uint32_t b)
+{
+	int d;
+	asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
+	return d;
+}
+/* a loop-invariant constant pinned in a vector register */
+__device__ __forceinline__ uint32_t vreg(uint32_t c)
+{
+	asm("" : "+v"(c));
+	return c;
 }
 /* sum of four u8*u8 products + acc (v_dot4_u32_u8) */
 __device__ __forceinline__ uint32_t dot4(uint32_t a, uint32_t b, uint32_t acc) { return __builtin_amdgcn_udot4(a, b, acc, false); }
@@ -75,29 +97,48 @@ __device__ __forceinline__ uint32_t pkmul(uint32_t a, uint32_t b)
 {
 	return __builtin_bit_cast(uint32_t, (v2u)(__builtin_bit_cast(v2u, a) * __builtin_bit_cast(v2u, b)));
 }
-/* saturating pack of two i32 to i16 pairs (v_cvt_pk_i16_i32); exact whenever both fit */
-__device__ __forceinline__ uint32_t pack_i16(int lo, int hi) { return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(lo, hi)); }
+/* (x & m) | o in one instruction */
+__device__ __forceinline__ uint32_t and_or(uint32_t x, uint32_t m, uint32_t o)
+{
+	uint32_t d;
+	asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(m), "v"(o));
+	return d;
+}
 
 __device__ __forceinline__ int clamp255(int x) { return x < 0 ? 0 : (x > 255 ? 255 : x); }
 
 /*
- * v_ashr_pk_u8_i32 (new on gfx950): byte0 = sat_u8(a >> S), byte1 = sat_u8(b >> S).  The
- * instruction writes only the low half of its destination (the other half keeps whatever the
- * register held; ROCm 7.2's own pattern for it assumes zeros there and mis-compiles
- * "clamp(x>>n) | clamp(y>>n) << 8 | ..." chains), so it is used through asm and only bytes 0..1
- * of the result are ever consumed (join16).  This one instruction is the reference's
- * ">> 17, stbi__clamp" (codec/jpeg.c:670-677) and ">> 20, clamp" (:1988-2011) for two samples.
+ * v_ashr_pk_u8_i32 (new on gfx950): sat_u8(a >> S) | sat_u8(b >> S) << 8 into ONE half of the
+ * destination (op_sel picks the half, the other half is preserved -- measured).  ROCm 7.2's own
+ * pattern for it assumes the other half is zeroed and mis-compiles "clamp(x>>n) | clamp(y>>n) << 8
+ * | ..." chains, so it is only ever emitted here, through asm.  Two of them give four clamped
+ * samples in a dword: the reference's ">> 17, stbi__clamp" (codec/jpeg.c:670-677) and
+ * ">> 20, clamp" (:1988-2011).
  */
 template <int S>
-__device__ __forceinline__ uint32_t ashr_sat_pk2(int a, int b)
+__device__ __forceinline__ uint32_t sat4(int a, int b, int c, int d)
 {
-	uint32_t d;
-	asm("v_ashr_pk_u8_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "n"(S));
-	return d;
+	uint32_t r;
+	asm("v_ashr_pk_u8_i32 %0, %1, %2, %5\n\t"
+		 "v_ashr_pk_u8_i32 %0, %3, %4, %5 op_sel:[0,0,0,1]\n\t"
+		 "s_nop 0"
+		 : "=&v"(r)
+		 : "v"(a), "v"(b), "v"(c), "v"(d), "n"(S));
+	return r;
 }
-/* bytes (lo.0, lo.1, hi.0, hi.1) */
-__device__ __forceinline__ uint32_t join16(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x05040100); }
-/* keeps the compiler from fusing a preceding shift with a following clamp into the pattern above */
+/* (lo >> S) | (hi >> S) << 16 as int16 pairs: shift, then an SDWA shift into the upper half */
+template <int S>
+__device__ __forceinline__ uint32_t shr_pack_i16(int lo, int hi)
+{
+	uint32_t r;
+	asm("v_ashrrev_i32 %0, %3, %1\n\t"
+		 "v_ashrrev_i32_sdwa %0, %3, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+		 "s_nop 0"
+		 : "=&v"(r)
+		 : "v"(lo), "v"(hi), "n"(S));
+	return r;
+}
+/* keeps the compiler from fusing a preceding shift with a following clamp into the v_ashr_pk pattern */
 __device__ __forceinline__ int opaque(int x)
 {
 	asm("" : "+v"(x));
@@ -114,34 +155,58 @@ __device__ __forceinline__ int opaque(int x)
  *     x3 = 4096 s0 - 5352 s2 + 4096 s4 - 2217 s6          t0 = 1131 s1 - 3218 s3 + 4816 s5 - 5680 s7
  * out = (x0+t3, x1+t2, x2+t1, x3+t0, x3-t0, x2-t1, x1-t2, x0-t3) + bias; the callers shift (>>10, >>17).
  * With the inputs paired as (s0,s4) (s2,s6) (s1,s3) (s5,s7) -- exactly how the tile layout stores
- * a column -- that is 14 v_dot2 + 8 add/sub + 8 shifts per 1-D transform.
+ * a column -- that is 14 v_dot2 + 8 add/sub per 1-D transform.
  */
 struct Idct1D {
 	int o[8];
 };
 
-template <int BIAS>
-__device__ __forceinline__ Idct1D idct1d_packed(uint32_t d04, uint32_t d26, uint32_t d13, uint32_t d57)
+/* the matrix entries as int16 pairs, pinned in vector registers once per kernel */
+struct IdctK {
+	uint32_t e0, e1, x0, x3, x1, x2, t3a, t3b, t2a, t2b, t1a, t1b, t0a, t0b;
+	int bias1, bias2;
+	__device__ __forceinline__ void init()
+	{
+		e0 = vreg(pk16(4096, 4096));
+		e1 = vreg(pk16(4096, -4096));
+		x0 = vreg(pk16(5352, 2217));
+		x3 = vreg(pk16(-5352, -2217));
+		x1 = vreg(pk16(2217, -5350));
+		x2 = vreg(pk16(-2217, 5350));
+		t3a = vreg(pk16(5683, 4816));
+		t3b = vreg(pk16(3219, 1131));
+		t2a = vreg(pk16(4816, -1129));
+		t2b = vreg(pk16(-5681, -3218));
+		t1a = vreg(pk16(3219, -5681));
+		t1b = vreg(pk16(1132, 4816));
+		t0a = vreg(pk16(1131, -3218));
+		t0b = vreg(pk16(4816, -5680));
+		bias1 = (int)vreg(512);                       /* codec/jpeg.c:639 */
+		bias2 = (int)vreg(65536 + (128 << 17));       /* codec/jpeg.c:664 */
+	}
+};
+
+__device__ __forceinline__ Idct1D idct1d_packed(const IdctK &K, int bias, uint32_t d04, uint32_t d26, uint32_t d13, uint32_t d57)
 {
-	int e0 = dot2(d04, pk16(4096, 4096), BIAS);
-	int e1 = dot2(d04, pk16(4096, -4096), BIAS);
-	int x0 = dot2(d26, pk16(5352, 2217), e0);
-	int x3 = dot2(d26, pk16(-5352, -2217), e0);
-	int x1 = dot2(d26, pk16(2217, -5350), e1);
-	int x2 = dot2(d26, pk16(-2217, 5350), e1);
-	int t3 = dot2(d13, pk16(5683, 4816), dot2(d57, pk16(3219, 1131), 0));
-	int t2 = dot2(d13, pk16(4816, -1129), dot2(d57, pk16(-5681, -3218), 0));
-	int t1 = dot2(d13, pk16(3219, -5681), dot2(d57, pk16(1132, 4816), 0));
-	int t0 = dot2(d13, pk16(1131, -3218), dot2(d57, pk16(4816, -5680), 0));
+	int e0 = dot2(d04, K.e0, bias);
+	int e1 = dot2(d04, K.e1, bias);
+	uint32_t x0 = (uint32_t)dot2(d26, K.x0, e0);
+	uint32_t x3 = (uint32_t)dot2(d26, K.x3, e0);
+	uint32_t x1 = (uint32_t)dot2(d26, K.x1, e1);
+	uint32_t x2 = (uint32_t)dot2(d26, K.x2, e1);
+	uint32_t t3 = (uint32_t)dot2(d13, K.t3a, dot2z(d57, K.t3b));
+	uint32_t t2 = (uint32_t)dot2(d13, K.t2a, dot2z(d57, K.t2b));
+	uint32_t t1 = (uint32_t)dot2(d13, K.t1a, dot2z(d57, K.t1b));
+	uint32_t t0 = (uint32_t)dot2(d13, K.t0a, dot2z(d57, K.t0b));
 	Idct1D r;
-	r.o[0] = (int)((uint32_t)x0 + (uint32_t)t3);
-	r.o[7] = (int)((uint32_t)x0 - (uint32_t)t3);
-	r.o[1] = (int)((uint32_t)x1 + (uint32_t)t2);
-	r.o[6] = (int)((uint32_t)x1 - (uint32_t)t2);
-	r.o[2] = (int)((uint32_t)x2 + (uint32_t)t1);
-	r.o[5] = (int)((uint32_t)x2 - (uint32_t)t1);
-	r.o[3] = (int)((uint32_t)x3 + (uint32_t)t0);
-	r.o[4] = (int)((uint32_t)x3 - (uint32_t)t0);
+	r.o[0] = (int)(x0 + t3);
+	r.o[7] = (int)(x0 - t3);
+	r.o[1] = (int)(x1 + t2);
+	r.o[6] = (int)(x1 - t2);
+	r.o[2] = (int)(x2 + t1);
+	r.o[5] = (int)(x2 - t1);
+	r.o[3] = (int)(x3 + t0);
+	r.o[4] = (int)(x3 - t0);
 	return r;
 }
 
@@ -176,8 +241,8 @@ __device__ __forceinline__ Idct1D idct1d_wide(int s0, int s1, int s2, int s3, in
 /* second-pass sums -> eight clamped samples: (x >> 17) saturated to 0..255 (codec/jpeg.c:670-677) */
 __device__ __forceinline__ void pack_row(const Idct1D &r, uint32_t &lo, uint32_t &hi)
 {
-	lo = join16(ashr_sat_pk2<17>(r.o[0], r.o[1]), ashr_sat_pk2<17>(r.o[2], r.o[3]));
-	hi = join16(ashr_sat_pk2<17>(r.o[4], r.o[5]), ashr_sat_pk2<17>(r.o[6], r.o[7]));
+	lo = sat4<17>(r.o[0], r.o[1], r.o[2], r.o[3]);
+	hi = sat4<17>(r.o[4], r.o[5], r.o[6], r.o[7]);
 }
 
 /*
@@ -187,7 +252,7 @@ __device__ __forceinline__ void pack_row(const Idct1D &r, uint32_t &lo, uint32_t
  * WIDE = false requires every first-pass output to fit int16 (host guarantee, mij.h).
  */
 template <bool WIDE>
-__device__ __forceinline__ void idct_block(const uint4 (&c)[8], const uint32_t *__restrict__ dq, uint2 (&rows)[8])
+__device__ __forceinline__ void idct_block(const IdctK &K, const uint4 (&c)[8], const uint32_t *__restrict__ dq, uint2 (&rows)[8])
 {
 	if constexpr (!WIDE) {
 		/* pk[i][g]: row i, column pair g = (0,4) (2,6) (1,3) (5,7) */
@@ -196,25 +261,25 @@ __device__ __forceinline__ void idct_block(const uint4 (&c)[8], const uint32_t *
 #pragma unroll
 		for (int g = 0; g < 4; ++g) {
 			const int a = ca[g], b = cb[g];
-			Idct1D va = idct1d_packed<512>(pkmul(c[a].x, dq[4 * a + 0]), pkmul(c[a].y, dq[4 * a + 1]), pkmul(c[a].z, dq[4 * a + 2]),
-														  pkmul(c[a].w, dq[4 * a + 3]));
-			Idct1D vb = idct1d_packed<512>(pkmul(c[b].x, dq[4 * b + 0]), pkmul(c[b].y, dq[4 * b + 1]), pkmul(c[b].z, dq[4 * b + 2]),
-														  pkmul(c[b].w, dq[4 * b + 3]));
+			Idct1D va = idct1d_packed(K, K.bias1, pkmul(c[a].x, dq[4 * a + 0]), pkmul(c[a].y, dq[4 * a + 1]), pkmul(c[a].z, dq[4 * a + 2]),
+											  pkmul(c[a].w, dq[4 * a + 3]));
+			Idct1D vb = idct1d_packed(K, K.bias1, pkmul(c[b].x, dq[4 * b + 0]), pkmul(c[b].y, dq[4 * b + 1]), pkmul(c[b].z, dq[4 * b + 2]),
+											  pkmul(c[b].w, dq[4 * b + 3]));
 #pragma unroll
 			for (int i = 0; i < 8; ++i)
-				pk[i][g] = pack_i16(va.o[i] >> 10, vb.o[i] >> 10);
+				pk[i][g] = shr_pack_i16<10>(va.o[i], vb.o[i]);
 		}
 #pragma unroll
 		for (int i = 0; i < 8; ++i) {
-			Idct1D r = idct1d_packed<MIJ_PASS2_BIAS>(pk[i][0], pk[i][1], pk[i][2], pk[i][3]);
+			Idct1D r = idct1d_packed(K, K.bias2, pk[i][0], pk[i][1], pk[i][2], pk[i][3]);
 			pack_row(r, rows[i].x, rows[i].y);
 		}
 	} else {
 		int v[8][8]; /* v[row][col] */
 #pragma unroll
 		for (int k = 0; k < 8; ++k) {
-			Idct1D col = idct1d_packed<512>(pkmul(c[k].x, dq[4 * k + 0]), pkmul(c[k].y, dq[4 * k + 1]), pkmul(c[k].z, dq[4 * k + 2]),
-															pkmul(c[k].w, dq[4 * k + 3]));
+			Idct1D col = idct1d_packed(K, K.bias1, pkmul(c[k].x, dq[4 * k + 0]), pkmul(c[k].y, dq[4 * k + 1]), pkmul(c[k].z, dq[4 * k + 2]),
+												pkmul(c[k].w, dq[4 * k + 3]));
 #pragma unroll
 			for (int i = 0; i < 8; ++i)
 				v[i][k] = col.o[i] >> 10;
@@ -394,10 +459,12 @@ __global__ __launch_bounds__(256) void k_idct_planes(const DevImage *__restrict_
 	const uint32_t L = wk.first + threadIdx.x;
 	if (L >= nblk)
 		return;
+	IdctK K;
+	K.init();
 	uint4 c[8];
 	load_block(coef + cp.coef_off, L, c);
 	uint2 rows[8];
-	idct_block<WIDE>(c, im.dq[wk.comp], rows);
+	idct_block<WIDE>(K, c, im.dq[wk.comp], rows);
 	const uint32_t by = L / (uint32_t)cp.bw, bx = L - by * (uint32_t)cp.bw;
 	const size_t w2 = (size_t)cp.bw * 8;
 	uint8_t *dst = planes + cp.plane_off + (size_t)by * 8 * w2 + (size_t)bx * 8;
@@ -485,40 +552,95 @@ __device__ __forceinline__ void fused420_pixel(const uint8_t *yrow, const uint8_
 	store_rgb_px<NOUT>(dst + (size_t)x * NOUT, r, g, b);
 }
 
+/* colour constants pinned in vector registers (see color_px) */
+struct ColorK {
+	uint32_t r, b, t, g, mask, o80, w128;
+	int kr, kb, kt;
+	uint32_t wBk, wBk1, wAk, wAk1;
+	uint32_t v0, v1, v2, p0, p1, p2, p3;
+	__device__ __forceinline__ void init()
+	{
+		r = vreg(pk16(5743, 4096));
+		b = vreg(pk16(7258, 4096));
+		t = vreg(pk16(-1410, 0));
+		g = vreg(pk16(-2925, 4096));
+		mask = vreg(0xffffff00u);
+		o80 = vreg(0x80u);
+		w128 = vreg(128u);
+		kr = (int)vreg((uint32_t)(2048 - 128 * 5743));
+		kb = (int)vreg((uint32_t)(2048 - 128 * 7258));
+		kt = (int)vreg((uint32_t)(128 * 1410 + 0x5BE00));
+		/* h2v2 weights x16, byte order of the operand is (B_k, A_k, B_k+1, A_k+1) */
+		wBk = vreg(0x10303090u);  /* near = B, centre = k   : 9B_k + 3A_k + 3B_k1 +  A_k1 */
+		wBk1 = vreg(0x30901030u); /* near = B, centre = k+1 : 3B_k +  A_k + 9B_k1 + 3A_k1 */
+		wAk = vreg(0x30109030u);  /* near = A, centre = k   : 3B_k + 9A_k +  B_k1 + 3A_k1 */
+		wAk1 = vreg(0x90303010u); /* near = A, centre = k+1 :  B_k + 3A_k + 3B_k1 + 9A_k1 */
+		/* v_perm selectors: V_k = (B[k], A[k], B[k+1], A[k+1]); (chroma byte 1 | luma byte j << 16) */
+		v0 = vreg(0x05010400u);
+		v1 = vreg(0x06020501u);
+		v2 = vreg(0x07030602u);
+		p0 = vreg(0x0c000c05u);
+		p1 = vreg(0x0c010c05u);
+		p2 = vreg(0x0c020c05u);
+		p3 = vreg(0x0c030c05u);
+	}
+};
+
 /* colour sums (before the >> 12) for one pixel from packed operands pcr = (cr | y << 16), pcb = (cb | y << 16):
- * r = 4096 y + 2048 + 5743 (cr-128), etc., constants folded into the accumulators */
+ * r = 4096 y + 2048 + 5743 (cr-128), etc., the constants folded into the accumulators
+ * (codec/jpeg.c:1981-1990 with every fixed-point constant divided by 256, see ycbcr_to_rgb) */
 struct Rgb12 {
 	int r, g, b;
 };
-__device__ __forceinline__ Rgb12 color_px(uint32_t pcr, uint32_t pcb)
+__device__ __forceinline__ Rgb12 color_px(const ColorK &K, uint32_t pcr, uint32_t pcb)
 {
 	Rgb12 c;
-	c.r = dot2(pcr, pk16(5743, 4096), 2048 - 128 * 5743);
-	c.b = dot2(pcb, pk16(7258, 4096), 2048 - 128 * 7258);
+	c.r = dot2(pcr, K.r, K.kr);
+	c.b = dot2(pcb, K.b, K.kb);
 	/* ((cb-128) * -1410) & ~255, plus 2048 + 128*2925 = 0x5BE80 split as 0x5BE00 (commutes with the mask) | 0x80 */
-	int t = dot2(pcb, pk16(-1410, 0), 128 * 1410 + 0x5BE00);
-	c.g = dot2(pcr, pk16(-2925, 4096), (t & ~255) | 0x80);
+	uint32_t t = (uint32_t)dot2(pcb, K.t, K.kt);
+	c.g = dot2(pcr, K.g, (int)and_or(t, K.mask, K.o80));
 	return c;
 }
 
-/* four pixels -> 12 (RGB) or 16 (RGBA) bytes, ">> 12 then clamp" done two samples per instruction */
+/* four pixels -> 12 (RGB) or 16 (RGBA) bytes: ">> 12 then clamp" for two samples per instruction */
 template <int NOUT>
 __device__ __forceinline__ void store_px4(uint8_t *__restrict__ dst, const Rgb12 &p0, const Rgb12 &p1, const Rgb12 &p2, const Rgb12 &p3)
 {
 	if (NOUT == 4) {
-		const int opaque_a = 0x7fffffff; /* saturates to 255 */
+		const int a = 0x7fffffff; /* saturates to 255 */
 		uint4 v;
-		v.x = join16(ashr_sat_pk2<12>(p0.r, p0.g), ashr_sat_pk2<12>(p0.b, opaque_a));
-		v.y = join16(ashr_sat_pk2<12>(p1.r, p1.g), ashr_sat_pk2<12>(p1.b, opaque_a));
-		v.z = join16(ashr_sat_pk2<12>(p2.r, p2.g), ashr_sat_pk2<12>(p2.b, opaque_a));
-		v.w = join16(ashr_sat_pk2<12>(p3.r, p3.g), ashr_sat_pk2<12>(p3.b, opaque_a));
+		v.x = sat4<12>(p0.r, p0.g, p0.b, a);
+		v.y = sat4<12>(p1.r, p1.g, p1.b, a);
+		v.z = sat4<12>(p2.r, p2.g, p2.b, a);
+		v.w = sat4<12>(p3.r, p3.g, p3.b, a);
 		*reinterpret_cast<uint4 *>(dst) = v;
 	} else {
 		uint32_t *q = reinterpret_cast<uint32_t *>(dst);
-		q[0] = join16(ashr_sat_pk2<12>(p0.r, p0.g), ashr_sat_pk2<12>(p0.b, p1.r));
-		q[1] = join16(ashr_sat_pk2<12>(p1.g, p1.b), ashr_sat_pk2<12>(p2.r, p2.g));
-		q[2] = join16(ashr_sat_pk2<12>(p2.b, p3.r), ashr_sat_pk2<12>(p3.g, p3.b));
+		const uint32_t q0 = sat4<12>(p0.r, p0.g, p0.b, p1.r);
+		const uint32_t q1 = sat4<12>(p1.g, p1.b, p2.r, p2.g);
+		const uint32_t q2 = sat4<12>(p2.b, p3.r, p3.g, p3.b);
+		q[0] = q0;
+		q[1] = q1;
+		q[2] = q2;
 	}
+}
+
+/* one output row of a 4-pixel strip: chroma operands V0..V2 (see ColorK), luma dword yv */
+template <int NOUT>
+__device__ __forceinline__ void strip_row(const ColorK &K, uint32_t wk, uint32_t wk1, uint32_t vb0, uint32_t vb1, uint32_t vb2, uint32_t vr0, uint32_t vr1,
+														uint32_t vr2, uint32_t yv, uint8_t *__restrict__ dst)
+{
+	/* weights x16 so that the filtered sample is byte 1 of the dot product:
+	 * (3*(3n+f) + (3n'+f') + 8) >> 4  ==  (16*(9n+3f+3n'+f') + 128) >> 8   (codec/jpeg.c:1826-1835)
+	 * pixel x0 uses chroma columns (i0, i0-1), x0+1: (i0, i0+1), x0+2: (i0+1, i0), x0+3: (i0+1, i0+2) */
+	const uint32_t cb0 = dot4(vb0, wk1, K.w128), cb1 = dot4(vb1, wk, K.w128), cb2 = dot4(vb1, wk1, K.w128), cb3 = dot4(vb2, wk, K.w128);
+	const uint32_t cr0 = dot4(vr0, wk1, K.w128), cr1 = dot4(vr1, wk, K.w128), cr2 = dot4(vr1, wk1, K.w128), cr3 = dot4(vr2, wk, K.w128);
+	const Rgb12 p0 = color_px(K, __builtin_amdgcn_perm(cr0, yv, K.p0), __builtin_amdgcn_perm(cb0, yv, K.p0));
+	const Rgb12 p1 = color_px(K, __builtin_amdgcn_perm(cr1, yv, K.p1), __builtin_amdgcn_perm(cb1, yv, K.p1));
+	const Rgb12 p2 = color_px(K, __builtin_amdgcn_perm(cr2, yv, K.p2), __builtin_amdgcn_perm(cb2, yv, K.p2));
+	const Rgb12 p3 = color_px(K, __builtin_amdgcn_perm(cr3, yv, K.p3), __builtin_amdgcn_perm(cb3, yv, K.p3));
+	store_px4<NOUT>(dst, p0, p1, p2, p3);
 }
 
 template <int NOUT, bool WIDE>
@@ -549,16 +671,22 @@ __global__ __launch_bounds__(256) void k_fused420(const DevImage *__restrict__ i
 	const uint8_t *const coefCb = coef + im.comp[1].coef_off;
 	const uint8_t *const coefCr = coef + im.comp[2].coef_off;
 	uint8_t *const out = outbase + im.out_off;
-	const size_t opitch = (size_t)W * NOUT;
+	const uint32_t opitch = (uint32_t)W * NOUT;
 
 	const int m0 = (int)wk.m0, m1 = (int)wk.m1;
 	const int row_lo = 16 * m0, row_hi = min(16 * m1, H); /* rows this band emits */
 	const int nYw = (4 * mcu_x + 63) >> 6, nCw = (mcu_x + 63) >> 6;
 	const int nstrip = (W + 3) >> 2;
-	const bool aligned = (NOUT == 4) || ((W & 3) == 0);
+	/* fast strips need dword-aligned rows (RGB: W % 4 == 0) and an output that fits 32-bit offsets */
+	const bool aligned = ((NOUT == 4) || ((W & 3) == 0)) && ((uint64_t)opitch * (uint32_t)H < 0xfffffff0ull);
 	int sv = 0; /* which save buffer holds the previous MCU row's last rows */
 
-	/* ---- chroma-only IDCT of block row mc, keeping sample row `keep` in dstCb/dstCr (halo rows) */
+	IdctK KI;
+	KI.init();
+	ColorK KC;
+	KC.init();
+
+	/* ---- chroma-only IDCT of block row mc, keeping sample row 7 (keep != 0) or 0 in dstCb/dstCr (halo rows) */
 	auto chroma_halo = [&](int mc, int keep, uint8_t *dstCb, uint8_t *dstCr) {
 		for (int ww = wave; ww < 2 * nCw; ww += 4) {
 			const int comp = ww < nCw ? 1 : 2;
@@ -567,7 +695,7 @@ __global__ __launch_bounds__(256) void k_fused420(const DevImage *__restrict__ i
 				uint4 c[8];
 				uint2 rows[8];
 				load_block(comp == 1 ? coefCb : coefCr, (uint32_t)(mc * bwC + bx), c);
-				idct_block<WIDE>(c, im.dq[comp], rows);
+				idct_block<WIDE>(KI, c, im.dq[comp], rows);
 				*reinterpret_cast<uint2 *>((comp == 1 ? dstCb : dstCr) + 8 * bx) = keep ? rows[7] : rows[0];
 			}
 		}
@@ -579,61 +707,40 @@ __global__ __launch_bounds__(256) void k_fused420(const DevImage *__restrict__ i
 		const bool doA = ra >= row_lo && ra < row_hi, doB = rb >= row_lo && rb < row_hi;
 		if (!doA && !doB)
 			return;
+		const uint32_t offA = (uint32_t)ra * opitch, offB = (uint32_t)rb * opitch;
 		for (int s = tid; s < nstrip; s += 256) {
 			const int x0 = 4 * s, i0 = 2 * s;
-			const bool interior = aligned && s >= 1 && (i0 + 2 <= wc - 1) && (x0 + 3 <= W - 1);
-			if (interior) {
-				/* bytes (c[i0-1], c[i0], c[i0+1], c[i0+2]) of each chroma row */
-				const int d0 = (i0 - 1) >> 2, sh = (i0 - 1) & 3;
-				const uint32_t *pbA = reinterpret_cast<const uint32_t *>(cbA), *pbB = reinterpret_cast<const uint32_t *>(cbB);
-				const uint32_t *prA = reinterpret_cast<const uint32_t *>(crA), *prB = reinterpret_cast<const uint32_t *>(crB);
-				uint32_t bA, bB, rA, rB;
-				if (sh == 3) {
-					bA = __builtin_amdgcn_alignbyte(pbA[d0 + 1], pbA[d0], 3);
-					bB = __builtin_amdgcn_alignbyte(pbB[d0 + 1], pbB[d0], 3);
-					rA = __builtin_amdgcn_alignbyte(prA[d0 + 1], prA[d0], 3);
-					rB = __builtin_amdgcn_alignbyte(prB[d0 + 1], prB[d0], 3);
-				} else {
-					bA = __builtin_amdgcn_alignbyte(pbA[d0 + 1], pbA[d0], 1);
-					bB = __builtin_amdgcn_alignbyte(pbB[d0 + 1], pbB[d0], 1);
-					rA = __builtin_amdgcn_alignbyte(prA[d0 + 1], prA[d0], 1);
-					rB = __builtin_amdgcn_alignbyte(prB[d0 + 1], prB[d0], 1);
+			if (aligned && x0 + 3 <= W - 1) {
+				/* bytes (c[i0-1], c[i0], c[i0+1], c[i0+2]) of each chroma row: two dwords + a byte funnel shift.
+				 * Strip 0 reads the dword in front of the row (inside LDS) and the edge fix below discards it. */
+				const int d0 = (i0 - 1) >> 2;
+				const uint32_t sh = (uint32_t)(i0 - 1) & 3u;
+				const uint32_t *pbA = reinterpret_cast<const uint32_t *>(cbA) + d0, *pbB = reinterpret_cast<const uint32_t *>(cbB) + d0;
+				const uint32_t *prA = reinterpret_cast<const uint32_t *>(crA) + d0, *prB = reinterpret_cast<const uint32_t *>(crB) + d0;
+				uint32_t bA = __builtin_amdgcn_alignbyte(pbA[1], pbA[0], sh);
+				uint32_t bB = __builtin_amdgcn_alignbyte(pbB[1], pbB[0], sh);
+				uint32_t rA = __builtin_amdgcn_alignbyte(prA[1], prA[0], sh);
+				uint32_t rB = __builtin_amdgcn_alignbyte(prB[1], prB[0], sh);
+				/* image edges: column -1 -> 0 and column wc -> wc-1 (the reference's (t+2)>>2 end cases are
+				 * the general form with the neighbour clamped, codec/jpeg.c:1820-1835) */
+				if (i0 == 0 || i0 + 2 > wc - 1) {
+					uint32_t sel = 0x03020100u;
+					if (i0 == 0)
+						sel = (sel & 0xffffff00u) | 0x01u;
+					if (i0 + 2 > wc - 1)
+						sel = (sel & 0x00ffffffu) | 0x02000000u;
+					bA = __builtin_amdgcn_perm(0, bA, sel);
+					bB = __builtin_amdgcn_perm(0, bB, sel);
+					rA = __builtin_amdgcn_perm(0, rA, sel);
+					rB = __builtin_amdgcn_perm(0, rB, sel);
 				}
-				/* V_k = (B[k], A[k], B[k+1], A[k+1]) for k = 0,1,2 (columns i0-1+k, i0+k) */
-				const uint32_t vb0 = __builtin_amdgcn_perm(bA, bB, 0x05010400), vb1 = __builtin_amdgcn_perm(bA, bB, 0x06020501),
-									vb2 = __builtin_amdgcn_perm(bA, bB, 0x07030602);
-				const uint32_t vr0 = __builtin_amdgcn_perm(rA, rB, 0x05010400), vr1 = __builtin_amdgcn_perm(rA, rB, 0x06020501),
-									vr2 = __builtin_amdgcn_perm(rA, rB, 0x07030602);
-				/* weights x16 so that the filtered sample is byte 1 of the dot product:
-				 * (3*(3n+f) + (3n'+f') + 8) >> 4  ==  (16*(9n+3f+3n'+f') + 128) >> 8 */
-				/* row 2C (near = B): pixel x0 uses columns (i0, i0-1), x0+1: (i0, i0+1), x0+2: (i0+1, i0), x0+3: (i0+1, i0+2) */
-				/* weight tables: byte order in V is (B_k, A_k, B_k+1, A_k+1) = (b0,b1,b2,b3) */
-				const uint32_t wBk = 0x10303090u;  /* near=B centre=k   : 9B_k +3A_k +3B_k1 + A_k1 -> b0=144,b1=48,b2=48,b3=16 */
-				const uint32_t wBk1 = 0x30901030u; /* near=B centre=k+1 : 3B_k + A_k +9B_k1 +3A_k1 -> b0=48,b1=16,b2=144,b3=48 */
-				const uint32_t wAk = 0x30109030u;  /* near=A centre=k   : 3B_k +9A_k + B_k1 +3A_k1 -> b0=48,b1=144,b2=16,b3=48 */
-				const uint32_t wAk1 = 0x90303010u; /* near=A centre=k+1 : B_k +3A_k +3B_k1 +9A_k1 -> b0=16,b1=48,b2=48,b3=144 */
-				uint8_t *dA = out + (size_t)ra * opitch + (size_t)x0 * NOUT;
-				uint8_t *dB = out + (size_t)rb * opitch + (size_t)x0 * NOUT;
-				if (doB) {
-					const uint32_t yv = *reinterpret_cast<const uint32_t *>(yB + x0);
-					const uint32_t cb0 = dot4(vb0, wBk1, 128), cb1 = dot4(vb1, wBk, 128), cb2 = dot4(vb1, wBk1, 128), cb3 = dot4(vb2, wBk, 128);
-					const uint32_t cr0 = dot4(vr0, wBk1, 128), cr1 = dot4(vr1, wBk, 128), cr2 = dot4(vr1, wBk1, 128), cr3 = dot4(vr2, wBk, 128);
-					const Rgb12 p0 = color_px(__builtin_amdgcn_perm(cr0, yv, 0x0c000c05), __builtin_amdgcn_perm(cb0, yv, 0x0c000c05));
-					const Rgb12 p1 = color_px(__builtin_amdgcn_perm(cr1, yv, 0x0c010c05), __builtin_amdgcn_perm(cb1, yv, 0x0c010c05));
-					const Rgb12 p2 = color_px(__builtin_amdgcn_perm(cr2, yv, 0x0c020c05), __builtin_amdgcn_perm(cb2, yv, 0x0c020c05));
-					const Rgb12 p3 = color_px(__builtin_amdgcn_perm(cr3, yv, 0x0c030c05), __builtin_amdgcn_perm(cb3, yv, 0x0c030c05));
-					store_px4<NOUT>(dB, p0, p1, p2, p3);
-				}
-				if (doA) {
-					const uint32_t yv = *reinterpret_cast<const uint32_t *>(yA + x0);
-					const uint32_t cb0 = dot4(vb0, wAk1, 128), cb1 = dot4(vb1, wAk, 128), cb2 = dot4(vb1, wAk1, 128), cb3 = dot4(vb2, wAk, 128);
-					const uint32_t cr0 = dot4(vr0, wAk1, 128), cr1 = dot4(vr1, wAk, 128), cr2 = dot4(vr1, wAk1, 128), cr3 = dot4(vr2, wAk, 128);
-					const Rgb12 p0 = color_px(__builtin_amdgcn_perm(cr0, yv, 0x0c000c05), __builtin_amdgcn_perm(cb0, yv, 0x0c000c05));
-					const Rgb12 p1 = color_px(__builtin_amdgcn_perm(cr1, yv, 0x0c010c05), __builtin_amdgcn_perm(cb1, yv, 0x0c010c05));
-					const Rgb12 p2 = color_px(__builtin_amdgcn_perm(cr2, yv, 0x0c020c05), __builtin_amdgcn_perm(cb2, yv, 0x0c020c05));
-					const Rgb12 p3 = color_px(__builtin_amdgcn_perm(cr3, yv, 0x0c030c05), __builtin_amdgcn_perm(cb3, yv, 0x0c030c05));
-					store_px4<NOUT>(dA, p0, p1, p2, p3);
-				}
+				const uint32_t vb0 = __builtin_amdgcn_perm(bA, bB, KC.v0), vb1 = __builtin_amdgcn_perm(bA, bB, KC.v1), vb2 = __builtin_amdgcn_perm(bA, bB, KC.v2);
+				const uint32_t vr0 = __builtin_amdgcn_perm(rA, rB, KC.v0), vr1 = __builtin_amdgcn_perm(rA, rB, KC.v1), vr2 = __builtin_amdgcn_perm(rA, rB, KC.v2);
+				const uint32_t xo = (uint32_t)x0 * NOUT;
+				if (doB)
+					strip_row<NOUT>(KC, KC.wBk, KC.wBk1, vb0, vb1, vb2, vr0, vr1, vr2, *reinterpret_cast<const uint32_t *>(yB + x0), out + (offB + xo));
+				if (doA)
+					strip_row<NOUT>(KC, KC.wAk, KC.wAk1, vb0, vb1, vb2, vr0, vr1, vr2, *reinterpret_cast<const uint32_t *>(yA + x0), out + (offA + xo));
 			} else {
 				const int xe = min(x0 + 4, W);
 				for (int x = x0; x < xe; ++x) {
@@ -648,7 +755,7 @@ __global__ __launch_bounds__(256) void k_fused420(const DevImage *__restrict__ i
 
 	/* ---- prologue: chroma row 8*m0-1 from the block row above the band */
 	if (m0 > 0) {
-		chroma_halo(m0 - 1, 7, saveCb + sv * CP, saveCr + sv * CP);
+		chroma_halo(m0 - 1, 1, saveCb + sv * CP, saveCr + sv * CP);
 	}
 
 	for (int m = m0; m < m1; ++m) {
@@ -661,7 +768,7 @@ __global__ __launch_bounds__(256) void k_fused420(const DevImage *__restrict__ i
 				const int i = ww * 64 + lane; /* block of the two luma block rows 2m, 2m+1 (contiguous in L) */
 				if (i < 2 * bwY) {
 					load_block(coefY, (uint32_t)(2 * m * bwY + i), c);
-					idct_block<WIDE>(c, im.dq[0], rows);
+					idct_block<WIDE>(KI, c, im.dq[0], rows);
 					const int by = i >= bwY ? 1 : 0, bx = i - by * bwY;
 					uint8_t *dst = sY + (8 * by) * YP + 8 * bx;
 #pragma unroll
@@ -673,7 +780,7 @@ __global__ __launch_bounds__(256) void k_fused420(const DevImage *__restrict__ i
 				const int bx = ((ww - nYw) - (comp == 2 ? nCw : 0)) * 64 + lane;
 				if (bx < bwC) {
 					load_block(comp == 1 ? coefCb : coefCr, (uint32_t)(m * bwC + bx), c);
-					idct_block<WIDE>(c, im.dq[comp], rows);
+					idct_block<WIDE>(KI, c, im.dq[comp], rows);
 					uint8_t *dst = (comp == 1 ? sCb : sCr) + 8 * bx;
 #pragma unroll
 					for (int r = 0; r < 8; ++r)

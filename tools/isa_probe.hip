@@ -22,6 +22,20 @@ __global__ void k_sem(const int *in, uint32_t *out)
 	uint32_t s = 0xdeadbeefu;
 	asm volatile("v_sat_pk_u8_i16 %0, %1" : "+v"(s) : "v"(in[4]));
 	out[3] = s;
+	// SDWA shift into the upper half, preserving the lower half
+	uint32_t p = 0xdeadbeefu;
+	asm volatile("v_ashrrev_i32 %0, 17, %1\n\tv_ashrrev_i32_sdwa %0, 17, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\ts_nop 0" : "+v"(p) : "v"(c), "v"(d));
+	out[4] = p; // expect 004dfffd  (c>>17 = -3 -> fffd, d>>17 = 77 -> 004d)
+	uint32_t q = 0xdeadbeefu;
+	asm volatile("v_sat_pk_u8_i16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\ts_nop 0" : "+v"(q) : "v"(in[4]));
+	out[5] = q; // expect 00ffbeef
+	uint32_t r3;
+	asm volatile("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r3) : "v"(in[4]), "v"(0x00020003), "v"(1000));
+	out[6] = r3; // (300*3 + (-5)*2) + 1000 = 1890
+	uint32_t al;
+	int sh = in[5];
+	asm volatile("v_alignbyte_b32 %0, %1, %2, %3" : "=v"(al) : "v"(0x44332211), "v"(0xddccbbaa), "v"(sh));
+	out[7] = al; // sh=3: bytes (dd,11,22,33) -> 0x332211dd
 }
 
 template <int OP>
@@ -45,6 +59,16 @@ __global__ __launch_bounds__(256) void k_rate(uint32_t *out, uint32_t seed, int 
 		if (OP == 11) { REP8(asm volatile("v_pk_mad_u16 %0, %0, %1, %0" : "+v"(x) : "v"(k));) }
 		if (OP == 12) { REP8(asm volatile("v_ashrrev_i32 %0, 3, %0" : "+v"(x));) }
 		if (OP == 13) { REP8(asm volatile("v_and_or_b32 %0, %0, %1, %0" : "+v"(x) : "v"(k));) }
+		if (OP == 14) { REP8(asm volatile("v_dot2_i32_i16 %0, %0, %1, %0" : "+v"(x) : "v"(k));) }
+		if (OP == 15) { REP8(asm volatile("v_ashrrev_i32_sdwa %0, 3, %0 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(x));) }
+		if (OP == 16) { REP8(asm volatile("v_sat_pk_u8_i16 %0, %0" : "+v"(x));) }
+		if (OP == 17) { REP8(asm volatile("v_mov_b32 %0, %1" : "+v"(x) : "v"(k));) }
+		if (OP == 18) { REP8(asm volatile("v_pk_add_i16 %0, %0, %1" : "+v"(x) : "v"(k));) }
+		if (OP == 19) { REP8(asm volatile("v_and_b32 %0, %0, %1" : "+v"(x) : "v"(k));) }
+		if (OP == 20) { REP8(asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(x) : "v"(k));) }
+		if (OP == 21) { REP8(asm volatile("v_sub_u32 %0, %0, %1" : "+v"(x) : "v"(k));) }
+		if (OP == 22) { REP8(asm volatile("v_pk_ashrrev_i16 %0, 3, %0" : "+v"(x));) }
+		if (OP == 23) { REP8(asm volatile("v_add3_u32 %0, %0, %1, %0" : "+v"(x) : "v"(k));) }
 	}
 	out[blockIdx.x * 256 + threadIdx.x] = x0 ^ x1 ^ x2 ^ x3 ^ x4 ^ x5 ^ x6 ^ x7;
 }
@@ -76,15 +100,19 @@ int main()
 	CK(hipMalloc(&d_in, 64));
 	CK(hipMalloc(&d_out, 256 * 8 * 256 * 4));
 	// a>>17 = 5, b>>17 = 300 (sat 255), c>>17 = -3 (sat 0), d>>17 = 77
-	int h_in[5] = {5 << 17, 300 << 17, -(3 << 17), 77 << 17, (int)(((uint32_t)(uint16_t)-5 << 16) | 300u)};
+	int h_in[6] = {5 << 17, 300 << 17, -(3 << 17), 77 << 17, (int)(((uint32_t)(uint16_t)-5 << 16) | 300u), 3};
 	CK(hipMemcpy(d_in, h_in, sizeof(h_in), hipMemcpyHostToDevice));
 	hipLaunchKernelGGL(k_sem, dim3(1), dim3(1), 0, 0, d_in, d_out);
-	uint32_t h_out[4];
+	uint32_t h_out[8];
 	CK(hipMemcpy(h_out, d_out, sizeof(h_out), hipMemcpyDeviceToHost));
 	printf("ashr_pk_u8_i32 lo  (dst preset deadbeef): %08x  (expect ....ff05)\n", h_out[0]);
 	printf("ashr_pk_u8_i32 hi  (dst preset deadbeef): %08x  (expect 4d00....)\n", h_out[1]);
 	printf("ashr_pk_u8_i32 lo then hi               : %08x  (expect 4d00ff05)\n", h_out[2]);
 	printf("sat_pk_u8_i16 of (300, -5)              : %08x  (expect ....00ff)\n", h_out[3]);
+	printf("ashrrev + ashrrev_sdwa WORD_1 preserve  : %08x  (expect 004dfffd)\n", h_out[4]);
+	printf("sat_pk_u8_i16_sdwa WORD_1 preserve      : %08x  (expect 00ffbeef)\n", h_out[5]);
+	printf("v_dot2_i32_i16 VOP3P vgpr operands      : %u  (expect 1890)\n", h_out[6]);
+	printf("v_alignbyte_b32 with VGPR shift 3       : %08x  (expect 332211dd)\n", h_out[7]);
 	rate<7>("v_add_u32", d_out);
 	rate<0>("v_dot2c_i32_i16", d_out);
 	rate<1>("v_dot4_u32_u8", d_out);
@@ -99,5 +127,15 @@ int main()
 	rate<11>("v_pk_mad_u16", d_out);
 	rate<12>("v_ashrrev_i32", d_out);
 	rate<13>("v_and_or_b32", d_out);
+	rate<14>("v_dot2_i32_i16 (VOP3P)", d_out);
+	rate<15>("v_ashrrev_i32_sdwa", d_out);
+	rate<16>("v_sat_pk_u8_i16", d_out);
+	rate<17>("v_mov_b32", d_out);
+	rate<18>("v_pk_add_i16", d_out);
+	rate<19>("v_and_b32", d_out);
+	rate<20>("v_lshl_add_u32", d_out);
+	rate<21>("v_sub_u32", d_out);
+	rate<22>("v_pk_ashrrev_i16", d_out);
+	rate<23>("v_add3_u32", d_out);
 	return 0;
 }
