@@ -115,28 +115,30 @@ __device__ __forceinline__ int clamp255(int x) { return x < 0 ? 0 : (x > 255 ? 2
  * samples in a dword: the reference's ">> 17, stbi__clamp" (codec/jpeg.c:670-677) and
  * ">> 20, clamp" (:1988-2011).
  */
+/* No trailing wait state: every consumer of a sat4 result in this file is a memory instruction
+ * (ds_write / global_store); the gfx940-family dst_sel forwarding hazard only concerns a VALU that
+ * reads the half-written register in the very next issue slot. */
 template <int S>
 __device__ __forceinline__ uint32_t sat4(int a, int b, int c, int d)
 {
 	uint32_t r;
 	asm("v_ashr_pk_u8_i32 %0, %1, %2, %5\n\t"
-		 "v_ashr_pk_u8_i32 %0, %3, %4, %5 op_sel:[0,0,0,1]\n\t"
-		 "s_nop 0"
+		 "v_ashr_pk_u8_i32 %0, %3, %4, %5 op_sel:[0,0,0,1]"
 		 : "=&v"(r)
 		 : "v"(a), "v"(b), "v"(c), "v"(d), "n"(S));
 	return r;
 }
-/* (lo >> S) | (hi >> S) << 16 as int16 pairs: shift, then an SDWA shift into the upper half */
+/* eight int16 pairs ((lo[i] >> S) | (hi[i] >> S) << 16): a plain shift, then an SDWA shift into the
+ * upper half.  The results feed v_dot2 (VALU), so one wait state closes the block (dst_sel hazard). */
 template <int S>
-__device__ __forceinline__ uint32_t shr_pack_i16(int lo, int hi)
+__device__ __forceinline__ void shr_pack8_i16(const int (&lo)[8], const int (&hi)[8], uint32_t (&o)[8])
 {
-	uint32_t r;
-	asm("v_ashrrev_i32 %0, %3, %1\n\t"
-		 "v_ashrrev_i32_sdwa %0, %3, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
-		 "s_nop 0"
-		 : "=&v"(r)
-		 : "v"(lo), "v"(hi), "n"(S));
-	return r;
+#define MIJ_SP(i, l, h) "v_ashrrev_i32 %" #i ", %24, %" #l "\n\tv_ashrrev_i32_sdwa %" #i ", %24, %" #h " dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+	asm(MIJ_SP(0, 8, 16) MIJ_SP(1, 9, 17) MIJ_SP(2, 10, 18) MIJ_SP(3, 11, 19) MIJ_SP(4, 12, 20) MIJ_SP(5, 13, 21) MIJ_SP(6, 14, 22) MIJ_SP(7, 15, 23) "s_nop 0"
+		 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+		 : "v"(lo[0]), "v"(lo[1]), "v"(lo[2]), "v"(lo[3]), "v"(lo[4]), "v"(lo[5]), "v"(lo[6]), "v"(lo[7]), "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]),
+			"v"(hi[4]), "v"(hi[5]), "v"(hi[6]), "v"(hi[7]), "n"(S));
+#undef MIJ_SP
 }
 /* keeps the compiler from fusing a preceding shift with a following clamp into the v_ashr_pk pattern */
 __device__ __forceinline__ int opaque(int x)
@@ -265,9 +267,11 @@ __device__ __forceinline__ void idct_block(const IdctK &K, const uint4 (&c)[8], 
 											  pkmul(c[a].w, dq[4 * a + 3]));
 			Idct1D vb = idct1d_packed(K, K.bias1, pkmul(c[b].x, dq[4 * b + 0]), pkmul(c[b].y, dq[4 * b + 1]), pkmul(c[b].z, dq[4 * b + 2]),
 											  pkmul(c[b].w, dq[4 * b + 3]));
+			uint32_t pg[8];
+			shr_pack8_i16<10>(va.o, vb.o, pg);
 #pragma unroll
 			for (int i = 0; i < 8; ++i)
-				pk[i][g] = shr_pack_i16<10>(va.o[i], vb.o[i]);
+				pk[i][g] = pg[i];
 		}
 #pragma unroll
 		for (int i = 0; i < 8; ++i) {
