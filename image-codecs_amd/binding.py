@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libimagecodecs_mi355x.so")
+LIB_PATH = os.environ.get("MIJ_LIB") or os.path.join(_HERE, "lib", "libimagecodecs_mi355x.so")  # MIJ_LIB: A/B builds
 
 MIJ_FLAG_WIDE_IDCT = 1
 COLOR_NAMES = {0: "grey", 1: "ycbcr", 2: "rgb", 3: "cmyk", 4: "ycck", 5: "ycbcra"}

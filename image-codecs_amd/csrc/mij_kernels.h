@@ -28,6 +28,10 @@
 
 #include "mij.h"
 
+#ifndef MIJ_VARIANT
+#define MIJ_VARIANT 0
+#endif
+
 namespace mij {
 
 /* ------------------------------------------------------------------ device-side descriptors */
@@ -712,47 +716,74 @@ __global__ __launch_bounds__(256) void k_fused420(const DevImage *__restrict__ i
 		if (!doA && !doB)
 			return;
 		const uint32_t offA = (uint32_t)ra * opitch, offB = (uint32_t)rb * opitch;
-		for (int s = tid; s < nstrip; s += 256) {
+		/* fast strips: 4 whole pixels, dword-aligned rows.  Two strips per thread and iteration, all LDS
+		 * reads of both issued before either is processed (hides LDS latency, halves the loop overhead) */
+		const int nfast = aligned ? (W >> 2) : 0;
+		struct StripIn {
+			uint32_t bA0, bA1, bB0, bB1, rA0, rA1, rB0, rB1, yA, yB;
+		};
+		auto load_strip = [&](int s, StripIn &in) {
+			const int d0 = (2 * s - 1) >> 2; /* strip 0 reads the dword in front of the row (inside LDS); the edge fix discards it */
+			const uint32_t *pbA = reinterpret_cast<const uint32_t *>(cbA) + d0, *pbB = reinterpret_cast<const uint32_t *>(cbB) + d0;
+			const uint32_t *prA = reinterpret_cast<const uint32_t *>(crA) + d0, *prB = reinterpret_cast<const uint32_t *>(crB) + d0;
+			in.bA0 = pbA[0];
+			in.bA1 = pbA[1];
+			in.bB0 = pbB[0];
+			in.bB1 = pbB[1];
+			in.rA0 = prA[0];
+			in.rA1 = prA[1];
+			in.rB0 = prB[0];
+			in.rB1 = prB[1];
+			in.yA = *reinterpret_cast<const uint32_t *>(yA + 4 * s);
+			in.yB = *reinterpret_cast<const uint32_t *>(yB + 4 * s);
+		};
+		auto do_strip = [&](int s, const StripIn &in) {
 			const int x0 = 4 * s, i0 = 2 * s;
-			if (aligned && x0 + 3 <= W - 1) {
-				/* bytes (c[i0-1], c[i0], c[i0+1], c[i0+2]) of each chroma row: two dwords + a byte funnel shift.
-				 * Strip 0 reads the dword in front of the row (inside LDS) and the edge fix below discards it. */
-				const int d0 = (i0 - 1) >> 2;
-				const uint32_t sh = (uint32_t)(i0 - 1) & 3u;
-				const uint32_t *pbA = reinterpret_cast<const uint32_t *>(cbA) + d0, *pbB = reinterpret_cast<const uint32_t *>(cbB) + d0;
-				const uint32_t *prA = reinterpret_cast<const uint32_t *>(crA) + d0, *prB = reinterpret_cast<const uint32_t *>(crB) + d0;
-				uint32_t bA = __builtin_amdgcn_alignbyte(pbA[1], pbA[0], sh);
-				uint32_t bB = __builtin_amdgcn_alignbyte(pbB[1], pbB[0], sh);
-				uint32_t rA = __builtin_amdgcn_alignbyte(prA[1], prA[0], sh);
-				uint32_t rB = __builtin_amdgcn_alignbyte(prB[1], prB[0], sh);
-				/* image edges: column -1 -> 0 and column wc -> wc-1 (the reference's (t+2)>>2 end cases are
-				 * the general form with the neighbour clamped, codec/jpeg.c:1820-1835) */
-				if (i0 == 0 || i0 + 2 > wc - 1) {
-					uint32_t sel = 0x03020100u;
-					if (i0 == 0)
-						sel = (sel & 0xffffff00u) | 0x01u;
-					if (i0 + 2 > wc - 1)
-						sel = (sel & 0x00ffffffu) | 0x02000000u;
-					bA = __builtin_amdgcn_perm(0, bA, sel);
-					bB = __builtin_amdgcn_perm(0, bB, sel);
-					rA = __builtin_amdgcn_perm(0, rA, sel);
-					rB = __builtin_amdgcn_perm(0, rB, sel);
-				}
-				const uint32_t vb0 = __builtin_amdgcn_perm(bA, bB, KC.v0), vb1 = __builtin_amdgcn_perm(bA, bB, KC.v1), vb2 = __builtin_amdgcn_perm(bA, bB, KC.v2);
-				const uint32_t vr0 = __builtin_amdgcn_perm(rA, rB, KC.v0), vr1 = __builtin_amdgcn_perm(rA, rB, KC.v1), vr2 = __builtin_amdgcn_perm(rA, rB, KC.v2);
-				const uint32_t xo = (uint32_t)x0 * NOUT;
-				if (doB)
-					strip_row<NOUT>(KC, KC.wBk, KC.wBk1, vb0, vb1, vb2, vr0, vr1, vr2, *reinterpret_cast<const uint32_t *>(yB + x0), out + (offB + xo));
+			/* bytes (c[i0-1], c[i0], c[i0+1], c[i0+2]) of each chroma row: two dwords + a byte funnel shift */
+			const uint32_t sh = (uint32_t)(i0 - 1) & 3u;
+			uint32_t bA = __builtin_amdgcn_alignbyte(in.bA1, in.bA0, sh);
+			uint32_t bB = __builtin_amdgcn_alignbyte(in.bB1, in.bB0, sh);
+			uint32_t rA = __builtin_amdgcn_alignbyte(in.rA1, in.rA0, sh);
+			uint32_t rB = __builtin_amdgcn_alignbyte(in.rB1, in.rB0, sh);
+			/* image edges: column -1 -> 0 and column wc -> wc-1 (the reference's (t+2)>>2 end cases are
+			 * the general form with the neighbour clamped, codec/jpeg.c:1820-1835) */
+			if (i0 == 0 || i0 + 2 > wc - 1) {
+				uint32_t sel = 0x03020100u;
+				if (i0 == 0)
+					sel = (sel & 0xffffff00u) | 0x01u;
+				if (i0 + 2 > wc - 1)
+					sel = (sel & 0x00ffffffu) | 0x02000000u;
+				bA = __builtin_amdgcn_perm(0, bA, sel);
+				bB = __builtin_amdgcn_perm(0, bB, sel);
+				rA = __builtin_amdgcn_perm(0, rA, sel);
+				rB = __builtin_amdgcn_perm(0, rB, sel);
+			}
+			const uint32_t vb0 = __builtin_amdgcn_perm(bA, bB, KC.v0), vb1 = __builtin_amdgcn_perm(bA, bB, KC.v1), vb2 = __builtin_amdgcn_perm(bA, bB, KC.v2);
+			const uint32_t vr0 = __builtin_amdgcn_perm(rA, rB, KC.v0), vr1 = __builtin_amdgcn_perm(rA, rB, KC.v1), vr2 = __builtin_amdgcn_perm(rA, rB, KC.v2);
+			const uint32_t xo = (uint32_t)x0 * NOUT;
+			if (doB)
+				strip_row<NOUT>(KC, KC.wBk, KC.wBk1, vb0, vb1, vb2, vr0, vr1, vr2, in.yB, out + (offB + xo));
+			if (doA)
+				strip_row<NOUT>(KC, KC.wAk, KC.wAk1, vb0, vb1, vb2, vr0, vr1, vr2, in.yA, out + (offA + xo));
+		};
+		for (int base = 0; base < nfast; base += 512) {
+			const int sa = base + tid, sb = sa + 256;
+			StripIn ia, ib;
+			load_strip(min(sa, nfast - 1), ia);
+			load_strip(min(sb, nfast - 1), ib);
+			if (sa < nfast)
+				do_strip(sa, ia);
+			if (sb < nfast)
+				do_strip(sb, ib);
+		}
+		/* the rest (partial last strip, unaligned widths): careful per-pixel path */
+		for (int s = nfast + tid; s < nstrip; s += 256) {
+			const int x0 = 4 * s, xe = min(x0 + 4, W);
+			for (int x = x0; x < xe; ++x) {
 				if (doA)
-					strip_row<NOUT>(KC, KC.wAk, KC.wAk1, vb0, vb1, vb2, vr0, vr1, vr2, *reinterpret_cast<const uint32_t *>(yA + x0), out + (offA + xo));
-			} else {
-				const int xe = min(x0 + 4, W);
-				for (int x = x0; x < xe; ++x) {
-					if (doA)
-						fused420_pixel<NOUT>(yA, cbA, cbB, crA, crB, 0, wc, x, out + (size_t)ra * opitch);
-					if (doB)
-						fused420_pixel<NOUT>(yB, cbA, cbB, crA, crB, 1, wc, x, out + (size_t)rb * opitch);
-				}
+					fused420_pixel<NOUT>(yA, cbA, cbB, crA, crB, 0, wc, x, out + (size_t)ra * opitch);
+				if (doB)
+					fused420_pixel<NOUT>(yB, cbA, cbB, crA, crB, 1, wc, x, out + (size_t)rb * opitch);
 			}
 		}
 	};

@@ -69,6 +69,13 @@ __global__ __launch_bounds__(256) void k_rate(uint32_t *out, uint32_t seed, int 
 		if (OP == 21) { REP8(asm volatile("v_sub_u32 %0, %0, %1" : "+v"(x) : "v"(k));) }
 		if (OP == 22) { REP8(asm volatile("v_pk_ashrrev_i16 %0, 3, %0" : "+v"(x));) }
 		if (OP == 23) { REP8(asm volatile("v_add3_u32 %0, %0, %1, %0" : "+v"(x) : "v"(k));) }
+		if (OP == 24) { REP8(asm volatile("v_dot2_i32_i16 %0, %0, %1, %0" : "+v"(x) : "s"(k));) }
+		if (OP == 25) { REP8(asm volatile("v_dot2_i32_i16 %0, %0, %1, 0" : "+v"(x) : "s"(k));) }
+		if (OP == 26) { REP8(asm volatile("v_perm_b32 %0, %0, %0, %1" : "+v"(x) : "s"(k));) }
+		if (OP == 27) { REP8(asm volatile("v_dot4_u32_u8 %0, %0, %1, 0" : "+v"(x) : "s"(k));) }
+		if (OP == 28) { REP8(asm volatile("v_dot2_i32_i16 %0, %0, %1, 0" : "+v"(x) : "v"(k));) }
+		if (OP == 29) { REP8(asm volatile("v_add_u32 %0, %1, %0" : "+v"(x) : "s"(k));) }
+		if (OP == 30) { REP8(asm volatile("v_pk_mul_lo_u16 %0, %0, %1" : "+v"(x) : "s"(k));) }
 	}
 	out[blockIdx.x * 256 + threadIdx.x] = x0 ^ x1 ^ x2 ^ x3 ^ x4 ^ x5 ^ x6 ^ x7;
 }
@@ -137,5 +144,12 @@ int main()
 	rate<21>("v_sub_u32", d_out);
 	rate<22>("v_pk_ashrrev_i16", d_out);
 	rate<23>("v_add3_u32", d_out);
+	rate<24>("v_dot2 v,v,S,v", d_out);
+	rate<25>("v_dot2 v,v,S,0", d_out);
+	rate<26>("v_perm v,v,v,S", d_out);
+	rate<27>("v_dot4 v,v,S,0", d_out);
+	rate<28>("v_dot2 v,v,v,0", d_out);
+	rate<29>("v_add_u32 v,S,v", d_out);
+	rate<30>("v_pk_mul_lo_u16 v,v,S", d_out);
 	return 0;
 }
