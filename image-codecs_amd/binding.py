@@ -103,6 +103,8 @@ def lib():
     L.mjh_probe_memory.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(ImageDesc), C.POINTER(C.c_char_p)]
     L.mjh_decode_memory.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(ImageDesc), C.c_void_p, C.c_size_t,
                                     C.POINTER(C.c_char_p)]
+    L.mjh_decode_batch.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int,
+                                   C.POINTER(C.c_int), C.POINTER(C.c_char_p)]
     _lib = L
     return L
 
@@ -316,6 +318,26 @@ class Batch:
         if d2.flags:
             _check(lib().mij_batch_set_flags(self._h, slot, d2.flags), "mij_batch_set_flags")
         return slot
+
+    def decode_jpegs(self, datas, req_comp=0, threads=1):
+        """mjh_decode_batch: host stage of many JPEGs on a thread pool into this batch's staging.
+        -> (n_ok, slots, reasons); slots[i] < 0 marks a rejected image (reasons[i] says why)."""
+        n = len(datas)
+        bufs = (C.c_char_p * n)(*[bytes(d) for d in datas])
+        lens = (C.c_int * n)(*[len(d) for d in datas])
+        slots = (C.c_int * n)()
+        reasons = (C.c_char_p * n)()
+        first = len(self.descs)
+        rc = lib().mjh_decode_batch(self._h, bufs, lens, n, int(req_comp), int(threads), slots, reasons)
+        if rc < 0:
+            raise MijError("mjh_decode_batch: %s" % lib().mij_last_error().decode())
+        out_slots = list(slots)
+        # mirror the descriptors of the slots the C side added (header probe is cheap)
+        for i, sl in enumerate(out_slots):
+            real = sl if sl >= 0 else (-1 - sl if sl < -1 else None)
+            if real is not None and real >= first:
+                self.descs.append(HostDecoder.probe(datas[i], req_comp))
+        return rc, out_slots, [r.decode() if r else None for r in reasons]
 
     def set_flags(self, slot, flags):
         _check(lib().mij_batch_set_flags(self._h, int(slot), int(flags)), "mij_batch_set_flags")

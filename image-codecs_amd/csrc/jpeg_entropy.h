@@ -17,6 +17,7 @@
 #include <stdint.h>
 #include "image_api.h"
 #include "mij.h"
+#include "mij_host.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -107,18 +108,7 @@ int mjh_decode_scans(mjh_decoder *d);
 /* Non-zero if the finished image needs MIJ_FLAG_WIDE_IDCT. */
 int mjh_needs_wide_idct(const mjh_decoder *d);
 
-/*
- * One-call forms of the host stage for memory inputs (used by the batch decoder, tests, bench):
- *   mjh_probe_memory   type test + header + describe (stbi__jpeg_test, then codec/jpeg.c:1670-1699,
- *                      :2241-2249); fills *desc so the caller can size the coefficient planes.
- *   mjh_decode_memory  the same plus the scans (codec/jpeg.c:1713-1755) into `arena`: the component
- *                      planes in tile layout, back to back in component order, exactly the layout of
- *                      the staging a mij batch hands out.  The callee zero-fills what it uses.
- *                      desc->flags gets MIJ_FLAG_WIDE_IDCT when needed.
- * Both return 1 on success, 0 on failure with *reason = the reference's short reason.
- */
-int mjh_probe_memory(const uint8_t *buf, int len, int req_comp, mij_image_desc *desc, const char **reason);
-int mjh_decode_memory(const uint8_t *buf, int len, int req_comp, mij_image_desc *desc, int16_t *arena, size_t arena_elems, const char **reason);
+/* the one-call memory forms and the batch front end are declared in include/mij_host.h */
 
 #ifdef __cplusplus
 }

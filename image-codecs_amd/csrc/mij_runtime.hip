@@ -451,7 +451,7 @@ extern "C" int mij_batch_force_generic(mij_batch *b, int on)
 /* can the fused h2v2 kernel take this image? */
 static bool fused420_ok(const mij_batch *b, const mij_image_desc &d)
 {
-	if (b->force_generic)
+	if (b->force_generic || (d.flags & MIJ_FLAG_SKIP))
 		return false;
 	if (d.ncomp != 3 || d.color != MIJ_COLOR_YCBCR || (d.n_out != 3 && d.n_out != 4))
 		return false;
@@ -536,6 +536,10 @@ extern "C" int mij_batch_upload(mij_batch *b)
 		Slot &s = b->slots[i];
 		const mij_image_desc &d = s.desc;
 		const int wide = (d.flags & MIJ_FLAG_WIDE_IDCT) ? 1 : 0;
+		if (d.flags & MIJ_FLAG_SKIP) { /* rejected by the host stage after it got a slot */
+			s.path = 0;
+			continue;
+		}
 		if (fused420_ok(b, d)) {
 			s.path = 1;
 			const int g = (d.n_out == 4 ? 2 : 0) + wide;
@@ -740,6 +744,8 @@ extern "C" int mij_batch_fetch(mij_batch *b, int slot, uint8_t *dst, size_t dst_
 	if (!b->launched)
 		return set_err(MIJ_E_STATE, "mij_batch_fetch before launch");
 	const Slot &s = b->slots[(size_t)slot];
+	if (s.desc.flags & MIJ_FLAG_SKIP)
+		return set_err(MIJ_E_STATE, "slot %d was rejected by the host stage", slot);
 	const size_t bytes = (size_t)s.desc.n_out * s.desc.width * s.desc.height;
 	if (dst_bytes < bytes)
 		return set_err(MIJ_E_ARG, "destination too small (%zu < %zu)", dst_bytes, bytes);

@@ -53,7 +53,9 @@ enum {
 
 /* descriptor flags */
 #define MIJ_FLAG_WIDE_IDCT 1u /* host could not prove that every first-pass IDCT output fits int16:
-                                 run the exact 32-bit second pass (see mij_block_l1_limit) */
+                                 run the exact 32-bit second pass (see MIJ_BLOCK_L1_LIMIT) */
+#define MIJ_FLAG_SKIP 2u      /* the host stage rejected this image after its slot was taken: upload and
+                                 launch ignore the slot (its output is undefined) */
 
 /* per component geometry, exactly the reference's img_comp[] fields (codec/jpeg.c:48-62, :1624-1655) */
 typedef struct {

@@ -214,6 +214,29 @@ def test_progressive_large(ica, oracle, gpu_ctx, golden):
     assert np.array_equal(ica.stbi_load_from_memory(data, 3)[0], golden.expect("prog_444_64x64", 3)[1])
 
 
+def test_batch_front_end_thread_pool(golden, ica, oracle, gpu_ctx):
+    """mjh_decode_batch: host stage on a thread pool; a rejected header costs no slot, a rejected
+    entropy segment keeps its slot but is skipped by the launch; everything else equals the oracle."""
+    datas = [ica.synth_jpeg(96 + 16 * i, 64 + 8 * i, i) for i in range(10)]
+    datas.insert(3, golden.jpg("garbage"))          # not a JPEG: rejected at the header
+    datas.insert(7, golden.jpg("trunc_noeoi"))      # header fine, stream rejected ("expected marker")
+    datas.append(golden.jpg("prog_420_64x64"))
+    datas.append(golden.jpg("grey_33x20"))
+    b = ica.Batch(gpu_ctx, len(datas), 64 << 20, 64 << 20, 64 << 20)
+    ok, slots, reasons = b.decode_jpegs(datas, 3, threads=4)
+    assert ok == len(datas) - 2
+    assert slots[3] == -1 and reasons[3] == "unknown image type"
+    assert slots[7] < -1 and reasons[7] == "expected marker"
+    b.submit()
+    b.wait()
+    for i, d in enumerate(datas):
+        if slots[i] >= 0:
+            assert np.array_equal(b.fetch(slots[i]), oracle.load(d, 3)[1]), i
+    with pytest.raises(ica.MijError):
+        b.fetch(-1 - slots[7])
+    b.close()
+
+
 def test_batch_api_errors(ica, gpu_ctx):
     d = ica.HostDecoder.probe(ica.synth_jpeg(32, 32, 0), 3)
     b = ica.Batch(gpu_ctx, 1, 1 << 20, 1 << 20, 1 << 20)

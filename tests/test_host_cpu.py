@@ -16,7 +16,7 @@ def _declared_functions(header):
     src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     names = set()
-    for m in re.finditer(r"^[A-Za-z_][\w\s\*]*?\b(stbi_\w+|mij_\w+)\s*\(", src, flags=re.M):
+    for m in re.finditer(r"^[A-Za-z_][\w\s\*]*?\b(stbi_\w+|mij_\w+|mjh_\w+)\s*\(", src, flags=re.M):
         names.add(m.group(1))
     # static inline helpers are not exported
     for m in re.finditer(r"static\s+inline\s+[\w\s\*]*?\b(\w+)\s*\(", src):
@@ -28,8 +28,9 @@ def _declared_functions(header):
 
 def test_library_exports_every_declared_symbol(ica):
     L = ica.lib()
-    declared = _declared_functions("image_api.h") + _declared_functions("mij.h")
-    assert len(declared) >= 45
+    declared = _declared_functions("image_api.h") + _declared_functions("mij.h") + _declared_functions("mij_host.h")
+    assert len(declared) >= 48
+    assert "mjh_decode_batch" in declared
     missing = [n for n in declared if not hasattr(L, n)]
     assert not missing, missing
     assert L.mij_abi_version() == 1
