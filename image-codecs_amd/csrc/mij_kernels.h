@@ -879,6 +879,82 @@ __global__ __launch_bounds__(256) void k_fused420(const DevImage *__restrict__ i
 	}
 }
 
+/* ------------------------------------------------------------------ fused 1x1 (4:4:4) YCbCr kernel
+ *
+ * No sub-sampling means no neighbourhood: one lane owns one 8x8 MCU -- three blocks, one per
+ * component, same block index L in each plane -- transforms them back to back and colour-converts
+ * its 64 pixels entirely in registers.  No LDS, no barriers, no halo.  Reads are the coalesced
+ * tile-layout chunks (3 x 128 B per lane); each output row of the MCU is 8 pixels = 24 (RGB) or 32
+ * (RGBA) contiguous bytes per lane.  Algorithmic bytes: 384 B read + 64*NOUT written per MCU
+ * (9 B/px for RGB: BASELINE config 4's shape).
+ */
+template <int NOUT, bool WIDE>
+__global__ __launch_bounds__(256) void k_fused444(const DevImage *__restrict__ imgs, const WorkIdct *__restrict__ work, const uint8_t *__restrict__ coef,
+																  uint8_t *__restrict__ outbase)
+{
+	const WorkIdct wk = work[blockIdx.x];
+	const DevImage &im = imgs[wk.img];
+	const int bw = im.comp[0].bw;
+	const uint32_t nblk = (uint32_t)(bw * im.comp[0].bh);
+	const uint32_t L = wk.first + threadIdx.x;
+	if (L >= nblk)
+		return;
+	const int W = im.width, H = im.height;
+	IdctK KI;
+	KI.init();
+	uint2 ry[8], rb[8], rr[8];
+	{
+		uint4 c[8];
+		load_block(coef + im.comp[0].coef_off, L, c);
+		idct_block<WIDE>(KI, c, im.dq[0], ry);
+	}
+	{
+		uint4 c[8];
+		load_block(coef + im.comp[1].coef_off, L, c);
+		idct_block<WIDE>(KI, c, im.dq[1], rb);
+	}
+	{
+		uint4 c[8];
+		load_block(coef + im.comp[2].coef_off, L, c);
+		idct_block<WIDE>(KI, c, im.dq[2], rr);
+	}
+	const uint32_t by = L / (uint32_t)bw, bx = L - by * (uint32_t)bw;
+	const int x0 = (int)bx * 8, y0 = (int)by * 8;
+	uint8_t *const out = outbase + im.out_off;
+	const size_t opitch = (size_t)W * NOUT;
+	ColorK KC;
+	KC.init();
+	/* (chroma byte j | luma byte j << 16) */
+	const uint32_t s0 = vreg(0x0c000c04u), s1 = vreg(0x0c010c05u), s2 = vreg(0x0c020c06u), s3 = vreg(0x0c030c07u);
+	const bool whole = (x0 + 8 <= W) && ((NOUT == 4) || ((W & 3) == 0));
+#pragma unroll
+	for (int r = 0; r < 8; ++r) {
+		if (y0 + r >= H)
+			break;
+		uint8_t *dst = out + (size_t)(y0 + r) * opitch + (size_t)x0 * NOUT;
+		const uint32_t ylo = ry[r].x, yhi = ry[r].y, blo = rb[r].x, bhi = rb[r].y, rlo = rr[r].x, rhi = rr[r].y;
+		const Rgb12 p0 = color_px(KC, __builtin_amdgcn_perm(rlo, ylo, s0), __builtin_amdgcn_perm(blo, ylo, s0));
+		const Rgb12 p1 = color_px(KC, __builtin_amdgcn_perm(rlo, ylo, s1), __builtin_amdgcn_perm(blo, ylo, s1));
+		const Rgb12 p2 = color_px(KC, __builtin_amdgcn_perm(rlo, ylo, s2), __builtin_amdgcn_perm(blo, ylo, s2));
+		const Rgb12 p3 = color_px(KC, __builtin_amdgcn_perm(rlo, ylo, s3), __builtin_amdgcn_perm(blo, ylo, s3));
+		const Rgb12 p4 = color_px(KC, __builtin_amdgcn_perm(rhi, yhi, s0), __builtin_amdgcn_perm(bhi, yhi, s0));
+		const Rgb12 p5 = color_px(KC, __builtin_amdgcn_perm(rhi, yhi, s1), __builtin_amdgcn_perm(bhi, yhi, s1));
+		const Rgb12 p6 = color_px(KC, __builtin_amdgcn_perm(rhi, yhi, s2), __builtin_amdgcn_perm(bhi, yhi, s2));
+		const Rgb12 p7 = color_px(KC, __builtin_amdgcn_perm(rhi, yhi, s3), __builtin_amdgcn_perm(bhi, yhi, s3));
+		if (whole) {
+			store_px4<NOUT>(dst, p0, p1, p2, p3);
+			store_px4<NOUT>(dst + 4 * NOUT, p4, p5, p6, p7);
+		} else {
+			/* right-edge MCU or a row pitch that is not dword aligned: byte stores of the valid pixels */
+			const Rgb12 px[8] = {p0, p1, p2, p3, p4, p5, p6, p7};
+#pragma unroll
+			for (int j = 0; j < 8; ++j)
+				if (x0 + j < W)
+					store_rgb_px<NOUT>(dst + j * NOUT, clamp255(opaque(px[j].r >> 12)), clamp255(opaque(px[j].g >> 12)), clamp255(opaque(px[j].b >> 12)));
+		}
+	}
+}
+
 } /* namespace mij */
 
 #endif

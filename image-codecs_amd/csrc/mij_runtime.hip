@@ -122,7 +122,7 @@ struct Slot {
 	size_t stage_off;  /* byte offset in the staging arena (clones: the source's) */
 	size_t coef_bytes; /* bytes of this image's coefficient planes */
 	int clone_of;      /* -1: own staging */
-	int path;          /* 0 none, 1 fused 4:2:0, 2 two-pass */
+	int path;          /* 0 none, 1 fused 4:2:0, 2 two-pass, 3 fused 4:4:4 */
 };
 
 struct mij_batch {
@@ -154,6 +154,8 @@ struct mij_batch {
 	};
 	std::vector<BandLaunch> band_launches;
 	struct IdctLaunch {
+		int kind; /* 0 two-pass pass 1, 1 fused 4:4:4 */
+		int nout;
 		int wide;
 		size_t first, count;
 	};
@@ -464,6 +466,19 @@ static bool fused420_ok(const mij_batch *b, const mij_image_desc &d)
 	return lds <= (size_t)b->ctx->max_dyn_lds;
 }
 
+/* can the register-resident 4:4:4 kernel take this image? */
+static bool fused444_ok(const mij_batch *b, const mij_image_desc &d)
+{
+	if (b->force_generic || (d.flags & MIJ_FLAG_SKIP))
+		return false;
+	if (d.ncomp != 3 || d.color != MIJ_COLOR_YCBCR || (d.n_out != 3 && d.n_out != 4))
+		return false;
+	for (int c = 0; c < 3; ++c)
+		if (d.comp[c].h != 1 || d.comp[c].v != 1)
+			return false;
+	return (uint64_t)d.width * d.height * d.n_out < 0xfffffff0ull;
+}
+
 template <typename T>
 static int grow_pair(T *&h, T *&d, size_t &cap, size_t need)
 {
@@ -494,7 +509,7 @@ extern "C" int mij_batch_upload(mij_batch *b)
 
 	/* ---- plan: group fused images by (n_out, wide); everything else goes two-pass */
 	std::vector<WorkBand> bands[4];
-	std::vector<WorkIdct> idct[2];
+	std::vector<WorkIdct> idct[6]; /* 0,1: two-pass (narrow, wide); 2..5: fused 4:4:4 (n_out 3/4 x narrow/wide) */
 	size_t band_lds[4] = {0, 0, 0, 0};
 	b->twopass_slots.clear();
 	size_t planes_need = 0, planes_off = 0;
@@ -560,6 +575,18 @@ extern "C" int mij_batch_upload(mij_batch *b)
 			size_t lds = (size_t)d.mcu_x * (16 * 16 + 2 * 8 * 8 + 2 * 16 + 4 * 8);
 			if (lds > band_lds[g])
 				band_lds[g] = lds;
+		} else if (fused444_ok(b, d)) {
+			s.path = 3;
+			const int g = 2 + (d.n_out == 4 ? 2 : 0) + wide;
+			const uint32_t nblk = (uint32_t)(d.comp[0].bw * d.comp[0].bh);
+			for (uint32_t f = 0; f < nblk; f += 256) {
+				WorkIdct w;
+				w.img = (uint32_t)i;
+				w.comp = 0;
+				w.first = f;
+				w.pad = 0;
+				idct[g].push_back(w);
+			}
 		} else {
 			s.path = 2;
 			b->twopass_slots.push_back((int)i);
@@ -602,7 +629,7 @@ extern "C" int mij_batch_upload(mij_batch *b)
 	size_t nb_total = 0, ni_total = 0;
 	for (int g = 0; g < 4; ++g)
 		nb_total += bands[g].size();
-	for (int g = 0; g < 2; ++g)
+	for (int g = 0; g < 6; ++g)
 		ni_total += idct[g].size();
 	int rc;
 	if ((nb_total > b->bands_cap || ni_total > b->idct_cap))
@@ -632,12 +659,14 @@ extern "C" int mij_batch_upload(mij_batch *b)
 		pos += bands[g].size();
 	}
 	pos = 0;
-	for (int g = 0; g < 2; ++g) {
+	for (int g = 0; g < 6; ++g) {
 		if (idct[g].empty())
 			continue;
 		memcpy(b->h_idct + pos, idct[g].data(), idct[g].size() * sizeof(WorkIdct));
 		mij_batch::IdctLaunch L;
-		L.wide = g;
+		L.kind = g >= 2 ? 1 : 0;
+		L.nout = (g >= 4) ? 4 : 3;
+		L.wide = g & 1;
 		L.first = pos;
 		L.count = idct[g].size();
 		b->idct_launches.push_back(L);
@@ -704,7 +733,16 @@ extern "C" int mij_batch_launch(mij_batch *b)
 	for (const auto &L : b->idct_launches) {
 		const dim3 grid((unsigned)L.count), block(256);
 		const WorkIdct *wk = b->d_idct + L.first;
-		if (L.wide)
+		if (L.kind == 1) {
+			if (L.nout == 3 && !L.wide)
+				hipLaunchKernelGGL((k_fused444<3, false>), grid, block, 0, b->stream, b->d_imgs, wk, b->d_coef, b->d_out);
+			else if (L.nout == 3)
+				hipLaunchKernelGGL((k_fused444<3, true>), grid, block, 0, b->stream, b->d_imgs, wk, b->d_coef, b->d_out);
+			else if (!L.wide)
+				hipLaunchKernelGGL((k_fused444<4, false>), grid, block, 0, b->stream, b->d_imgs, wk, b->d_coef, b->d_out);
+			else
+				hipLaunchKernelGGL((k_fused444<4, true>), grid, block, 0, b->stream, b->d_imgs, wk, b->d_coef, b->d_out);
+		} else if (L.wide)
 			hipLaunchKernelGGL((k_idct_planes<true>), grid, block, 0, b->stream, b->d_imgs, wk, b->d_coef, b->d_planes);
 		else
 			hipLaunchKernelGGL((k_idct_planes<false>), grid, block, 0, b->stream, b->d_imgs, wk, b->d_coef, b->d_planes);

@@ -219,6 +219,18 @@ def main():
     nonint = pil_jpeg(test_image(30, 22, 15), quality=85, subsampling="4:2:0", progressive=False, optimize=False)
     add_case("pil_base_30x22", nonint, coef=True)
 
+    # (8b) larger libjpeg-made streams (the GPU box has no Pillow): only req_comp 3 is stored
+    def add_big(name, data):
+        names.append(name)
+        out[name + "/jpg"] = np.frombuffer(data, dtype=np.uint8)
+        out[name + "/info"] = ref_info(data)
+        a, _ = ref_load(data, 3)
+        out[name + "/out3"] = a
+    add_big("big_prog_444_256x256", pil_jpeg(test_image(256, 256, 21), quality=90, subsampling="4:4:4", progressive=True))
+    add_big("big_prog_420_320x200", pil_jpeg(test_image(320, 200, 22), quality=85, subsampling="4:2:0", progressive=True))
+    add_big("big_b422_320x240", pil_jpeg(test_image(320, 240, 23), quality=85, subsampling="4:2:2"))
+    add_big("big_b444_rst_250x130", pil_jpeg(test_image(250, 130, 24), quality=92, subsampling="4:4:4", restart_marker_rows=2))
+
     # (9) known-answer vectors for the individual stages
     rng = np.random.default_rng(99)
     blocks = []

@@ -29,7 +29,10 @@ class Golden:
         k = "%s/out%d" % (name, req)
         if k in self.z:
             return "ok", self.z[k]
-        return "fail", bytes(self.z["%s/fail%d" % (name, req)]).decode()
+        k = "%s/fail%d" % (name, req)
+        if k in self.z:
+            return "fail", bytes(self.z[k]).decode()
+        return "skip", None  # the larger fixtures only store req_comp 3
 
     def has(self, key):
         return key in self.z

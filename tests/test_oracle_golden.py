@@ -19,6 +19,8 @@ def test_oracle_decode_matches_reference_outputs(golden, oracle):
         data = golden.jpg(name)
         for req in range(5):
             kind, want = golden.expect(name, req)
+            if kind == "skip":
+                continue
             got = oracle.load(data, req)
             if kind == "fail":
                 assert got[0] == "fail", (name, req)
