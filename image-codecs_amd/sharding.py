@@ -39,7 +39,8 @@ class ControlPlane:
         self.local_rank = int(os.environ.get("LOCAL_RANK", str(self.rank)))
         self.backend = None
         self.device = torch.device("cpu")
-        if self.world > 1:
+        self._dist = self.world > 1 or os.environ.get("MIJ_FORCE_DIST") == "1"  # the knob rehearses the RCCL path on one GPU
+        if self._dist:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
             if backend is None:
@@ -51,14 +52,14 @@ class ControlPlane:
             self.backend = backend
 
     def barrier(self):
-        if self.world > 1:
+        if self._dist:
             if self.backend == "nccl":
                 dist.barrier(device_ids=[self.local_rank])
             else:
                 dist.barrier()
 
     def _reduce(self, value, op):
-        if self.world == 1:
+        if not self._dist:
             return float(value)
         t = torch.tensor([float(value)], dtype=torch.float64, device=self.device)
         dist.all_reduce(t, op=op)
@@ -71,5 +72,5 @@ class ControlPlane:
         return self._reduce(value, dist.ReduceOp.SUM)
 
     def close(self):
-        if self.world > 1 and dist.is_initialized():
+        if self._dist and dist.is_initialized():
             dist.destroy_process_group()
