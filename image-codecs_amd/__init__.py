@@ -20,6 +20,10 @@ from .binding import (  # noqa: F401
     ImageDesc,
     Batch,
     Context,
+    Encoder,
+    host_transform,
+    emit_jpeg,
+    mij_write_jpg_to_memory,
     HostDecoder,
     lib,
     build_library,

@@ -390,3 +390,122 @@ class Batch:
         if self._h:
             lib().mij_batch_destroy(self._h)
             self._h = C.c_void_p()
+
+
+# ---------------------------------------------------------------- encoder (config 5)
+
+class WritePlan(C.Structure):
+    """mjw_plan (include/mij_host.h)."""
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("comp", C.c_int), ("subsample", C.c_int), ("mcu_x", C.c_int),
+                ("mcu_y", C.c_int), ("du_per_mcu", C.c_int), ("ytab", C.c_ubyte * 64), ("ctab", C.c_ubyte * 64),
+                ("fdtbl_y", C.c_float * 64), ("fdtbl_c", C.c_float * 64)]
+
+    def du_elems(self):
+        return self.mcu_x * self.mcu_y * self.du_per_mcu * 64
+
+
+def host_transform(pixels, quality=90, flip=False):
+    """mjw_plan_init + mjw_transform_host: the writer's data units computed on the HOST
+    (int16 [n_du, 64], zigzag order) -- the CPU twin of Encoder, used to check it."""
+    a = np.ascontiguousarray(pixels, dtype=np.uint8)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    h, w, comp = a.shape
+    L = lib()
+    plan = WritePlan()
+    L.mjw_plan_init.argtypes = [C.POINTER(WritePlan), C.c_int, C.c_int, C.c_int, C.c_int]
+    L.mjw_transform_host.argtypes = [C.POINTER(WritePlan), C.c_void_p, C.c_int, C.c_void_p]
+    if not L.mjw_plan_init(C.byref(plan), w, h, comp, int(quality)):
+        return None, None
+    du = np.empty(plan.du_elems(), dtype=np.int16)
+    L.mjw_transform_host(C.byref(plan), a.ctypes.data_as(C.c_void_p), int(bool(flip)), du.ctypes.data_as(C.c_void_p))
+    return plan, du.reshape(-1, 64)
+
+
+def emit_jpeg(plan, du):
+    """mjw_emit: headers + Huffman stage over given data units -> bytes."""
+    L = lib()
+    L.mjw_emit.argtypes = [C.POINTER(WritePlan), C.c_void_p, _WRITE_CB, C.c_void_p]
+    chunks = []
+    cb = _WRITE_CB(lambda _c, data, size: chunks.append(C.string_at(data, size)))
+    d = np.ascontiguousarray(du, dtype=np.int16)
+    ok = L.mjw_emit(C.byref(plan), d.ctypes.data_as(C.c_void_p), cb, None)
+    return b"".join(chunks) if ok else None
+
+
+def mij_write_jpg_to_memory(pixels, quality=90):
+    """mij_write_jpg_to_func: the writer with its transform stage on the GPU -> bytes (None on failure)."""
+    a = np.ascontiguousarray(pixels, dtype=np.uint8)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    h, w, comp = a.shape
+    L = lib()
+    L.mij_write_jpg_to_func.argtypes = [_WRITE_CB, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    chunks = []
+    cb = _WRITE_CB(lambda _c, data, size: chunks.append(C.string_at(data, size)))
+    ok = L.mij_write_jpg_to_func(cb, None, w, h, comp, a.ctypes.data_as(C.c_void_p), int(quality))
+    return b"".join(chunks) if ok else None
+
+
+class Encoder:
+    """mij_encoder: batch colour + subsample + fDCT + quantiser on the GPU."""
+
+    def __init__(self, ctx, max_images, pixel_bytes, du_bytes):
+        L = lib()
+        L.mij_enc_create.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.mij_enc_destroy.argtypes = [C.c_void_p]
+        L.mij_enc_add.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.mij_enc_add_clone.argtypes = [C.c_void_p, C.c_int]
+        for name in ("mij_enc_reset", "mij_enc_upload", "mij_enc_launch", "mij_enc_wait", "mij_enc_timer_begin", "mij_enc_timer_end"):
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.mij_enc_fetch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        L.mij_enc_plan.argtypes = [C.c_void_p, C.c_int, C.POINTER(WritePlan)]
+        L.mij_enc_timer_elapsed_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        self._h = C.c_void_p()
+        _check(L.mij_enc_create(ctx._h, int(max_images), C.c_size_t(pixel_bytes), C.c_size_t(du_bytes), C.byref(self._h)), "mij_enc_create")
+
+    def add(self, pixels, quality=90, flip=False):
+        a = np.ascontiguousarray(pixels, dtype=np.uint8)
+        if a.ndim == 2:
+            a = a[:, :, None]
+        h, w, comp = a.shape
+        return _check(lib().mij_enc_add(self._h, a.ctypes.data_as(C.c_void_p), w, h, comp, int(quality), int(bool(flip))), "mij_enc_add")
+
+    def add_clone(self, src):
+        return _check(lib().mij_enc_add_clone(self._h, int(src)), "mij_enc_add_clone")
+
+    def upload(self):
+        _check(lib().mij_enc_upload(self._h), "mij_enc_upload")
+
+    def launch(self):
+        _check(lib().mij_enc_launch(self._h), "mij_enc_launch")
+
+    def wait(self):
+        _check(lib().mij_enc_wait(self._h), "mij_enc_wait")
+
+    def plan(self, slot):
+        p = WritePlan()
+        _check(lib().mij_enc_plan(self._h, int(slot), C.byref(p)), "mij_enc_plan")
+        return p
+
+    def fetch(self, slot):
+        p = self.plan(slot)
+        du = np.empty(p.du_elems(), dtype=np.int16)
+        _check(lib().mij_enc_fetch(self._h, int(slot), du.ctypes.data_as(C.c_void_p), C.c_size_t(du.size)), "mij_enc_fetch")
+        return du.reshape(-1, 64)
+
+    def timer_begin(self):
+        _check(lib().mij_enc_timer_begin(self._h), "mij_enc_timer_begin")
+
+    def timer_end(self):
+        _check(lib().mij_enc_timer_end(self._h), "mij_enc_timer_end")
+
+    def timer_ms(self):
+        ms = C.c_float()
+        _check(lib().mij_enc_timer_elapsed_ms(self._h, C.byref(ms)), "mij_enc_timer_elapsed_ms")
+        return ms.value
+
+    def close(self):
+        if self._h:
+            lib().mij_enc_destroy(self._h)
+            self._h = C.c_void_p()

@@ -19,7 +19,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <stdint.h>
+
 #include "image_api.h"
+#include "mij_host.h"
 
 static int g_flip_on_write = 0;
 void stbi_flip_vertically_on_write(int flag) { g_flip_on_write = flag; }
@@ -175,7 +178,7 @@ static inline void fdct8(float *p, int s)
 }
 
 /* forward DCT + quantise one data unit into zigzag order (codec/jpeg_write.c:96-118) */
-static void transform_du(float *cdu, int stride, const float *fdtbl, int *du)
+static void transform_du(float *cdu, int stride, const float *fdtbl, int16_t *du)
 {
 	int y, x, j;
 	for (y = 0; y < 8; ++y)
@@ -185,12 +188,12 @@ static void transform_du(float *cdu, int stride, const float *fdtbl, int *du)
 	for (y = 0, j = 0; y < 8; ++y)
 		for (x = 0; x < 8; ++x, ++j) {
 			float v = cdu[y * stride + x] * fdtbl[j];
-			du[k_zigzag_of[j]] = (int)(v < 0 ? v - 0.5f : v + 0.5f);
+			du[k_zigzag_of[j]] = (int16_t)(int)(v < 0 ? v - 0.5f : v + 0.5f);
 		}
 }
 
 /* Huffman-code one quantised data unit (codec/jpeg_write.c:120-169); returns its DC */
-static int emit_du(jw_sink *s, const int *du, int dc_pred, const enc_table *hdc, const enc_table *hac)
+static int emit_du(jw_sink *s, const int16_t *du, int dc_pred, const enc_table *hdc, const enc_table *hac)
 {
 	int diff = du[0] - dc_pred, end0, i;
 	unsigned bits;
@@ -229,40 +232,109 @@ static int emit_du(jw_sink *s, const int *du, int dc_pred, const enc_table *hdc,
 	return du[0];
 }
 
-/* codec/jpeg_write.c:172-366 */
-static int write_jpg_core(jw_sink *s, int width, int height, int comp, const void *data, int quality)
+/*
+ * The writer in three separable steps (so that step 2 can run on the GPU, mij_enc_* in mij.h):
+ *   1. mjw_plan_init      quality mapping, quantisation + scaled-reciprocal tables (codec/jpeg_write.c:220-243)
+ *   2. mjw_transform_host colour transform, edge replication, 2x2 chroma mean, fDCT, quantiser for every
+ *                         data unit (:283-352 minus the Huffman calls): DU blocks, MCU order, zigzag order
+ *   3. mjw_emit           headers (:245-268), Huffman emission (:120-169), padding and EOI (:358-363)
+ */
+int mjw_plan_init(mjw_plan *p, int width, int height, int comp, int quality)
 {
 	static const float aasf[8] = {1.0f * 2.828427125f,         1.387039845f * 2.828427125f, 1.306562965f * 2.828427125f, 1.175875602f * 2.828427125f,
 											1.0f * 2.828427125f,         0.785694958f * 2.828427125f, 0.541196100f * 2.828427125f, 0.275899379f * 2.828427125f};
-	enc_table ydc, yac, cdc, cac;
-	float fdtbl_y[64], fdtbl_c[64];
-	unsigned char ytab[64], ctab[64];
-	int i, row, col, k, subsample;
-
-	if (!data || !width || !height || comp > 4 || comp < 1)
+	int i, row, col, k, mcu;
+	if (!p || !width || !height || comp > 4 || comp < 1 || width < 0 || height < 0)
 		return 0;
-
 	quality = quality ? quality : 90;
-	subsample = quality <= 90 ? 1 : 0;
+	p->subsample = quality <= 90 ? 1 : 0;
 	quality = quality < 1 ? 1 : (quality > 100 ? 100 : quality);
 	quality = quality < 50 ? 5000 / quality : 200 - quality * 2;
-
 	for (i = 0; i < 64; ++i) {
 		int yq = (k_qt_lum[i] * quality + 50) / 100;
 		int cq = (k_qt_chr[i] * quality + 50) / 100;
-		ytab[k_zigzag_of[i]] = (unsigned char)(yq < 1 ? 1 : (yq > 255 ? 255 : yq));
-		ctab[k_zigzag_of[i]] = (unsigned char)(cq < 1 ? 1 : (cq > 255 ? 255 : cq));
+		p->ytab[k_zigzag_of[i]] = (unsigned char)(yq < 1 ? 1 : (yq > 255 ? 255 : yq));
+		p->ctab[k_zigzag_of[i]] = (unsigned char)(cq < 1 ? 1 : (cq > 255 ? 255 : cq));
 	}
 	for (row = 0, k = 0; row < 8; ++row)
 		for (col = 0; col < 8; ++col, ++k) {
-			fdtbl_y[k] = 1 / (ytab[k_zigzag_of[k]] * aasf[row] * aasf[col]);
-			fdtbl_c[k] = 1 / (ctab[k_zigzag_of[k]] * aasf[row] * aasf[col]);
+			p->fdtbl_y[k] = 1 / (p->ytab[k_zigzag_of[k]] * aasf[row] * aasf[col]);
+			p->fdtbl_c[k] = 1 / (p->ctab[k_zigzag_of[k]] * aasf[row] * aasf[col]);
 		}
+	p->width = width;
+	p->height = height;
+	p->comp = comp;
+	mcu = p->subsample ? 16 : 8;
+	p->mcu_x = (width + mcu - 1) / mcu;
+	p->mcu_y = (height + mcu - 1) / mcu;
+	p->du_per_mcu = p->subsample ? 6 : 3;
+	return 1;
+}
+
+size_t mjw_plan_du_count(const mjw_plan *p) { return (size_t)p->mcu_x * (size_t)p->mcu_y * (size_t)p->du_per_mcu; }
+
+void mjw_transform_host(const mjw_plan *p, const void *data, int flip, int16_t *du)
+{
+	const int width = p->width, height = p->height, comp = p->comp;
+	const int og = comp > 2 ? 1 : 0, ob = comp > 2 ? 2 : 0; /* comp 1/2: grey replicated */
+	const unsigned char *px = (const unsigned char *)data;
+	const int mcu = p->subsample ? 16 : 8;
+	int x, y, row, col, pos;
+	float Y[256], U[256], V[256];
+	for (y = 0; y < height; y += mcu)
+		for (x = 0; x < width; x += mcu) {
+			for (row = y, pos = 0; row < y + mcu; ++row) {
+				int crow = row < height ? row : height - 1; /* replicate the last row / column */
+				int base = (flip ? (height - 1 - crow) : crow) * width * comp;
+				for (col = x; col < x + mcu; ++col, ++pos) {
+					int q = base + (col < width ? col : width - 1) * comp;
+					float r = px[q], g = px[q + og], b = px[q + ob];
+					Y[pos] = +0.29900f * r + 0.58700f * g + 0.11400f * b - 128;
+					U[pos] = -0.16874f * r - 0.33126f * g + 0.50000f * b;
+					V[pos] = +0.50000f * r - 0.41869f * g - 0.08131f * b;
+				}
+			}
+			if (p->subsample) {
+				float su[64], sv[64];
+				int yy, xx;
+				transform_du(Y + 0, 16, p->fdtbl_y, du);
+				transform_du(Y + 8, 16, p->fdtbl_y, du + 64);
+				transform_du(Y + 128, 16, p->fdtbl_y, du + 128);
+				transform_du(Y + 136, 16, p->fdtbl_y, du + 192);
+				for (yy = 0, pos = 0; yy < 8; ++yy)
+					for (xx = 0; xx < 8; ++xx, ++pos) {
+						int j = yy * 32 + xx * 2;
+						su[pos] = (U[j + 0] + U[j + 1] + U[j + 16] + U[j + 17]) * 0.25f;
+						sv[pos] = (V[j + 0] + V[j + 1] + V[j + 16] + V[j + 17]) * 0.25f;
+					}
+				transform_du(su, 8, p->fdtbl_c, du + 256);
+				transform_du(sv, 8, p->fdtbl_c, du + 320);
+				du += 384;
+			} else {
+				transform_du(Y, 8, p->fdtbl_y, du);
+				transform_du(U, 8, p->fdtbl_c, du + 64);
+				transform_du(V, 8, p->fdtbl_c, du + 128);
+				du += 192;
+			}
+		}
+}
+
+int mjw_emit(const mjw_plan *p, const int16_t *du, mjw_write_func *func, void *context)
+{
+	enc_table ydc, yac, cdc, cac;
+	jw_sink *s;
+	const int width = p->width, height = p->height;
+	if (!func || !du)
+		return 0;
+	s = (jw_sink *)calloc(1, sizeof(*s));
+	if (!s)
+		return 0;
+	s->func = func;
+	s->context = context;
 	make_enc_table(&ydc, k_dc_lum_bits, k_dc_vals);
 	make_enc_table(&cdc, k_dc_chr_bits, k_dc_vals);
 	make_enc_table(&yac, k_ac_lum_bits, k_ac_lum_vals);
 	make_enc_table(&cac, k_ac_chr_bits, k_ac_chr_vals);
-
 	/* headers (codec/jpeg_write.c:245-268) */
 	{
 		static const unsigned char soi_app0_dqt[] = {0xFF, 0xD8, 0xFF, 0xE0, 0, 0x10, 'J', 'F', 'I', 'F', 0, 1, 1, 0, 0, 1, 0, 1, 0, 0, 0xFF, 0xDB, 0, 0x84, 0};
@@ -272,11 +344,11 @@ static int write_jpg_core(jw_sink *s, int width, int height, int comp, const voi
 		sof_dht[6] = (unsigned char)(height & 0xff);
 		sof_dht[7] = (unsigned char)(width >> 8);
 		sof_dht[8] = (unsigned char)(width & 0xff);
-		sof_dht[11] = (unsigned char)(subsample ? 0x22 : 0x11);
+		sof_dht[11] = (unsigned char)(p->subsample ? 0x22 : 0x11);
 		sink_bytes(s, soi_app0_dqt, (int)sizeof(soi_app0_dqt));
-		sink_bytes(s, ytab, 64);
+		sink_bytes(s, p->ytab, 64);
 		sink_byte(s, 1);
-		sink_bytes(s, ctab, 64);
+		sink_bytes(s, p->ctab, 64);
 		sink_bytes(s, sof_dht, (int)sizeof(sof_dht));
 		sink_bytes(s, k_dc_lum_bits + 1, 16);
 		sink_bytes(s, k_dc_vals, 12);
@@ -291,82 +363,55 @@ static int write_jpg_core(jw_sink *s, int width, int height, int comp, const voi
 		sink_bytes(s, k_ac_chr_vals, 162);
 		sink_bytes(s, sos, (int)sizeof(sos));
 	}
-
 	{
 		int dcy = 0, dcu = 0, dcv = 0;
-		const int og = comp > 2 ? 1 : 0, ob = comp > 2 ? 2 : 0; /* comp 1/2: grey replicated */
-		const unsigned char *px = (const unsigned char *)data;
-		const int mcu = subsample ? 16 : 8;
-		int x, y, pos, du[64];
-		float Y[256], U[256], V[256];
+		size_t m, nm = (size_t)p->mcu_x * (size_t)p->mcu_y;
 		s->bit_buf = 0;
 		s->bit_cnt = 0;
-		for (y = 0; y < height; y += mcu)
-			for (x = 0; x < width; x += mcu) {
-				for (row = y, pos = 0; row < y + mcu; ++row) {
-					int crow = row < height ? row : height - 1; /* replicate the last row / column */
-					int base = (g_flip_on_write ? (height - 1 - crow) : crow) * width * comp;
-					for (col = x; col < x + mcu; ++col, ++pos) {
-						int p = base + (col < width ? col : width - 1) * comp;
-						float r = px[p], g = px[p + og], b = px[p + ob];
-						Y[pos] = +0.29900f * r + 0.58700f * g + 0.11400f * b - 128;
-						U[pos] = -0.16874f * r - 0.33126f * g + 0.50000f * b;
-						V[pos] = +0.50000f * r - 0.41869f * g - 0.08131f * b;
-					}
-				}
-				if (subsample) {
-					float su[64], sv[64];
-					int yy, xx;
-					transform_du(Y + 0, 16, fdtbl_y, du);
-					dcy = emit_du(s, du, dcy, &ydc, &yac);
-					transform_du(Y + 8, 16, fdtbl_y, du);
-					dcy = emit_du(s, du, dcy, &ydc, &yac);
-					transform_du(Y + 128, 16, fdtbl_y, du);
-					dcy = emit_du(s, du, dcy, &ydc, &yac);
-					transform_du(Y + 136, 16, fdtbl_y, du);
-					dcy = emit_du(s, du, dcy, &ydc, &yac);
-					for (yy = 0, pos = 0; yy < 8; ++yy)
-						for (xx = 0; xx < 8; ++xx, ++pos) {
-							int j = yy * 32 + xx * 2;
-							su[pos] = (U[j + 0] + U[j + 1] + U[j + 16] + U[j + 17]) * 0.25f;
-							sv[pos] = (V[j + 0] + V[j + 1] + V[j + 16] + V[j + 17]) * 0.25f;
-						}
-					transform_du(su, 8, fdtbl_c, du);
-					dcu = emit_du(s, du, dcu, &cdc, &cac);
-					transform_du(sv, 8, fdtbl_c, du);
-					dcv = emit_du(s, du, dcv, &cdc, &cac);
-				} else {
-					transform_du(Y, 8, fdtbl_y, du);
-					dcy = emit_du(s, du, dcy, &ydc, &yac);
-					transform_du(U, 8, fdtbl_c, du);
-					dcu = emit_du(s, du, dcu, &cdc, &cac);
-					transform_du(V, 8, fdtbl_c, du);
-					dcv = emit_du(s, du, dcv, &cdc, &cac);
-				}
+		for (m = 0; m < nm; ++m) {
+			if (p->subsample) {
+				dcy = emit_du(s, du, dcy, &ydc, &yac);
+				dcy = emit_du(s, du + 64, dcy, &ydc, &yac);
+				dcy = emit_du(s, du + 128, dcy, &ydc, &yac);
+				dcy = emit_du(s, du + 192, dcy, &ydc, &yac);
+				dcu = emit_du(s, du + 256, dcu, &cdc, &cac);
+				dcv = emit_du(s, du + 320, dcv, &cdc, &cac);
+				du += 384;
+			} else {
+				dcy = emit_du(s, du, dcy, &ydc, &yac);
+				dcu = emit_du(s, du + 64, dcu, &cdc, &cac);
+				dcv = emit_du(s, du + 128, dcv, &cdc, &cac);
+				du += 192;
 			}
+		}
 		put_bits(s, 0x7F, 7); /* pad to a byte boundary with ones */
 	}
 	sink_byte(s, 0xFF);
 	sink_byte(s, 0xD9);
 	sink_flush(s);
+	free(s);
 	return 1;
 }
 
 int stbi_write_jpg_to_func(stbi_write_func *func, void *context, int x, int y, int comp, const void *data, int quality)
 {
-	jw_sink *s;
+	mjw_plan plan;
+	int16_t *du;
 	int ok;
-	if (!func)
+	if (!func || !data)
 		return 0;
-	s = (jw_sink *)calloc(1, sizeof(*s));
-	if (!s)
+	if (!mjw_plan_init(&plan, x, y, comp, quality))
 		return 0;
-	s->func = func;
-	s->context = context;
-	ok = write_jpg_core(s, x, y, comp, data, quality);
-	free(s);
+	du = (int16_t *)malloc(mjw_plan_du_count(&plan) * 64 * sizeof(int16_t));
+	if (!du)
+		return 0;
+	mjw_transform_host(&plan, data, g_flip_on_write, du);
+	ok = mjw_emit(&plan, du, func, context);
+	free(du);
 	return ok;
 }
+
+int mjw_flip_on_write(void) { return g_flip_on_write; }
 
 static void file_sink(void *context, void *data, int size) { fwrite(data, 1, (size_t)size, (FILE *)context); }
 

@@ -955,6 +955,209 @@ __global__ __launch_bounds__(256) void k_fused444(const DevImage *__restrict__ i
 	}
 }
 
+/* ------------------------------------------------------------------ encoder: colour + subsample + fDCT + quantiser
+ *
+ * The writer's arithmetic is float and order-sensitive (codec/jpeg_write.c:24-74, :96-118, :283-352):
+ * this translation unit is compiled with -ffp-contract=off, every expression keeps the reference's
+ * association, and conversions truncate like the C casts do.  IEEE single add/mul are correctly
+ * rounded on both sides, so the data units are bit-identical to the host's (tests compare them).
+ * One lane = one MCU: its data units are produced one after the other (luma quadrants, then the
+ * 2x2-mean chroma units), re-reading the MCU's pixels (L1/L2 hits) rather than holding 768 floats.
+ * Output: int16[64] per data unit, zigzag order, MCU after MCU -- what the host Huffman stage reads.
+ */
+struct EncImage {
+	int32_t width, height, comp, subsample;
+	int32_t mcu_x, mcu_y, flip, pad;
+	uint64_t pix_off, du_off;
+	float fy[64], fc[64];
+};
+
+__device__ __forceinline__ void fdct8(float &d0, float &d1, float &d2, float &d3, float &d4, float &d5, float &d6, float &d7)
+{
+	const float a0 = d0 + d7, a7 = d0 - d7, a1 = d1 + d6, a6 = d1 - d6;
+	const float a2 = d2 + d5, a5 = d2 - d5, a3 = d3 + d4, a4 = d3 - d4;
+	float b0 = a0 + a3, b3 = a0 - a3, b1 = a1 + a2, b2 = a1 - a2;
+	const float o0 = b0 + b1, o4 = b0 - b1;
+	const float z1 = (b2 + b3) * 0.707106781f;
+	const float o2 = b3 + z1, o6 = b3 - z1;
+	b0 = a4 + a5;
+	b1 = a5 + a6;
+	b2 = a6 + a7;
+	const float z5 = (b0 - b2) * 0.382683433f;
+	const float z2 = b0 * 0.541196100f + z5;
+	const float z4 = b2 * 1.306562965f + z5;
+	const float z3 = b1 * 0.707106781f;
+	const float z11 = a7 + z3, z13 = a7 - z3;
+	d5 = z13 + z2;
+	d3 = z13 - z2;
+	d1 = z11 + z4;
+	d7 = z11 - z4;
+	d0 = o0;
+	d2 = o2;
+	d4 = o4;
+	d6 = o6;
+}
+
+/* rows, then columns, then quantise into zigzag order and store 128 bytes (codec/jpeg_write.c:96-118) */
+__device__ __forceinline__ void fdct_quant_store(float (&d)[64], const float *__restrict__ fdtbl, int16_t *__restrict__ dst)
+{
+	constexpr int zz[64] = {0,  1,  5,  6,  14, 15, 27, 28, 2,  4,  7,  13, 16, 26, 29, 42, 3,  8,  12, 17, 25, 30, 41, 43, 9,  11, 18, 24, 31, 40, 44, 53,
+									10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38, 46, 51, 55, 60, 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
+#pragma unroll
+	for (int y = 0; y < 8; ++y)
+		fdct8(d[8 * y + 0], d[8 * y + 1], d[8 * y + 2], d[8 * y + 3], d[8 * y + 4], d[8 * y + 5], d[8 * y + 6], d[8 * y + 7]);
+#pragma unroll
+	for (int x = 0; x < 8; ++x)
+		fdct8(d[x], d[8 + x], d[16 + x], d[24 + x], d[32 + x], d[40 + x], d[48 + x], d[56 + x]);
+	int q[64];
+#pragma unroll
+	for (int j = 0; j < 64; ++j) {
+		const float v = d[j] * fdtbl[j];
+		q[zz[j]] = (int)(v < 0 ? v - 0.5f : v + 0.5f);
+	}
+	uint32_t *o = reinterpret_cast<uint32_t *>(dst);
+#pragma unroll
+	for (int k = 0; k < 8; ++k) {
+		uint4 w;
+		w.x = (uint32_t)(uint16_t)q[8 * k + 0] | ((uint32_t)(uint16_t)q[8 * k + 1] << 16);
+		w.y = (uint32_t)(uint16_t)q[8 * k + 2] | ((uint32_t)(uint16_t)q[8 * k + 3] << 16);
+		w.z = (uint32_t)(uint16_t)q[8 * k + 4] | ((uint32_t)(uint16_t)q[8 * k + 5] << 16);
+		w.w = (uint32_t)(uint16_t)q[8 * k + 6] | ((uint32_t)(uint16_t)q[8 * k + 7] << 16);
+		*reinterpret_cast<uint4 *>(o + 4 * k) = w;
+	}
+}
+
+/* the three colour transforms, spelled as the reference spells them (codec/jpeg_write.c:298-300) */
+template <int C>
+__device__ __forceinline__ float enc_component(float r, float g, float b)
+{
+	if (C == 0)
+		return +0.29900f * r + 0.58700f * g + 0.11400f * b - 128;
+	if (C == 1)
+		return -0.16874f * r - 0.33126f * g + 0.50000f * b;
+	return +0.50000f * r - 0.41869f * g - 0.08131f * b;
+}
+
+/* keeps the loads of one pixel row from being hoisted above the previous row's arithmetic: without it
+ * the fully unrolled fetch of a 16x16 MCU wants ~800 live registers and spills */
+__device__ __forceinline__ void enc_row_fence()
+{
+	asm volatile("" ::: "memory");
+	__builtin_amdgcn_sched_barrier(0);
+}
+
+/* pixel fetch with the reference's edge replication (codec/jpeg_write.c:289-296); 32-bit offsets:
+ * column offsets are computed once per data unit, the row base once per row */
+struct EncPix {
+	const uint8_t *px;
+	int W, H, comp, og, ob, flip;
+	__device__ __forceinline__ uint32_t row_base(int row) const
+	{
+		const int crow = row < H ? row : H - 1;
+		return (uint32_t)(flip ? (H - 1 - crow) : crow) * (uint32_t)W * (uint32_t)comp;
+	}
+	__device__ __forceinline__ uint32_t col_off(int col) const { return (uint32_t)(col < W ? col : W - 1) * (uint32_t)comp; }
+	template <int C>
+	__device__ __forceinline__ float at(uint32_t p) const
+	{
+		return enc_component<C>((float)px[p], (float)px[p + og], (float)px[p + ob]);
+	}
+};
+
+/* One lane = one data unit.  Two kernels so that a wave never mixes the 64-pixel luma units with the
+ * 256-pixel (2x2 mean) chroma units: k_encode_y (SUB: 4 units per MCU, else 1), k_encode_c (2 per MCU).
+ * work.first counts data units of that kind. */
+__device__ __forceinline__ void enc_setup(const EncImage &im, const uint8_t *pix, EncPix &P)
+{
+	P.px = pix + im.pix_off;
+	P.W = im.width;
+	P.H = im.height;
+	P.comp = im.comp;
+	P.og = im.comp > 2 ? 1 : 0;
+	P.ob = im.comp > 2 ? 2 : 0;
+	P.flip = im.flip;
+}
+
+template <int SUB>
+__global__ __launch_bounds__(256) void k_encode_y(const EncImage *__restrict__ imgs, const WorkIdct *__restrict__ work, const uint8_t *__restrict__ pix,
+																  int16_t *__restrict__ du)
+{
+	const WorkIdct wk = work[blockIdx.x];
+	const EncImage &im = imgs[wk.img];
+	const uint32_t per = SUB ? 4u : 1u;
+	const uint32_t t = wk.first + threadIdx.x;
+	if (t >= (uint32_t)(im.mcu_x * im.mcu_y) * per)
+		return;
+	const uint32_t m = SUB ? (t >> 2) : t, q = SUB ? (t & 3u) : 0u;
+	const int my = (int)(m / (uint32_t)im.mcu_x), mx = (int)(m - (uint32_t)my * (uint32_t)im.mcu_x);
+	EncPix P;
+	enc_setup(im, pix, P);
+	const int qy = (SUB ? 16 : 8) * my + 8 * (int)(q >> 1), qx = (SUB ? 16 : 8) * mx + 8 * (int)(q & 1u);
+	float d[64];
+	uint32_t co[8];
+#pragma unroll
+	for (int j = 0; j < 8; ++j)
+		co[j] = P.col_off(qx + j);
+#pragma unroll
+	for (int i = 0; i < 8; ++i) {
+		const uint32_t rb = P.row_base(qy + i);
+#pragma unroll
+		for (int j = 0; j < 8; ++j)
+			d[8 * i + j] = P.at<0>(rb + co[j]);
+	}
+	fdct_quant_store(d, im.fy, du + im.du_off / 2 + (size_t)m * (SUB ? 384 : 192) + 64 * q);
+}
+
+template <int SUB>
+__global__ __launch_bounds__(256) void k_encode_c(const EncImage *__restrict__ imgs, const WorkIdct *__restrict__ work, const uint8_t *__restrict__ pix,
+																  int16_t *__restrict__ du)
+{
+	const WorkIdct wk = work[blockIdx.x];
+	const EncImage &im = imgs[wk.img];
+	const uint32_t t = wk.first + threadIdx.x;
+	if (t >= (uint32_t)(im.mcu_x * im.mcu_y) * 2u)
+		return;
+	const uint32_t m = t >> 1, c = t & 1u; /* c = 0: U, 1: V */
+	const int my = (int)(m / (uint32_t)im.mcu_x), mx = (int)(m - (uint32_t)my * (uint32_t)im.mcu_x);
+	EncPix P;
+	enc_setup(im, pix, P);
+	float d[64];
+	if (SUB) {
+		const int y0 = 16 * my, x0 = 16 * mx;
+		uint32_t co[16];
+#pragma unroll
+		for (int j = 0; j < 16; ++j)
+			co[j] = P.col_off(x0 + j);
+#pragma unroll
+		for (int i = 0; i < 8; ++i) {
+			const uint32_t r0 = P.row_base(y0 + 2 * i), r1 = P.row_base(y0 + 2 * i + 1);
+#pragma unroll
+			for (int j = 0; j < 8; ++j) {
+				if (c == 0)
+					d[8 * i + j] = (P.at<1>(r0 + co[2 * j]) + P.at<1>(r0 + co[2 * j + 1]) + P.at<1>(r1 + co[2 * j]) + P.at<1>(r1 + co[2 * j + 1])) * 0.25f;
+				else
+					d[8 * i + j] = (P.at<2>(r0 + co[2 * j]) + P.at<2>(r0 + co[2 * j + 1]) + P.at<2>(r1 + co[2 * j]) + P.at<2>(r1 + co[2 * j + 1])) * 0.25f;
+			}
+			enc_row_fence();
+		}
+		fdct_quant_store(d, im.fc, du + im.du_off / 2 + (size_t)m * 384 + 256 + 64 * c);
+	} else {
+		const int y0 = 8 * my, x0 = 8 * mx;
+		uint32_t co[8];
+#pragma unroll
+		for (int j = 0; j < 8; ++j)
+			co[j] = P.col_off(x0 + j);
+#pragma unroll
+		for (int i = 0; i < 8; ++i) {
+			const uint32_t rb = P.row_base(y0 + i);
+#pragma unroll
+			for (int j = 0; j < 8; ++j)
+				d[8 * i + j] = c == 0 ? P.at<1>(rb + co[j]) : P.at<2>(rb + co[j]);
+		}
+		fdct_quant_store(d, im.fc, du + im.du_off / 2 + (size_t)m * 192 + 64 + 64 * c);
+	}
+}
+
 } /* namespace mij */
 
 #endif

@@ -844,3 +844,330 @@ extern "C" int mij_batch_hash_out(mij_batch *b, int slot, uint64_t *hash)
 	*hash = h;
 	return MIJ_OK;
 }
+
+/* ------------------------------------------------------------------ encoder (mij_enc_*)
+ *
+ * GPU half of the JPEG writer: colour transform + 2x2 chroma mean + float AAN fDCT + quantiser
+ * (codec/jpeg_write.c:24-118, :283-352) for a batch of images; the host then Huffman-codes the data
+ * units (mjw_emit, mij_host.h).  Same arena / stream / work-list design as the decode batch.
+ */
+#include "mij_host.h"
+
+struct EncSlot {
+	mjw_plan plan;
+	EncImage dev;
+	size_t stage_off, pix_bytes, du_bytes;
+	int clone_of, flip;
+};
+
+struct mij_encoder {
+	mij_ctx *ctx;
+	hipStream_t stream;
+	hipEvent_t ev_begin, ev_end;
+	int max_images;
+	uint8_t *stage;   /* pinned pixels */
+	size_t stage_cap, stage_used;
+	uint8_t *d_pix;
+	size_t pix_cap, pix_used;
+	int16_t *d_du;
+	size_t du_cap, du_used; /* bytes */
+	int16_t *h_du;   /* pinned mirror for fetch */
+	EncImage *h_imgs, *d_imgs;
+	WorkIdct *h_work, *d_work;
+	size_t work_cap;
+	size_t n_work[4], first_work[4]; /* [sub*2 + kind]: kind 0 luma units, 1 chroma units */
+	std::vector<EncSlot> slots;
+	bool uploaded, launched;
+};
+
+extern "C" int mij_enc_create(mij_ctx *ctx, int max_images, size_t pixel_bytes, size_t du_bytes, mij_encoder **out)
+{
+	if (!ctx || !out || max_images <= 0)
+		return set_err(MIJ_E_ARG, "mij_enc_create: bad argument");
+	*out = nullptr;
+	HIP_TRY(hipSetDevice(ctx->device));
+	mij_encoder *e = new (std::nothrow) mij_encoder();
+	if (!e)
+		return set_err(MIJ_E_NOMEM, "out of host memory");
+	e->ctx = ctx;
+	e->max_images = max_images;
+	e->stage = nullptr;
+	e->d_pix = nullptr;
+	e->d_du = nullptr;
+	e->h_du = nullptr;
+	e->h_imgs = e->d_imgs = nullptr;
+	e->h_work = e->d_work = nullptr;
+	e->work_cap = 0;
+	e->stage_cap = pixel_bytes;
+	e->pix_cap = pixel_bytes;
+	e->du_cap = du_bytes;
+	e->stage_used = e->pix_used = e->du_used = 0;
+	e->uploaded = e->launched = false;
+	e->stream = nullptr;
+	e->ev_begin = e->ev_end = nullptr;
+	hipError_t r = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+	if (r == hipSuccess)
+		r = hipEventCreate(&e->ev_begin);
+	if (r == hipSuccess)
+		r = hipEventCreate(&e->ev_end);
+	if (r == hipSuccess)
+		r = hipHostMalloc(reinterpret_cast<void **>(&e->stage), pixel_bytes ? pixel_bytes : 16, hipHostMallocDefault);
+	if (r == hipSuccess)
+		r = hipMalloc(reinterpret_cast<void **>(&e->d_pix), pixel_bytes ? pixel_bytes : 16);
+	if (r == hipSuccess)
+		r = hipMalloc(reinterpret_cast<void **>(&e->d_du), du_bytes ? du_bytes : 16);
+	if (r == hipSuccess)
+		r = hipHostMalloc(reinterpret_cast<void **>(&e->h_imgs), sizeof(EncImage) * (size_t)max_images, hipHostMallocDefault);
+	if (r == hipSuccess)
+		r = hipMalloc(reinterpret_cast<void **>(&e->d_imgs), sizeof(EncImage) * (size_t)max_images);
+	if (r != hipSuccess) {
+		int code = (r == hipErrorOutOfMemory) ? MIJ_E_NOMEM : MIJ_E_HIP;
+		set_err(code, "mij_enc_create: %s", hipGetErrorString(r));
+		mij_enc_destroy(e);
+		return code;
+	}
+	*out = e;
+	return MIJ_OK;
+}
+
+extern "C" void mij_enc_destroy(mij_encoder *e)
+{
+	if (!e)
+		return;
+	(void)hipSetDevice(e->ctx->device);
+	if (e->stream)
+		(void)hipStreamSynchronize(e->stream);
+	if (e->stage)
+		(void)hipHostFree(e->stage);
+	if (e->d_pix)
+		(void)hipFree(e->d_pix);
+	if (e->d_du)
+		(void)hipFree(e->d_du);
+	if (e->h_du)
+		(void)hipHostFree(e->h_du);
+	if (e->h_imgs)
+		(void)hipHostFree(e->h_imgs);
+	if (e->d_imgs)
+		(void)hipFree(e->d_imgs);
+	if (e->h_work)
+		(void)hipHostFree(e->h_work);
+	if (e->d_work)
+		(void)hipFree(e->d_work);
+	if (e->ev_begin)
+		(void)hipEventDestroy(e->ev_begin);
+	if (e->ev_end)
+		(void)hipEventDestroy(e->ev_end);
+	if (e->stream)
+		(void)hipStreamDestroy(e->stream);
+	delete e;
+}
+
+extern "C" int mij_enc_reset(mij_encoder *e)
+{
+	if (!e)
+		return set_err(MIJ_E_ARG, "encoder is NULL");
+	HIP_TRY(hipSetDevice(e->ctx->device));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	e->slots.clear();
+	e->stage_used = e->pix_used = e->du_used = 0;
+	e->uploaded = e->launched = false;
+	return MIJ_OK;
+}
+
+static int enc_add_common(mij_encoder *e, const mjw_plan &plan, const void *pixels, int flip, int clone_of)
+{
+	if ((int)e->slots.size() >= e->max_images)
+		return set_err(MIJ_E_NOMEM, "encoder batch is full (%d images)", e->max_images);
+	EncSlot s;
+	s.plan = plan;
+	s.flip = flip;
+	s.clone_of = clone_of;
+	s.pix_bytes = align_up((size_t)plan.width * plan.height * plan.comp, 256);
+	s.du_bytes = align_up(mjw_plan_du_count(&plan) * 128, 256);
+	if (e->pix_used + s.pix_bytes > e->pix_cap)
+		return set_err(MIJ_E_NOMEM, "pixel arena exhausted");
+	if (e->du_used + s.du_bytes > e->du_cap)
+		return set_err(MIJ_E_NOMEM, "data-unit arena exhausted");
+	if (clone_of < 0) {
+		if (e->stage_used + s.pix_bytes > e->stage_cap)
+			return set_err(MIJ_E_NOMEM, "pixel staging exhausted");
+		s.stage_off = e->stage_used;
+		memcpy(e->stage + s.stage_off, pixels, (size_t)plan.width * plan.height * plan.comp);
+		e->stage_used += s.pix_bytes;
+	} else {
+		s.stage_off = e->slots[(size_t)clone_of].stage_off;
+	}
+	memset(&s.dev, 0, sizeof(s.dev));
+	s.dev.width = plan.width;
+	s.dev.height = plan.height;
+	s.dev.comp = plan.comp;
+	s.dev.subsample = plan.subsample;
+	s.dev.mcu_x = plan.mcu_x;
+	s.dev.mcu_y = plan.mcu_y;
+	s.dev.flip = flip;
+	s.dev.pix_off = e->pix_used;
+	s.dev.du_off = e->du_used;
+	memcpy(s.dev.fy, plan.fdtbl_y, sizeof(s.dev.fy));
+	memcpy(s.dev.fc, plan.fdtbl_c, sizeof(s.dev.fc));
+	e->pix_used += s.pix_bytes;
+	e->du_used += s.du_bytes;
+	e->slots.push_back(s);
+	e->uploaded = e->launched = false;
+	return (int)e->slots.size() - 1;
+}
+
+extern "C" int mij_enc_add(mij_encoder *e, const void *pixels, int width, int height, int comp, int quality, int flip_vertically)
+{
+	if (!e || !pixels)
+		return set_err(MIJ_E_ARG, "bad argument");
+	mjw_plan plan;
+	if (!mjw_plan_init(&plan, width, height, comp, quality))
+		return set_err(MIJ_E_ARG, "bad image arguments (%dx%dx%d)", width, height, comp);
+	return enc_add_common(e, plan, pixels, flip_vertically ? 1 : 0, -1);
+}
+
+extern "C" int mij_enc_add_clone(mij_encoder *e, int src_slot)
+{
+	if (!e || src_slot < 0 || src_slot >= (int)e->slots.size())
+		return set_err(MIJ_E_ARG, "bad source slot");
+	const int root = e->slots[(size_t)src_slot].clone_of >= 0 ? e->slots[(size_t)src_slot].clone_of : src_slot;
+	const EncSlot src = e->slots[(size_t)root];
+	return enc_add_common(e, src.plan, nullptr, src.flip, root);
+}
+
+extern "C" int mij_enc_upload(mij_encoder *e)
+{
+	if (!e)
+		return set_err(MIJ_E_ARG, "encoder is NULL");
+	HIP_TRY(hipSetDevice(e->ctx->device));
+	const size_t n = e->slots.size();
+	if (!n)
+		return set_err(MIJ_E_STATE, "encoder batch is empty");
+	std::vector<WorkIdct> work[4];
+	for (size_t i = 0; i < n; ++i) {
+		const EncSlot &s = e->slots[i];
+		const uint32_t nm = (uint32_t)(s.plan.mcu_x * s.plan.mcu_y);
+		const int sub = s.plan.subsample ? 1 : 0;
+		const uint32_t ny = nm * (sub ? 4u : 1u), nc = nm * 2u;
+		for (uint32_t f = 0; f < ny; f += 256) {
+			WorkIdct w = {(uint32_t)i, 0u, f, 0u};
+			work[sub * 2 + 0].push_back(w);
+		}
+		for (uint32_t f = 0; f < nc; f += 256) {
+			WorkIdct w = {(uint32_t)i, 1u, f, 0u};
+			work[sub * 2 + 1].push_back(w);
+		}
+		e->h_imgs[i] = s.dev;
+	}
+	const size_t total = work[0].size() + work[1].size() + work[2].size() + work[3].size();
+	if (total > e->work_cap)
+		HIP_TRY(hipStreamSynchronize(e->stream));
+	int rc = grow_pair(e->h_work, e->d_work, e->work_cap, total);
+	if (rc != MIJ_OK)
+		return rc;
+	size_t pos = 0;
+	for (int g = 0; g < 4; ++g) {
+		e->first_work[g] = pos;
+		e->n_work[g] = work[g].size();
+		if (!work[g].empty())
+			memcpy(e->h_work + pos, work[g].data(), work[g].size() * sizeof(WorkIdct));
+		pos += work[g].size();
+	}
+	HIP_TRY(hipMemcpyAsync(e->d_imgs, e->h_imgs, sizeof(EncImage) * n, hipMemcpyHostToDevice, e->stream));
+	HIP_TRY(hipMemcpyAsync(e->d_work, e->h_work, sizeof(WorkIdct) * total, hipMemcpyHostToDevice, e->stream));
+	for (size_t i = 0; i < n; ++i) {
+		const EncSlot &s = e->slots[i];
+		if (s.clone_of < 0)
+			HIP_TRY(hipMemcpyAsync(e->d_pix + s.dev.pix_off, e->stage + s.stage_off, s.pix_bytes, hipMemcpyHostToDevice, e->stream));
+	}
+	for (size_t i = 0; i < n; ++i) {
+		const EncSlot &s = e->slots[i];
+		if (s.clone_of >= 0)
+			HIP_TRY(hipMemcpyAsync(e->d_pix + s.dev.pix_off, e->d_pix + e->slots[(size_t)s.clone_of].dev.pix_off, s.pix_bytes, hipMemcpyDeviceToDevice, e->stream));
+	}
+	e->uploaded = true;
+	e->launched = false;
+	return MIJ_OK;
+}
+
+extern "C" int mij_enc_launch(mij_encoder *e)
+{
+	if (!e)
+		return set_err(MIJ_E_ARG, "encoder is NULL");
+	if (!e->uploaded)
+		return set_err(MIJ_E_STATE, "mij_enc_launch before mij_enc_upload");
+	HIP_TRY(hipSetDevice(e->ctx->device));
+	for (int g = 0; g < 4; ++g) {
+		if (!e->n_work[g])
+			continue;
+		const dim3 grid((unsigned)e->n_work[g]), block(256);
+		const WorkIdct *wk = e->d_work + e->first_work[g];
+		if (g == 0)
+			hipLaunchKernelGGL((k_encode_y<0>), grid, block, 0, e->stream, e->d_imgs, wk, e->d_pix, e->d_du);
+		else if (g == 1)
+			hipLaunchKernelGGL((k_encode_c<0>), grid, block, 0, e->stream, e->d_imgs, wk, e->d_pix, e->d_du);
+		else if (g == 2)
+			hipLaunchKernelGGL((k_encode_y<1>), grid, block, 0, e->stream, e->d_imgs, wk, e->d_pix, e->d_du);
+		else
+			hipLaunchKernelGGL((k_encode_c<1>), grid, block, 0, e->stream, e->d_imgs, wk, e->d_pix, e->d_du);
+		HIP_TRY(hipGetLastError());
+	}
+	e->launched = true;
+	return MIJ_OK;
+}
+
+extern "C" int mij_enc_wait(mij_encoder *e)
+{
+	if (!e)
+		return set_err(MIJ_E_ARG, "encoder is NULL");
+	HIP_TRY(hipSetDevice(e->ctx->device));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	return MIJ_OK;
+}
+
+extern "C" int mij_enc_fetch(mij_encoder *e, int slot, int16_t *dst, size_t dst_elems)
+{
+	if (!e || slot < 0 || slot >= (int)e->slots.size() || !dst)
+		return set_err(MIJ_E_ARG, "bad slot or destination");
+	if (!e->launched)
+		return set_err(MIJ_E_STATE, "mij_enc_fetch before launch");
+	const EncSlot &s = e->slots[(size_t)slot];
+	const size_t elems = mjw_plan_du_count(&s.plan) * 64;
+	if (dst_elems < elems)
+		return set_err(MIJ_E_ARG, "destination too small");
+	HIP_TRY(hipSetDevice(e->ctx->device));
+	HIP_TRY(hipMemcpyAsync(dst, reinterpret_cast<const uint8_t *>(e->d_du) + s.dev.du_off, elems * 2, hipMemcpyDeviceToHost, e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	return MIJ_OK;
+}
+
+extern "C" int mij_enc_plan(const mij_encoder *e, int slot, mjw_plan *out)
+{
+	if (!e || slot < 0 || slot >= (int)e->slots.size() || !out)
+		return set_err(MIJ_E_ARG, "bad slot");
+	*out = e->slots[(size_t)slot].plan;
+	return MIJ_OK;
+}
+
+extern "C" int mij_enc_timer_begin(mij_encoder *e)
+{
+	if (!e)
+		return set_err(MIJ_E_ARG, "encoder is NULL");
+	HIP_TRY(hipEventRecord(e->ev_begin, e->stream));
+	return MIJ_OK;
+}
+extern "C" int mij_enc_timer_end(mij_encoder *e)
+{
+	if (!e)
+		return set_err(MIJ_E_ARG, "encoder is NULL");
+	HIP_TRY(hipEventRecord(e->ev_end, e->stream));
+	return MIJ_OK;
+}
+extern "C" int mij_enc_timer_elapsed_ms(mij_encoder *e, float *ms)
+{
+	if (!e || !ms)
+		return set_err(MIJ_E_ARG, "bad argument");
+	HIP_TRY(hipEventSynchronize(e->ev_end));
+	HIP_TRY(hipEventElapsedTime(ms, e->ev_begin, e->ev_end));
+	return MIJ_OK;
+}

@@ -184,6 +184,31 @@ int mij_batch_slot_path(const mij_batch *b, int slot);
 /* force the generic (unfused) path for every image of a batch: parity tests compare both */
 int mij_batch_force_generic(mij_batch *b, int on);
 
+/*
+ * Encoder half (BASELINE config 5): the JPEG writer's colour transform, edge replication, 2x2
+ * chroma mean, float AAN forward DCT and quantiser (codec/jpeg_write.c:24-74, :96-118, :283-352)
+ * for a batch of images on the GPU.  Input: interleaved 8-bit pixels, comp 1..4 as passed to
+ * stbi_write_jpg; output: int16[64] data units in zigzag order, MCU after MCU (4:2:0: Y00 Y01 Y10
+ * Y11 U V; 4:4:4: Y U V), bit-identical to mjw_transform_host (mij_host.h), for the host's
+ * Huffman stage (mjw_emit).  Algorithmic bytes per 1080p image: 6 220 800 read + 6 266 880 written.
+ */
+typedef struct mij_encoder mij_encoder;
+
+int mij_enc_create(mij_ctx *ctx, int max_images, size_t pixel_bytes, size_t du_bytes, mij_encoder **out);
+void mij_enc_destroy(mij_encoder *e);
+int mij_enc_reset(mij_encoder *e);
+/* copies the pixels into pinned staging; quality and 4:2:0/4:4:4 choice as stbi_write_jpg; returns the slot */
+int mij_enc_add(mij_encoder *e, const void *pixels, int width, int height, int comp, int quality, int flip_vertically);
+int mij_enc_add_clone(mij_encoder *e, int src_slot); /* own device buffers, same pixels (benchmarks) */
+int mij_enc_upload(mij_encoder *e);
+int mij_enc_launch(mij_encoder *e);
+int mij_enc_wait(mij_encoder *e);
+/* D2H of a slot's data units (mcu_x*mcu_y*du_per_mcu*64 int16) */
+int mij_enc_fetch(mij_encoder *e, int slot, int16_t *dst, size_t dst_elems);
+int mij_enc_timer_begin(mij_encoder *e);
+int mij_enc_timer_end(mij_encoder *e);
+int mij_enc_timer_elapsed_ms(mij_encoder *e, float *ms);
+
 #ifdef __cplusplus
 }
 #endif

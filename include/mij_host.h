@@ -46,6 +46,40 @@ int mjh_decode_memory(const uint8_t *buf, int len, int req_comp, mij_image_desc 
  */
 int mjh_decode_batch(mij_batch *b, const uint8_t *const *bufs, const int *lens, int n, int req_comp, int threads, int *slots, const char **reasons);
 
+/*
+ * JPEG writer in three steps (stbi_write_jpg_to_func = plan + transform + emit); step 2 also exists
+ * on the GPU (mij_enc_* in mij.h) and must produce the same data units bit for bit.
+ *   mjw_plan_init       quality mapping and tables                       codec/jpeg_write.c:220-243
+ *   mjw_transform_host  colour transform, edge replication, 2x2 chroma mean, float AAN fDCT, quantiser
+ *                       for every data unit                              codec/jpeg_write.c:24-74,96-118,283-352
+ *   mjw_emit            headers, Huffman emission, padding, EOI          codec/jpeg_write.c:245-268,120-169,358-363
+ * Data units: int16[64] each, zigzag order, MCU after MCU (4:2:0: Y00 Y01 Y10 Y11 U V; 4:4:4: Y U V).
+ */
+typedef void mjw_write_func(void *context, void *data, int size); /* == stbi_write_func */
+typedef struct {
+	int width, height, comp; /* comp 1..4 as passed to stbi_write_jpg */
+	int subsample;           /* 1: 4:2:0 (quality <= 90), 0: 4:4:4 */
+	int mcu_x, mcu_y, du_per_mcu;
+	unsigned char ytab[64], ctab[64]; /* quantisation tables, zigzag order (as written to DQT) */
+	float fdtbl_y[64], fdtbl_c[64];   /* 1 / (q * aan scale), natural order */
+} mjw_plan;
+
+int mjw_plan_init(mjw_plan *p, int width, int height, int comp, int quality); /* 0 on bad arguments */
+size_t mjw_plan_du_count(const mjw_plan *p);
+void mjw_transform_host(const mjw_plan *p, const void *pixels, int flip_vertically, int16_t *du);
+int mjw_emit(const mjw_plan *p, const int16_t *du, mjw_write_func *func, void *context);
+int mjw_flip_on_write(void); /* the flag set by stbi_flip_vertically_on_write */
+
+/* the plan (tables, geometry) the GPU encoder built for a slot, for mjw_emit */
+int mij_enc_plan(const mij_encoder *e, int slot, mjw_plan *out);
+
+/*
+ * stbi_write_jpg_to_func with step 2 on the GPU: same arguments, same byte stream (the data units
+ * are bit-identical), 0 on bad arguments or when no gfx950 device is present (no CPU fallback: use
+ * stbi_write_jpg_to_func for the host-only writer).
+ */
+int mij_write_jpg_to_func(mjw_write_func *func, void *context, int x, int y, int comp, const void *data, int quality);
+
 #ifdef __cplusplus
 }
 #endif
