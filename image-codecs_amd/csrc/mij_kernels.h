@@ -1078,6 +1078,15 @@ __device__ __forceinline__ void enc_setup(const EncImage &im, const uint8_t *pix
 	P.flip = im.flip;
 }
 
+/* byte k of a row of dwords as float (v_cvt_f32_ubyteN) */
+template <int K>
+__device__ __forceinline__ float enc_byte(const uint32_t *w)
+{
+	return (float)((w[K >> 2] >> (8 * (K & 3))) & 0xffu);
+}
+
+/* Lanes walk the luma data units in raster order of 8x8 blocks (consecutive lanes = horizontally
+ * adjacent blocks = contiguous pixel bytes); the unit is stored at its place in MCU order. */
 template <int SUB>
 __global__ __launch_bounds__(256) void k_encode_y(const EncImage *__restrict__ imgs, const WorkIdct *__restrict__ work, const uint8_t *__restrict__ pix,
 																  int16_t *__restrict__ du)
@@ -1088,24 +1097,68 @@ __global__ __launch_bounds__(256) void k_encode_y(const EncImage *__restrict__ i
 	const uint32_t t = wk.first + threadIdx.x;
 	if (t >= (uint32_t)(im.mcu_x * im.mcu_y) * per)
 		return;
-	const uint32_t m = SUB ? (t >> 2) : t, q = SUB ? (t & 3u) : 0u;
-	const int my = (int)(m / (uint32_t)im.mcu_x), mx = (int)(m - (uint32_t)my * (uint32_t)im.mcu_x);
+	const uint32_t bpr = (uint32_t)im.mcu_x * (SUB ? 2u : 1u); /* 8x8 luma blocks per block row */
+	const uint32_t by = t / bpr, bx = t - by * bpr;
+	const uint32_t m = SUB ? (by >> 1) * (uint32_t)im.mcu_x + (bx >> 1) : t;
+	const uint32_t q = SUB ? ((by & 1u) << 1 | (bx & 1u)) : 0u;
 	EncPix P;
 	enc_setup(im, pix, P);
-	const int qy = (SUB ? 16 : 8) * my + 8 * (int)(q >> 1), qx = (SUB ? 16 : 8) * mx + 8 * (int)(q & 1u);
+	const int qy = 8 * (int)by, qx = 8 * (int)bx;
 	float d[64];
-	uint32_t co[8];
+	if (im.comp == 3 && (im.width & 15) == 0) {
+		/* whole rows inside the image, 8 pixels = 24 bytes, 8-byte aligned: three 8-byte loads per row */
 #pragma unroll
-	for (int j = 0; j < 8; ++j)
-		co[j] = P.col_off(qx + j);
-#pragma unroll
-	for (int i = 0; i < 8; ++i) {
-		const uint32_t rb = P.row_base(qy + i);
+		for (int i = 0; i < 8; ++i) {
+			const uint2 *rp = reinterpret_cast<const uint2 *>(P.px + P.row_base(qy + i) + (uint32_t)qx * 3u);
+			const uint2 a = rp[0], b = rp[1], c = rp[2];
+			const uint32_t w[6] = {a.x, a.y, b.x, b.y, c.x, c.y};
+			d[8 * i + 0] = enc_component<0>(enc_byte<0>(w), enc_byte<1>(w), enc_byte<2>(w));
+			d[8 * i + 1] = enc_component<0>(enc_byte<3>(w), enc_byte<4>(w), enc_byte<5>(w));
+			d[8 * i + 2] = enc_component<0>(enc_byte<6>(w), enc_byte<7>(w), enc_byte<8>(w));
+			d[8 * i + 3] = enc_component<0>(enc_byte<9>(w), enc_byte<10>(w), enc_byte<11>(w));
+			d[8 * i + 4] = enc_component<0>(enc_byte<12>(w), enc_byte<13>(w), enc_byte<14>(w));
+			d[8 * i + 5] = enc_component<0>(enc_byte<15>(w), enc_byte<16>(w), enc_byte<17>(w));
+			d[8 * i + 6] = enc_component<0>(enc_byte<18>(w), enc_byte<19>(w), enc_byte<20>(w));
+			d[8 * i + 7] = enc_component<0>(enc_byte<21>(w), enc_byte<22>(w), enc_byte<23>(w));
+		}
+	} else {
+		uint32_t co[8];
 #pragma unroll
 		for (int j = 0; j < 8; ++j)
-			d[8 * i + j] = P.at<0>(rb + co[j]);
+			co[j] = P.col_off(qx + j);
+#pragma unroll
+		for (int i = 0; i < 8; ++i) {
+			const uint32_t rb = P.row_base(qy + i);
+#pragma unroll
+			for (int j = 0; j < 8; ++j)
+				d[8 * i + j] = P.at<0>(rb + co[j]);
+		}
 	}
 	fdct_quant_store(d, im.fy, du + im.du_off / 2 + (size_t)m * (SUB ? 384 : 192) + 64 * q);
+}
+
+/* one 2x2-mean chroma sample from two rows of packed RGB dwords; J = sample column 0..7 */
+template <int C, int J>
+__device__ __forceinline__ float enc_mean4(const uint32_t *r0, const uint32_t *r1)
+{
+	const float a = enc_component<C>(enc_byte<6 * J + 0>(r0), enc_byte<6 * J + 1>(r0), enc_byte<6 * J + 2>(r0));
+	const float b = enc_component<C>(enc_byte<6 * J + 3>(r0), enc_byte<6 * J + 4>(r0), enc_byte<6 * J + 5>(r0));
+	const float c = enc_component<C>(enc_byte<6 * J + 0>(r1), enc_byte<6 * J + 1>(r1), enc_byte<6 * J + 2>(r1));
+	const float e = enc_component<C>(enc_byte<6 * J + 3>(r1), enc_byte<6 * J + 4>(r1), enc_byte<6 * J + 5>(r1));
+	return (a + b + c + e) * 0.25f;
+}
+
+template <int C>
+__device__ __forceinline__ void enc_mean_row(const uint32_t *r0, const uint32_t *r1, float *d)
+{
+	d[0] = enc_mean4<C, 0>(r0, r1);
+	d[1] = enc_mean4<C, 1>(r0, r1);
+	d[2] = enc_mean4<C, 2>(r0, r1);
+	d[3] = enc_mean4<C, 3>(r0, r1);
+	d[4] = enc_mean4<C, 4>(r0, r1);
+	d[5] = enc_mean4<C, 5>(r0, r1);
+	d[6] = enc_mean4<C, 6>(r0, r1);
+	d[7] = enc_mean4<C, 7>(r0, r1);
 }
 
 template <int SUB>
@@ -1114,31 +1167,50 @@ __global__ __launch_bounds__(256) void k_encode_c(const EncImage *__restrict__ i
 {
 	const WorkIdct wk = work[blockIdx.x];
 	const EncImage &im = imgs[wk.img];
+	const uint32_t nmcu = (uint32_t)(im.mcu_x * im.mcu_y);
 	const uint32_t t = wk.first + threadIdx.x;
-	if (t >= (uint32_t)(im.mcu_x * im.mcu_y) * 2u)
+	if (t >= nmcu * 2u)
 		return;
-	const uint32_t m = t >> 1, c = t & 1u; /* c = 0: U, 1: V */
+	/* first all U units in MCU raster order, then all V units: consecutive lanes read adjacent MCUs */
+	const uint32_t c = t >= nmcu ? 1u : 0u, m = t - c * nmcu;
 	const int my = (int)(m / (uint32_t)im.mcu_x), mx = (int)(m - (uint32_t)my * (uint32_t)im.mcu_x);
 	EncPix P;
 	enc_setup(im, pix, P);
 	float d[64];
 	if (SUB) {
 		const int y0 = 16 * my, x0 = 16 * mx;
-		uint32_t co[16];
+		if (im.comp == 3 && (im.width & 15) == 0) {
+			/* 16 pixels = 48 bytes per row, 16-byte aligned: three 16-byte loads per row */
 #pragma unroll
-		for (int j = 0; j < 16; ++j)
-			co[j] = P.col_off(x0 + j);
-#pragma unroll
-		for (int i = 0; i < 8; ++i) {
-			const uint32_t r0 = P.row_base(y0 + 2 * i), r1 = P.row_base(y0 + 2 * i + 1);
-#pragma unroll
-			for (int j = 0; j < 8; ++j) {
+			for (int i = 0; i < 8; ++i) {
+				const uint4 *p0 = reinterpret_cast<const uint4 *>(P.px + P.row_base(y0 + 2 * i) + (uint32_t)x0 * 3u);
+				const uint4 *p1 = reinterpret_cast<const uint4 *>(P.px + P.row_base(y0 + 2 * i + 1) + (uint32_t)x0 * 3u);
+				const uint4 a0 = p0[0], a1 = p0[1], a2 = p0[2], b0 = p1[0], b1 = p1[1], b2 = p1[2];
+				const uint32_t r0[12] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w};
+				const uint32_t r1[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
 				if (c == 0)
-					d[8 * i + j] = (P.at<1>(r0 + co[2 * j]) + P.at<1>(r0 + co[2 * j + 1]) + P.at<1>(r1 + co[2 * j]) + P.at<1>(r1 + co[2 * j + 1])) * 0.25f;
+					enc_mean_row<1>(r0, r1, d + 8 * i);
 				else
-					d[8 * i + j] = (P.at<2>(r0 + co[2 * j]) + P.at<2>(r0 + co[2 * j + 1]) + P.at<2>(r1 + co[2 * j]) + P.at<2>(r1 + co[2 * j + 1])) * 0.25f;
+					enc_mean_row<2>(r0, r1, d + 8 * i);
+				enc_row_fence();
 			}
-			enc_row_fence();
+		} else {
+			uint32_t co[16];
+#pragma unroll
+			for (int j = 0; j < 16; ++j)
+				co[j] = P.col_off(x0 + j);
+#pragma unroll
+			for (int i = 0; i < 8; ++i) {
+				const uint32_t r0 = P.row_base(y0 + 2 * i), r1 = P.row_base(y0 + 2 * i + 1);
+#pragma unroll
+				for (int j = 0; j < 8; ++j) {
+					if (c == 0)
+						d[8 * i + j] = (P.at<1>(r0 + co[2 * j]) + P.at<1>(r0 + co[2 * j + 1]) + P.at<1>(r1 + co[2 * j]) + P.at<1>(r1 + co[2 * j + 1])) * 0.25f;
+					else
+						d[8 * i + j] = (P.at<2>(r0 + co[2 * j]) + P.at<2>(r0 + co[2 * j + 1]) + P.at<2>(r1 + co[2 * j]) + P.at<2>(r1 + co[2 * j + 1])) * 0.25f;
+				}
+				enc_row_fence();
+			}
 		}
 		fdct_quant_store(d, im.fc, du + im.du_off / 2 + (size_t)m * 384 + 256 + 64 * c);
 	} else {
