@@ -219,3 +219,44 @@ def mutate(data, seed, n_mut=3, allow_markers=False):
             b[pos] = new
             break
     return bytes(b)
+
+
+# ---------------------------------------------------------------- progressive test-stream writer
+
+PROGW_SRC = os.path.join(ROOT, "tests", "support", "prog_writer.c")
+PROGW_SO = os.path.join(ROOT, "tests", "support", "libprogwriter.so")
+
+
+def build_prog_writer():
+    if not os.path.exists(PROGW_SO) or os.path.getmtime(PROGW_SO) < os.path.getmtime(PROGW_SRC):
+        subprocess.run(["gcc", "-O2", "-std=gnu99", "-shared", "-fPIC", "-o", PROGW_SO, PROGW_SRC], check=True)
+    return PROGW_SO
+
+
+def du_to_planes(plan, du):
+    """The writer's data units (MCU order: Y.. U V, zigzag) -> per-component planes [bh][bw][64]."""
+    du = np.asarray(du, dtype=np.int16).reshape(plan.mcu_y, plan.mcu_x, plan.du_per_mcu, 64)
+    if plan.du_per_mcu == 6:
+        y = du[:, :, :4].reshape(plan.mcu_y, plan.mcu_x, 2, 2, 64).transpose(0, 2, 1, 3, 4).reshape(plan.mcu_y * 2, plan.mcu_x * 2, 64)
+        return [np.ascontiguousarray(y), np.ascontiguousarray(du[:, :, 4]), np.ascontiguousarray(du[:, :, 5])], (2, 1, 1)
+    if plan.du_per_mcu == 3:
+        return [np.ascontiguousarray(du[:, :, c]) for c in range(3)], (1, 1, 1)
+    raise ValueError("unsupported data-unit layout")
+
+
+def progressive_from_du(plan, du, script=1):
+    """Re-emit a writer plan's quantised data units as a progressive (SOF2) stream: same coefficients as
+    the baseline stream emit_jpeg(plan, du) carries, so both must decode to identical pixels."""
+    L = C.CDLL(build_prog_writer())
+    L.pw_write_progressive.restype = C.c_long
+    L.pw_write_progressive.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, P_INT, P_INT, C.c_void_p, C.c_int, C.c_void_p, C.c_long]
+    planes, samp = du_to_planes(plan, du)
+    ptrs = (C.c_void_p * 3)(*[p.ctypes.data for p in planes])
+    hs = (C.c_int * 3)(*samp)
+    vs = (C.c_int * 3)(*samp)
+    qt = np.concatenate([np.frombuffer(bytes(plan.ytab), np.uint8), np.frombuffer(bytes(plan.ctab), np.uint8)])
+    cap = 64 + sum(p.size for p in planes) * 3
+    out = np.empty(cap, np.uint8)
+    n = L.pw_write_progressive(ptrs, 3, plan.width, plan.height, hs, vs, qt.ctypes.data_as(C.c_void_p), int(script), out.ctypes.data_as(C.c_void_p), cap)
+    assert 0 < n <= cap, n
+    return out[:n].tobytes()

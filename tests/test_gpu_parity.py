@@ -272,3 +272,40 @@ def test_batch_api_errors(ica, gpu_ctx):
     with pytest.raises(ica.MijError):
         b.add(bad)
     b.close()
+
+
+def test_config4_full_size_progressive_444(ica, oracle, gpu_ctx):
+    """BASELINE config 4 at its real size: a 4096x4096 progressive 4:4:4 stream (ten scans, spectral
+    selection + successive approximation, EOB runs) made by tests/support/prog_writer.c from the same
+    data units as the baseline stream.  Host stage on the thread pool, register-resident kernel on the
+    GPU; whole image equal to the oracle's decode of the same stream, and to the baseline twin."""
+    img = ica.synth_rgb(4096, 4096, 1)
+    plan, du = ica.host_transform(img, 95)
+    base = ica.emit_jpeg(plan, du)
+    prog = helpers.progressive_from_du(plan, du, 1)
+    want = oracle.load(prog, 3)[1]
+    assert want.shape == (4096, 4096, 3)
+    d = ica.HostDecoder.probe(prog, 3)
+    cb, ob = ica.Batch.coef_bytes(d), ica.Batch.out_bytes(d)
+    b = ica.Batch(gpu_ctx, 2, 2 * cb, 2 * cb, 2 * ob)
+    ok, slots, reasons = b.decode_jpegs([prog, base], 3, threads=2)
+    assert ok == 2, reasons
+    b.submit()
+    b.wait()
+    for s in slots:
+        assert b.slot_path(s) == 3
+        assert np.array_equal(b.fetch(s), want), s
+    b.close()
+
+
+def test_progressive_420_full_hd_takes_the_fused_kernel(ica, oracle, gpu_ctx):
+    """A progressive 1080p 4:2:0 stream lands in the same staging layout, so the headline kernel serves it."""
+    plan, du = ica.host_transform(ica.synth_rgb(1920, 1080, 7), 90)
+    prog = helpers.progressive_from_du(plan, du, 1)
+    for req in (3, 4):
+        b, slots = _batch_for(ica, gpu_ctx, [prog], req)
+        b.submit()
+        b.wait()
+        assert b.slot_path(slots[0]) == 1
+        assert np.array_equal(b.fetch(slots[0]), oracle.load(prog, req)[1]), req
+        b.close()
