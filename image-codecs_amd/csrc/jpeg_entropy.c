@@ -245,6 +245,21 @@ static const int32_t k_bias[17] = {0, -1, -3, -7, -15, -31, -63, -127, -255, -51
 /* codec/jpeg.c:167-187 */
 static void bits_grow(mjh_decoder *d)
 {
+	/* Several bytes at once when none of them is 0xff and no marker has been seen: the same bytes land
+	 * at the same positions as in the byte loop below (bits under code_bits are zero by construction). */
+	if (!d->nomore && d->code_bits >= 0 && d->code_bits <= 24 && d->r->end - d->r->p >= 4) {
+		const uint8_t *p = d->r->p;
+		uint32_t w = ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
+		int n = (32 - d->code_bits) >> 3; /* bytes the loop below would take: 1..4 */
+		uint32_t keep = w & (0xffffffffu << (32 - 8 * n));
+		uint32_t y = ~keep; /* a zero byte in y <=> one of the n stream bytes is 0xff */
+		if (!((y - 0x01010101u) & ~y & 0x80808080u)) {
+			d->code_buffer |= keep >> d->code_bits;
+			d->code_bits += 8 * n;
+			d->r->p = p + n;
+			return;
+		}
+	}
 	do {
 		unsigned b = d->nomore ? 0 : rd8(d->r);
 		if (b == 0xff) {
@@ -266,54 +281,114 @@ static void bits_grow(mjh_decoder *d)
 
 static inline uint32_t rotl32(uint32_t x, int n) { return (x << (n & 31)) | (x >> ((32 - n) & 31)); }
 
+/* The bit register of stbi__jpeg (code_buffer / code_bits, codec/jpeg.c:69-70) held in locals across a
+ * block: the decoder struct is only touched when more bytes are needed. */
+typedef struct {
+	uint32_t buf;
+	int bits;
+} bitreg;
+
+static inline bitreg reg_load(const mjh_decoder *d)
+{
+	bitreg b;
+	b.buf = d->code_buffer;
+	b.bits = d->code_bits;
+	return b;
+}
+
+static inline void reg_store(mjh_decoder *d, const bitreg *b)
+{
+	d->code_buffer = b->buf;
+	d->code_bits = b->bits;
+}
+
+static inline void reg_grow(mjh_decoder *d, bitreg *b)
+{
+	/* bits_grow's several-bytes-at-once case on the local register */
+	mjh_reader *r = d->r;
+	if (!d->nomore && (unsigned)b->bits <= 24 && r->end - r->p >= 4) {
+		uint32_t w, keep, y;
+		int n = (32 - b->bits) >> 3;
+		memcpy(&w, r->p, 4);
+		w = __builtin_bswap32(w);
+		keep = w & (0xffffffffu << (32 - 8 * n));
+		y = ~keep;
+		if (!((y - 0x01010101u) & ~y & 0x80808080u)) {
+			b->buf |= keep >> b->bits;
+			b->bits += 8 * n;
+			r->p += n;
+			return;
+		}
+	}
+	reg_store(d, b);
+	bits_grow(d);
+	*b = reg_load(d);
+}
+
 /* codec/jpeg.c:193-243 */
-static inline int huff_decode(mjh_decoder *d, const mjh_huff *h)
+static inline int huff_decode_r(mjh_decoder *d, const mjh_huff *h, bitreg *b)
 {
 	unsigned top, temp;
 	int k, c;
-	if (d->code_bits < 16)
-		bits_grow(d);
-	top = d->code_buffer >> (32 - MJH_FAST_BITS);
+	if (b->bits < 16)
+		reg_grow(d, b);
+	top = b->buf >> (32 - MJH_FAST_BITS);
 	k = h->fast[top];
 	if (k < 255) {
 		int s = h->size[k];
-		if (s > d->code_bits)
+		if (s > b->bits)
 			return -1;
-		d->code_buffer <<= s;
-		d->code_bits -= s;
+		b->buf <<= s;
+		b->bits -= s;
 		return h->values[k];
 	}
-	temp = d->code_buffer >> 16;
+	temp = b->buf >> 16;
 	for (k = MJH_FAST_BITS + 1;; ++k)
 		if (temp < h->maxcode[k])
 			break;
 	if (k == 17) {
-		d->code_bits -= 16;
+		b->bits -= 16;
 		return -1;
 	}
-	if (k > d->code_bits)
+	if (k > b->bits)
 		return -1;
-	c = (int)((d->code_buffer >> (32 - k)) & k_bmask[k]) + h->delta[k];
-	d->code_bits -= k;
-	d->code_buffer <<= k;
+	c = (int)((b->buf >> (32 - k)) & k_bmask[k]) + h->delta[k];
+	b->bits -= k;
+	b->buf <<= k;
 	return h->values[c & 255];
 }
 
 /* codec/jpeg.c:250-265 */
-static inline int extend_receive(mjh_decoder *d, int n)
+static inline int extend_receive_r(mjh_decoder *d, int n, bitreg *b)
 {
 	uint32_t k;
 	int32_t sgn;
-	if (d->code_bits < n)
-		bits_grow(d);
+	if (b->bits < n)
+		reg_grow(d, b);
 	if (n < 0 || n > 16)
 		return 0;
-	sgn = (int32_t)d->code_buffer >> 31;
-	k = rotl32(d->code_buffer, n);
-	d->code_buffer = k & ~k_bmask[n];
+	sgn = (int32_t)b->buf >> 31;
+	k = rotl32(b->buf, n);
+	b->buf = k & ~k_bmask[n];
 	k &= k_bmask[n];
-	d->code_bits -= n;
+	b->bits -= n;
 	return (int)k + (k_bias[n] & ~sgn);
+}
+
+static inline int huff_decode(mjh_decoder *d, const mjh_huff *h)
+{
+	bitreg b = reg_load(d);
+	int v = huff_decode_r(d, h, &b);
+	reg_store(d, &b);
+	return v;
+}
+
+static inline int extend_receive(mjh_decoder *d, int n)
+{
+	bitreg b = reg_load(d);
+	int v = extend_receive_r(d, n, &b);
+	reg_store(d, &b);
+	return v;
 }
 
 /* codec/jpeg.c:268-278 */
@@ -366,16 +441,21 @@ static int decode_block(mjh_decoder *d, int16_t *blk, const mjh_huff *hdc, const
 {
 	int diff, dc, k, t;
 	int32_t l1;
+	bitreg b = reg_load(d);
 
-	if (d->code_bits < 16)
-		bits_grow(d);
-	t = huff_decode(d, hdc);
-	if (t < 0)
+	/* the reference refills here and again on entry to its Huffman routine (:313, :197): two calls
+	 * differ from one when the first stopped at a marker, so both stay */
+	if (b.bits < 16)
+		reg_grow(d, &b);
+	t = huff_decode_r(d, hdc, &b);
+	if (t < 0) {
+		reg_store(d, &b);
 		return fail(d, "bad huffman code");
+	}
 	if (cp->touched)
 		zero_block(blk);
 
-	diff = t ? extend_receive(d, t) : 0;
+	diff = t ? extend_receive_r(d, t, &b) : 0;
 	dc = (int)((unsigned)cp->dc_pred + (unsigned)diff);
 	cp->dc_pred = dc;
 	blk[0] = (int16_t)dc;
@@ -384,22 +464,24 @@ static int decode_block(mjh_decoder *d, int16_t *blk, const mjh_huff *hdc, const
 	k = 1;
 	do {
 		int c, r, s;
-		if (d->code_bits < 16)
-			bits_grow(d);
-		c = (int)(d->code_buffer >> (32 - MJH_FAST_BITS));
+		if (b.bits < 16)
+			reg_grow(d, &b);
+		c = (int)(b.buf >> (32 - MJH_FAST_BITS));
 		r = fac[c];
 		if (r) {
 			k += (r >> 4) & 15;
 			s = r & 15;
-			d->code_buffer <<= s;
-			d->code_bits -= s;
+			b.buf <<= s;
+			b.bits -= s;
 			blk[k_tile_off[k]] = (int16_t)(r >> 8);
 			l1 += iabs16((r >> 8) * qz[k]);
 			++k;
 		} else {
-			int rs = huff_decode(d, hac);
-			if (rs < 0)
+			int rs = huff_decode_r(d, hac, &b);
+			if (rs < 0) {
+				reg_store(d, &b);
 				return fail(d, "bad huffman code");
+			}
 			s = rs & 15;
 			r = rs >> 4;
 			if (s == 0) {
@@ -409,13 +491,14 @@ static int decode_block(mjh_decoder *d, int16_t *blk, const mjh_huff *hdc, const
 			} else {
 				int v;
 				k += r;
-				v = extend_receive(d, s);
+				v = extend_receive_r(d, s, &b);
 				blk[k_tile_off[k]] = (int16_t)v;
 				l1 += iabs16((int)((unsigned)v * qz[k]));
 				++k;
 			}
 		}
 	} while (k < 64);
+	reg_store(d, &b);
 	if (l1 > d->max_block_l1)
 		d->max_block_l1 = l1;
 	return 1;
