@@ -11,6 +11,7 @@
  */
 #include "jpeg_entropy.h"
 
+#include <emmintrin.h>
 #include <limits.h>
 #include <stdlib.h>
 #include <string.h>
@@ -375,47 +376,6 @@ static inline int extend_receive_r(mjh_decoder *d, int n, bitreg *b)
 	return (int)k + (k_bias[n] & ~sgn);
 }
 
-static inline int huff_decode(mjh_decoder *d, const mjh_huff *h)
-{
-	bitreg b = reg_load(d);
-	int v = huff_decode_r(d, h, &b);
-	reg_store(d, &b);
-	return v;
-}
-
-static inline int extend_receive(mjh_decoder *d, int n)
-{
-	bitreg b = reg_load(d);
-	int v = extend_receive_r(d, n, &b);
-	reg_store(d, &b);
-	return v;
-}
-
-/* codec/jpeg.c:268-278 */
-static inline int get_bits(mjh_decoder *d, int n)
-{
-	uint32_t k;
-	if (d->code_bits < n)
-		bits_grow(d);
-	k = rotl32(d->code_buffer, n);
-	d->code_buffer = k & ~k_bmask[n];
-	k &= k_bmask[n];
-	d->code_bits -= n;
-	return (int)k;
-}
-
-/* codec/jpeg.c:280-289 */
-static inline int get_bit(mjh_decoder *d)
-{
-	uint32_t k;
-	if (d->code_bits < 1)
-		bits_grow(d);
-	k = d->code_buffer;
-	d->code_buffer <<= 1;
-	--d->code_bits;
-	return (int)(k & 0x80000000u);
-}
-
 /* ------------------------------------------------------------------ block decoders */
 
 static void zero_block(int16_t *blk)
@@ -504,33 +464,63 @@ static int decode_block(mjh_decoder *d, int16_t *blk, const mjh_huff *hdc, const
 	return 1;
 }
 
+/* codec/jpeg.c:268-278 on the local register */
+static inline int get_bits_r(mjh_decoder *d, int n, bitreg *b)
+{
+	uint32_t k;
+	if (b->bits < n)
+		reg_grow(d, b);
+	k = rotl32(b->buf, n);
+	b->buf = k & ~k_bmask[n];
+	k &= k_bmask[n];
+	b->bits -= n;
+	return (int)k;
+}
+
+/* codec/jpeg.c:280-289 on the local register */
+static inline int get_bit_r(mjh_decoder *d, bitreg *b)
+{
+	uint32_t k;
+	if (b->bits < 1)
+		reg_grow(d, b);
+	k = b->buf;
+	b->buf <<= 1;
+	--b->bits;
+	return (int)(k & 0x80000000u);
+}
+
 /* codec/jpeg.c:372-402 */
 static int decode_block_prog_dc(mjh_decoder *d, int16_t *blk, const mjh_huff *hdc, mjh_comp *cp)
 {
+	bitreg b;
 	if (d->spec_end != 0)
 		return fail(d, "can't merge dc and ac");
-	if (d->code_bits < 16)
-		bits_grow(d);
+	b = reg_load(d);
+	if (b.bits < 16)
+		reg_grow(d, &b);
 	if (d->succ_high == 0) {
 		int t, diff, dc;
 		zero_block(blk);
-		t = huff_decode(d, hdc);
-		if (t < 0)
+		t = huff_decode_r(d, hdc, &b);
+		if (t < 0) {
+			reg_store(d, &b);
 			return fail(d, "can't merge dc and ac");
-		diff = t ? extend_receive(d, t) : 0;
+		}
+		diff = t ? extend_receive_r(d, t, &b) : 0;
 		dc = (int)((unsigned)cp->dc_pred + (unsigned)diff);
 		cp->dc_pred = dc;
 		blk[0] = (int16_t)((unsigned)dc << d->succ_low);
 	} else {
-		if (get_bit(d))
+		if (get_bit_r(d, &b))
 			blk[0] = (int16_t)(blk[0] + (int16_t)(1 << d->succ_low));
 	}
+	reg_store(d, &b);
 	return 1;
 }
 
-static inline void refine_nonzero(mjh_decoder *d, int16_t *p, int bit)
+static inline void refine_nonzero(mjh_decoder *d, int16_t *p, int bit, bitreg *b)
 {
-	if (get_bit(d))
+	if (get_bit_r(d, b))
 		if ((*p & bit) == 0) {
 			if (*p > 0)
 				*p = (int16_t)(*p + bit);
@@ -542,7 +532,9 @@ static inline void refine_nonzero(mjh_decoder *d, int16_t *p, int bit)
 /* codec/jpeg.c:406-558 */
 static int decode_block_prog_ac(mjh_decoder *d, int16_t *blk, const mjh_huff *hac, const int16_t *fac)
 {
+	const int spec_end = d->spec_end;
 	int k;
+	bitreg b;
 	if (d->spec_start == 0)
 		return fail(d, "can't merge dc and ac");
 
@@ -552,77 +544,86 @@ static int decode_block_prog_ac(mjh_decoder *d, int16_t *blk, const mjh_huff *ha
 			--d->eob_run;
 			return 1;
 		}
+		b = reg_load(d);
 		k = d->spec_start;
 		do {
 			int c, r, s;
-			if (d->code_bits < 16)
-				bits_grow(d);
-			c = (int)(d->code_buffer >> (32 - MJH_FAST_BITS));
+			if (b.bits < 16)
+				reg_grow(d, &b);
+			c = (int)(b.buf >> (32 - MJH_FAST_BITS));
 			r = fac[c];
 			if (r) {
 				k += (r >> 4) & 15;
 				s = r & 15;
-				d->code_buffer <<= s;
-				d->code_bits -= s;
+				b.buf <<= s;
+				b.bits -= s;
 				blk[k_tile_off[k]] = (int16_t)((unsigned)(r >> 8) << shift);
 				++k;
 			} else {
-				int rs = huff_decode(d, hac);
-				if (rs < 0)
+				int rs = huff_decode_r(d, hac, &b);
+				if (rs < 0) {
+					reg_store(d, &b);
 					return fail(d, "bad huffman code");
+				}
 				s = rs & 15;
 				r = rs >> 4;
 				if (s == 0) {
 					if (r < 15) {
 						d->eob_run = (1 << r);
 						if (r)
-							d->eob_run += get_bits(d, r);
+							d->eob_run += get_bits_r(d, r, &b);
 						--d->eob_run;
 						break;
 					}
 					k += 16;
 				} else {
 					k += r;
-					blk[k_tile_off[k]] = (int16_t)((unsigned)extend_receive(d, s) << shift);
+					blk[k_tile_off[k]] = (int16_t)((unsigned)extend_receive_r(d, s, &b) << shift);
 					++k;
 				}
 			}
-		} while (k <= d->spec_end);
+		} while (k <= spec_end);
+		reg_store(d, &b);
 	} else {
 		int bit = (int16_t)(1 << d->succ_low);
+		b = reg_load(d);
 		if (d->eob_run) {
 			--d->eob_run;
-			for (k = d->spec_start; k <= d->spec_end; ++k) {
+			for (k = d->spec_start; k <= spec_end; ++k) {
 				int16_t *p = &blk[k_tile_off[k]];
 				if (*p != 0)
-					refine_nonzero(d, p, bit);
+					refine_nonzero(d, p, bit, &b);
 			}
 		} else {
 			k = d->spec_start;
 			do {
 				int r, s;
-				int rs = huff_decode(d, hac);
-				if (rs < 0)
+				int rs = huff_decode_r(d, hac, &b);
+				if (rs < 0) {
+					reg_store(d, &b);
 					return fail(d, "bad huffman code");
+				}
 				s = rs & 15;
 				r = rs >> 4;
 				if (s == 0) {
 					if (r < 15) {
 						d->eob_run = (1 << r) - 1;
 						if (r)
-							d->eob_run += get_bits(d, r);
+							d->eob_run += get_bits_r(d, r, &b);
 						r = 64; /* run to the end of the band */
 					}
 					/* r == 15: sixteen zeros, handled by the run below with s = 0 */
 				} else {
-					if (s != 1)
+					if (s != 1) {
+						reg_store(d, &b);
 						return fail(d, "bad huffman code");
-					s = get_bit(d) ? bit : -bit;
+					}
+					s = get_bit_r(d, &b) ? bit : -bit;
 				}
-				while (k <= d->spec_end) {
+				while (k <= spec_end) {
 					int16_t *p = &blk[k_tile_off[k++]];
 					if (*p != 0) {
-						refine_nonzero(d, p, bit);
+						refine_nonzero(d, p, bit, &b);
 					} else {
 						if (r == 0) {
 							*p = (int16_t)s;
@@ -631,8 +632,9 @@ static int decode_block_prog_ac(mjh_decoder *d, int16_t *blk, const mjh_huff *ha
 						--r;
 					}
 				}
-			} while (k <= d->spec_end);
+			} while (k <= spec_end);
 		}
+		reg_store(d, &b);
 	}
 	return 1;
 }
@@ -1090,19 +1092,26 @@ static void progressive_l1(mjh_decoder *d)
 		}
 		for (t = 0; t < ntile; ++t) {
 			const int16_t *tile = cp->plane + ((size_t)t << 12);
-			int32_t acc[64];
-			memset(acc, 0, sizeof(acc));
-			for (P = 0; P < 64; ++P) {
-				const int16_t *src = tile + ((P >> 3) << 9) + (P & 7);
-				int qq = qp[P];
-				for (l = 0; l < 64; ++l) {
-					int v = (int16_t)((unsigned)src[l << 3] * (unsigned)qq);
-					acc[l] += v < 0 ? -v : v;
+			/* a block's column chunk is 8 contiguous int16: (short)(coef * q) wraps like pmullw, and
+			 * |-32768| = 32768 survives as an unsigned 16-bit lane */
+			for (l = 0; l < 64; ++l) {
+				__m128i sum = _mm_setzero_si128(), zero = _mm_setzero_si128();
+				int c;
+				uint32_t lanes[4];
+				for (c = 0; c < 8; ++c) {
+					__m128i v = _mm_loadu_si128((const __m128i *)(tile + (c << 9) + (l << 3)));
+					__m128i q8 = _mm_loadu_si128((const __m128i *)(qp + 8 * c));
+					__m128i m = _mm_mullo_epi16(v, q8);
+					__m128i a = _mm_max_epi16(m, _mm_sub_epi16(zero, m));
+					sum = _mm_add_epi32(sum, _mm_add_epi32(_mm_unpacklo_epi16(a, zero), _mm_unpackhi_epi16(a, zero)));
+				}
+				_mm_storeu_si128((__m128i *)lanes, sum);
+				{
+					int32_t l1 = (int32_t)(lanes[0] + lanes[1] + lanes[2] + lanes[3]);
+					if (l1 > d->max_block_l1)
+						d->max_block_l1 = l1;
 				}
 			}
-			for (l = 0; l < 64; ++l)
-				if (acc[l] > d->max_block_l1)
-					d->max_block_l1 = acc[l];
 		}
 	}
 }
