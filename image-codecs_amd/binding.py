@@ -483,6 +483,12 @@ class Encoder:
     def wait(self):
         _check(lib().mij_enc_wait(self._h), "mij_enc_wait")
 
+    def force_generic(self, on=True):
+        """Per-unit kernels even where the fused 4:2:0 strip kernel applies (tests); call before upload."""
+        L = lib()
+        L.mij_enc_force_generic.argtypes = [C.c_void_p, C.c_int]
+        _check(L.mij_enc_force_generic(self._h, int(bool(on))), "mij_enc_force_generic")
+
     def plan(self, slot):
         p = WritePlan()
         _check(lib().mij_enc_plan(self._h, int(slot), C.byref(p)), "mij_enc_plan")

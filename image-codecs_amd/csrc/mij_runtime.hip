@@ -91,6 +91,7 @@ extern "C" int mij_ctx_create(int device, mij_ctx **out)
 	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused420<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
 	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused420<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
 	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused420<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_encode420), hipFuncAttributeMaxDynamicSharedMemorySize, MIJ_ENC_LDS);
 	(void)hipGetLastError();
 	*out = c;
 	return MIJ_OK;
@@ -875,9 +876,9 @@ struct mij_encoder {
 	EncImage *h_imgs, *d_imgs;
 	WorkIdct *h_work, *d_work;
 	size_t work_cap;
-	size_t n_work[4], first_work[4]; /* [sub*2 + kind]: kind 0 luma units, 1 chroma units */
+	size_t n_work[5], first_work[5]; /* [sub*2 + kind]: kind 0 luma units, 1 chroma units; [4]: fused 4:2:0 strips */
 	std::vector<EncSlot> slots;
-	bool uploaded, launched;
+	bool uploaded, launched, force_generic;
 };
 
 extern "C" int mij_enc_create(mij_ctx *ctx, int max_images, size_t pixel_bytes, size_t du_bytes, mij_encoder **out)
@@ -903,6 +904,7 @@ extern "C" int mij_enc_create(mij_ctx *ctx, int max_images, size_t pixel_bytes, 
 	e->du_cap = du_bytes;
 	e->stage_used = e->pix_used = e->du_used = 0;
 	e->uploaded = e->launched = false;
+	e->force_generic = getenv("MIJ_ENC_GENERIC") != nullptr;
 	e->stream = nullptr;
 	e->ev_begin = e->ev_end = nullptr;
 	hipError_t r = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
@@ -1043,12 +1045,21 @@ extern "C" int mij_enc_upload(mij_encoder *e)
 	const size_t n = e->slots.size();
 	if (!n)
 		return set_err(MIJ_E_STATE, "encoder batch is empty");
-	std::vector<WorkIdct> work[4];
+	std::vector<WorkIdct> work[5];
 	for (size_t i = 0; i < n; ++i) {
 		const EncSlot &s = e->slots[i];
 		const uint32_t nm = (uint32_t)(s.plan.mcu_x * s.plan.mcu_y);
 		const int sub = s.plan.subsample ? 1 : 0;
 		const uint32_t ny = nm * (sub ? 4u : 1u), nc = nm * 2u;
+		e->h_imgs[i] = s.dev;
+		/* strips of 32 MCUs through the fused kernel: whole 16-pixel columns, packed RGB, 16-byte aligned rows */
+		if (sub && s.plan.comp == 3 && (s.plan.width & 15) == 0 && !e->force_generic) {
+			for (uint32_t f = 0; f < nm; f += MIJ_ENC_STRIP) {
+				WorkIdct w = {(uint32_t)i, 0u, f, 0u};
+				work[4].push_back(w);
+			}
+			continue;
+		}
 		for (uint32_t f = 0; f < ny; f += 256) {
 			WorkIdct w = {(uint32_t)i, 0u, f, 0u};
 			work[sub * 2 + 0].push_back(w);
@@ -1057,16 +1068,15 @@ extern "C" int mij_enc_upload(mij_encoder *e)
 			WorkIdct w = {(uint32_t)i, 1u, f, 0u};
 			work[sub * 2 + 1].push_back(w);
 		}
-		e->h_imgs[i] = s.dev;
 	}
-	const size_t total = work[0].size() + work[1].size() + work[2].size() + work[3].size();
+	const size_t total = work[0].size() + work[1].size() + work[2].size() + work[3].size() + work[4].size();
 	if (total > e->work_cap)
 		HIP_TRY(hipStreamSynchronize(e->stream));
 	int rc = grow_pair(e->h_work, e->d_work, e->work_cap, total);
 	if (rc != MIJ_OK)
 		return rc;
 	size_t pos = 0;
-	for (int g = 0; g < 4; ++g) {
+	for (int g = 0; g < 5; ++g) {
 		e->first_work[g] = pos;
 		e->n_work[g] = work[g].size();
 		if (!work[g].empty())
@@ -1097,12 +1107,14 @@ extern "C" int mij_enc_launch(mij_encoder *e)
 	if (!e->uploaded)
 		return set_err(MIJ_E_STATE, "mij_enc_launch before mij_enc_upload");
 	HIP_TRY(hipSetDevice(e->ctx->device));
-	for (int g = 0; g < 4; ++g) {
+	for (int g = 0; g < 5; ++g) {
 		if (!e->n_work[g])
 			continue;
-		const dim3 grid((unsigned)e->n_work[g]), block(256);
+		const dim3 grid((unsigned)e->n_work[g]), block(g == 4 ? 192 : 256);
 		const WorkIdct *wk = e->d_work + e->first_work[g];
-		if (g == 0)
+		if (g == 4)
+			hipLaunchKernelGGL(k_encode420, grid, block, MIJ_ENC_LDS, e->stream, e->d_imgs, wk, e->d_pix, e->d_du);
+		else if (g == 0)
 			hipLaunchKernelGGL((k_encode_y<0>), grid, block, 0, e->stream, e->d_imgs, wk, e->d_pix, e->d_du);
 		else if (g == 1)
 			hipLaunchKernelGGL((k_encode_c<0>), grid, block, 0, e->stream, e->d_imgs, wk, e->d_pix, e->d_du);
@@ -1113,6 +1125,15 @@ extern "C" int mij_enc_launch(mij_encoder *e)
 		HIP_TRY(hipGetLastError());
 	}
 	e->launched = true;
+	return MIJ_OK;
+}
+
+extern "C" int mij_enc_force_generic(mij_encoder *e, int on)
+{
+	if (!e)
+		return set_err(MIJ_E_ARG, "encoder is NULL");
+	e->force_generic = on != 0;
+	e->uploaded = e->launched = false;
 	return MIJ_OK;
 }
 

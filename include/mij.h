@@ -203,6 +203,7 @@ int mij_enc_add_clone(mij_encoder *e, int src_slot); /* own device buffers, same
 int mij_enc_upload(mij_encoder *e);
 int mij_enc_launch(mij_encoder *e);
 int mij_enc_wait(mij_encoder *e);
+int mij_enc_force_generic(mij_encoder *e, int on); /* tests: per-unit kernels even where the fused 4:2:0 kernel applies; before upload */
 /* D2H of a slot's data units (mcu_x*mcu_y*du_per_mcu*64 int16) */
 int mij_enc_fetch(mij_encoder *e, int slot, int16_t *dst, size_t dst_elems);
 int mij_enc_timer_begin(mij_encoder *e);

@@ -58,3 +58,28 @@ def test_gpu_encoder_flip_and_full_size(ica, oracle, gpu_ctx):
     # round trip through the GPU decoder: bytes the GPU helped write decode to what the oracle decodes
     assert np.array_equal(ica.stbi_load_from_memory(ja, 3)[0], oracle.load(ja, 3)[1])
     enc.close()
+
+
+def test_fused_strip_kernel_and_per_unit_kernels_agree(ica, gpu_ctx):
+    """Widths that are multiples of 16 take the fused 4:2:0 strip kernel (32 MCUs per workgroup, strips
+    running over MCU-row ends, a partial last strip, rows replicated below the image); the same images
+    through the per-unit kernels and through the host transform must give identical data units."""
+    rng = np.random.default_rng(23)
+    shapes = [(16, 16), (16, 1), (32, 40), (48, 17), (512, 16), (528, 33), (1024, 8), (80, 250), (1920, 1080), (16, 1100)]
+    imgs = [rng.integers(0, 256, (h, w, 3)).astype(np.uint8) for (w, h) in shapes]
+    qs = [90, 50, 75, 1, 90, 60, 90, 85, 90, 90]
+    want = [ica.host_transform(im, q)[1] for im, q in zip(imgs, qs)]
+    for generic in (False, True):
+        enc = ica.Encoder(gpu_ctx, 2 * len(imgs), 64 << 20, 64 << 20)
+        enc.force_generic(generic)
+        slots = [enc.add(im, q) for im, q in zip(imgs, qs)]
+        flipped = [enc.add(im, q, flip=True) for im, q in zip(imgs[:4], qs[:4])]
+        enc.upload()
+        enc.launch()
+        enc.wait()
+        for s, w_, shape in zip(slots, want, shapes):
+            got = enc.fetch(s)
+            assert np.array_equal(got, w_), (generic, shape, int((got != w_).sum()))
+        for s, im, q in zip(flipped, imgs, qs):
+            assert np.array_equal(enc.fetch(s), ica.host_transform(im[::-1], q)[1]), (generic, im.shape)
+        enc.close()
