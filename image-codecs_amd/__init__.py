@@ -21,6 +21,7 @@ from .binding import (  # noqa: F401
     Batch,
     Context,
     Encoder,
+    PinnedBuffer,
     host_transform,
     emit_jpeg,
     mij_write_jpg_to_memory,

@@ -363,6 +363,24 @@ class Batch:
         _check(lib().mij_batch_fetch(self._h, int(slot), out.ctypes.data_as(C.c_void_p), C.c_size_t(out.size)), "mij_batch_fetch")
         return out
 
+    def fetch_all_async(self, dst_ptr, dst_bytes):
+        """mij_batch_fetch_all_async into a (pinned) host buffer; wait() completes it."""
+        L = lib()
+        L.mij_batch_fetch_all_async.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        _check(L.mij_batch_fetch_all_async(self._h, C.c_void_p(dst_ptr), C.c_size_t(dst_bytes)), "mij_batch_fetch_all_async")
+
+    def out_offset(self, slot):
+        L = lib()
+        L.mij_batch_out_offset.restype = C.c_size_t
+        L.mij_batch_out_offset.argtypes = [C.c_void_p, C.c_int]
+        return L.mij_batch_out_offset(self._h, int(slot))
+
+    def out_total_bytes(self):
+        L = lib()
+        L.mij_batch_out_bytes.restype = C.c_size_t
+        L.mij_batch_out_bytes.argtypes = [C.c_void_p]
+        return L.mij_batch_out_bytes(self._h)
+
     def hash_out(self, slot):
         h = C.c_uint64()
         _check(lib().mij_batch_hash_out(self._h, int(slot), C.byref(h)), "mij_batch_hash_out")
@@ -390,6 +408,27 @@ class Batch:
         if self._h:
             lib().mij_batch_destroy(self._h)
             self._h = C.c_void_p()
+
+
+class PinnedBuffer:
+    """mij_host_alloc / mij_host_free: page-locked host memory as a numpy uint8 view."""
+
+    def __init__(self, nbytes):
+        L = lib()
+        L.mij_host_alloc.restype = C.c_void_p
+        L.mij_host_alloc.argtypes = [C.c_size_t]
+        L.mij_host_free.argtypes = [C.c_void_p]
+        self.ptr = L.mij_host_alloc(C.c_size_t(nbytes))
+        if not self.ptr:
+            raise MijError("mij_host_alloc(%d) failed" % nbytes)
+        self.nbytes = nbytes
+        self.array = np.ctypeslib.as_array(C.cast(self.ptr, C.POINTER(C.c_ubyte)), shape=(nbytes,))
+
+    def close(self):
+        if self.ptr:
+            self.array = None
+            lib().mij_host_free(C.c_void_p(self.ptr))
+            self.ptr = None
 
 
 # ---------------------------------------------------------------- encoder (config 5)

@@ -794,6 +794,46 @@ extern "C" int mij_batch_fetch(mij_batch *b, int slot, uint8_t *dst, size_t dst_
 	return MIJ_OK;
 }
 
+extern "C" int mij_batch_fetch_all_async(mij_batch *b, uint8_t *dst, size_t dst_bytes)
+{
+	if (!b || !dst)
+		return set_err(MIJ_E_ARG, "bad batch or destination");
+	if (!b->launched)
+		return set_err(MIJ_E_STATE, "mij_batch_fetch_all_async before launch");
+	if (dst_bytes < b->out_used)
+		return set_err(MIJ_E_ARG, "destination too small (%zu < %zu)", dst_bytes, b->out_used);
+	HIP_TRY(hipSetDevice(b->ctx->device));
+	if (b->out_used)
+		HIP_TRY(hipMemcpyAsync(dst, b->d_out, b->out_used, hipMemcpyDeviceToHost, b->stream));
+	return MIJ_OK;
+}
+
+extern "C" size_t mij_batch_out_offset(const mij_batch *b, int slot)
+{
+	if (!b || slot < 0 || slot >= (int)b->slots.size())
+		return (size_t)-1;
+	return (size_t)b->slots[(size_t)slot].dev.out_off;
+}
+
+extern "C" size_t mij_batch_out_bytes(const mij_batch *b) { return b ? b->out_used : 0; }
+
+extern "C" void *mij_host_alloc(size_t bytes)
+{
+	void *p = nullptr;
+	if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) {
+		(void)hipGetLastError();
+		set_err(MIJ_E_NOMEM, "pinned host allocation of %zu bytes failed", bytes);
+		return nullptr;
+	}
+	return p;
+}
+
+extern "C" void mij_host_free(void *p)
+{
+	if (p)
+		(void)hipHostFree(p);
+}
+
 extern "C" void *mij_batch_device_out(mij_batch *b, int slot)
 {
 	if (!b || slot < 0 || slot >= (int)b->slots.size())

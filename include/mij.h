@@ -165,6 +165,14 @@ int mij_batch_wait(mij_batch *b);
 
 /* D2H of one image's pixels into dst (dst_bytes >= n_out*width*height); waits for the batch. */
 int mij_batch_fetch(mij_batch *b, int slot, uint8_t *dst, size_t dst_bytes);
+/* The whole output arena in one asynchronous D2H on the batch's stream (image `slot` starts at byte
+ * mij_batch_out_offset(b, slot) of dst; mij_batch_out_bytes(b) in total); mij_batch_wait() completes it.
+ * Full PCIe rate needs a pinned destination: mij_host_alloc / mij_host_free. */
+int mij_batch_fetch_all_async(mij_batch *b, uint8_t *dst, size_t dst_bytes);
+size_t mij_batch_out_offset(const mij_batch *b, int slot);
+size_t mij_batch_out_bytes(const mij_batch *b);
+void *mij_host_alloc(size_t bytes);
+void mij_host_free(void *p);
 /* Device address of an image's pixels (valid until reset/destroy) for device-resident consumers. */
 void *mij_batch_device_out(mij_batch *b, int slot);
 int mij_batch_image_count(const mij_batch *b);

@@ -256,6 +256,18 @@ def test_batch_front_end_thread_pool(golden, ica, oracle, gpu_ctx):
             assert np.array_equal(b.fetch(slots[i]), oracle.load(d, 3)[1]), i
     with pytest.raises(ica.MijError):
         b.fetch(-1 - slots[7])
+    # the whole output arena in one asynchronous D2H into pinned memory
+    pin = ica.PinnedBuffer(b.out_total_bytes())
+    b.fetch_all_async(pin.ptr, pin.nbytes)
+    b.wait()
+    for i, d in enumerate(datas):
+        if slots[i] >= 0:
+            want = oracle.load(d, 3)[1].reshape(-1)
+            off = b.out_offset(slots[i])
+            assert np.array_equal(pin.array[off:off + want.size], want), i
+    with pytest.raises(ica.MijError):
+        b.fetch_all_async(pin.ptr, 16)
+    pin.close()
     b.close()
 
 
