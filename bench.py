@@ -107,6 +107,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--images", type=int, default=1024, help="images per GPU (BASELINE configs[1]: 1024)")
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic images cycled to fill the batch")
+    ap.add_argument("--settle-ms", type=float, default=0.0,
+                    help="keep issuing untimed warm-up launches until this much wall time has passed; 0 = exactly --warmup "
+                         "launches.  Measured: no gain -- the kernel is power-limited, a hot chip is ~3 %% slower than a cool one "
+                         "(profiles/r01_clock_probe.txt)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the (untimed-region) end-to-end measurement")
     ap.add_argument("--e2e-images", type=int, default=256)
@@ -143,8 +147,13 @@ def main():
     batch.wait()
 
     # ---- warm-up (untimed) + parity of what the kernel writes
-    for _ in range(max(1, args.warmup)):
+    t_w = time.perf_counter()
+    n_warm = 0
+    while n_warm < max(1, args.warmup) or (time.perf_counter() - t_w) * 1e3 < args.settle_ms:
         batch.launch()
+        n_warm += 1
+        if n_warm % 8 == 0:
+            batch.wait()  # bound the queue depth while watching the wall clock
     batch.wait()
     paths = {batch.slot_path(s) for s in range(n_img)}
     assert paths == {1}, "the fused kernel did not take the batch: %r" % paths
@@ -267,6 +276,7 @@ def main():
                 "images_per_gpu": n_img,
                 "distinct_images": distinct,
                 "sharding": "independent images, contiguous slices per GPU, no collective",
+                "warmup_launches_issued": n_warm,
                 "device": arch,
                 "compute_units": cus,
             },

@@ -3,6 +3,7 @@
 // measurements.  Build: hipcc --offload-arch=gfx950 -O3 tools/isa_probe.hip -o tools/isa_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <vector>
 
@@ -80,6 +81,54 @@ __global__ __launch_bounds__(256) void k_rate(uint32_t *out, uint32_t seed, int 
 	out[blockIdx.x * 256 + threadIdx.x] = x0 ^ x1 ^ x2 ^ x3 ^ x4 ^ x5 ^ x6 ^ x7;
 }
 
+/* sustained shader clock under a VALU-bound load: s_memtime (core clock) against s_memrealtime (100 MHz) */
+__global__ __launch_bounds__(256) void k_clock(unsigned long long *out, uint32_t *sink, uint32_t seed, int iters)
+{
+	uint32_t x0 = seed + threadIdx.x, x1 = x0 * 3u, x2 = x0 * 5u, x3 = x0 * 7u, x4 = x0 * 11u, x5 = x0 * 13u, x6 = x0 * 17u, x7 = x0 * 19u;
+	const uint32_t k = seed | 0x10001u;
+	const unsigned long long c0 = clock64(), w0 = wall_clock64();
+	for (int i = 0; i < iters; ++i) {
+		REP8(asm volatile("v_dot2_i32_i16 %0, %0, %1, %0" : "+v"(x) : "v"(k));)
+	}
+	const unsigned long long c1 = clock64(), w1 = wall_clock64();
+	sink[blockIdx.x * 256 + threadIdx.x] = x0 ^ x1 ^ x2 ^ x3 ^ x4 ^ x5 ^ x6 ^ x7;
+	if (threadIdx.x == 0) {
+		out[2 * blockIdx.x] = c1 - c0;
+		out[2 * blockIdx.x + 1] = w1 - w0;
+	}
+}
+
+static int clock_probe(uint32_t *d_out)
+{
+	const int blocks = 256 * 8;
+	unsigned long long *d_t, *h_t = (unsigned long long *)malloc(sizeof(unsigned long long) * 2 * blocks);
+	CK(hipMalloc(&d_t, sizeof(unsigned long long) * 2 * blocks));
+	for (int round = 0; round < 4; ++round) {
+		const int iters = 4096 << (2 * round > 6 ? 6 : 2 * round); /* 4096, 16384, 65536, 262144 */
+		hipEvent_t e0, e1;
+		CK(hipEventCreate(&e0));
+		CK(hipEventCreate(&e1));
+		CK(hipEventRecord(e0));
+		hipLaunchKernelGGL(k_clock, dim3(blocks), dim3(256), 0, 0, d_t, d_out, 12345u, iters);
+		CK(hipEventRecord(e1));
+		CK(hipEventSynchronize(e1));
+		float ms = 0;
+		CK(hipEventElapsedTime(&ms, e0, e1));
+		CK(hipMemcpy(h_t, d_t, sizeof(unsigned long long) * 2 * blocks, hipMemcpyDeviceToHost));
+		double sc = 0, sw = 0;
+		for (int i = 0; i < blocks; ++i) {
+			sc += (double)h_t[2 * i];
+			sw += (double)h_t[2 * i + 1];
+		}
+		const double ops = (double)blocks * 256 * iters * 8;
+		printf("clock probe: %7d iters  %8.3f ms  %6.2f T lane-ops/s  s_memtime/s_memrealtime = %.3f  (x100 MHz = %.0f MHz if s_memtime is the core clock)\n", iters, ms,
+				 ops / ms / 1e9, sc / sw, sc / sw * 100.0);
+	}
+	free(h_t);
+	CK(hipFree(d_t));
+	return 0;
+}
+
 template <int OP>
 static int rate(const char *name, uint32_t *d_out)
 {
@@ -120,6 +169,10 @@ int main()
 	printf("sat_pk_u8_i16_sdwa WORD_1 preserve      : %08x  (expect 00ffbeef)\n", h_out[5]);
 	printf("v_dot2_i32_i16 VOP3P vgpr operands      : %u  (expect 1890)\n", h_out[6]);
 	printf("v_alignbyte_b32 with VGPR shift 3       : %08x  (expect 332211dd)\n", h_out[7]);
+	if (getenv("PROBE_CLOCK_ONLY")) {
+		clock_probe(d_out);
+		return 0;
+	}
 	rate<7>("v_add_u32", d_out);
 	rate<0>("v_dot2c_i32_i16", d_out);
 	rate<1>("v_dot4_u32_u8", d_out);
@@ -151,5 +204,6 @@ int main()
 	rate<28>("v_dot2 v,v,v,0", d_out);
 	rate<29>("v_add_u32 v,S,v", d_out);
 	rate<30>("v_pk_mul_lo_u16 v,v,S", d_out);
+	clock_probe(d_out);
 	return 0;
 }
