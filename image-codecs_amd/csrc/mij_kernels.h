@@ -1013,7 +1013,8 @@ __device__ __forceinline__ void fdct8(T &d0, T &d1, T &d2, T &d3, T &d4, T &d5, 
  * turns them into column pairs H[y][j] = (col 2j, col 2j+1) of row y for the column pass.
  * "(int)(v < 0 ? v - 0.5f : v + 0.5f)" is spelled v + copysign(0.5, v): identical for every finite v
  * (for v = -0.0 both give 0). */
-__device__ __forceinline__ void fdct_quant_store(f2 (&V)[4][8], const float *__restrict__ fdtbl, int16_t *__restrict__ dst)
+template <int SWZ = -1>
+__device__ __forceinline__ void fdct_quant_store(f2 (&V)[4][8], const float *__restrict__ fdtbl, int16_t *__restrict__ dst, int swz = 0)
 {
 	constexpr int zz[64] = {0,  1,  5,  6,  14, 15, 27, 28, 2,  4,  7,  13, 16, 26, 29, 42, 3,  8,  12, 17, 25, 30, 41, 43, 9,  11, 18, 24, 31, 40, 44, 53,
 									10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38, 46, 51, 55, 60, 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
@@ -1049,7 +1050,8 @@ __device__ __forceinline__ void fdct_quant_store(f2 (&V)[4][8], const float *__r
 		w.y = (uint32_t)(uint16_t)q[8 * k + 2] | ((uint32_t)(uint16_t)q[8 * k + 3] << 16);
 		w.z = (uint32_t)(uint16_t)q[8 * k + 4] | ((uint32_t)(uint16_t)q[8 * k + 5] << 16);
 		w.w = (uint32_t)(uint16_t)q[8 * k + 6] | ((uint32_t)(uint16_t)q[8 * k + 7] << 16);
-		*reinterpret_cast<uint4 *>(o + 4 * k) = w;
+		/* SWZ >= 0: 16-byte chunk k of the unit lands at chunk k ^ swz (LDS staging, see k_encode420) */
+		*reinterpret_cast<uint4 *>(o + 4 * (SWZ >= 0 ? (k ^ swz) : k)) = w;
 	}
 }
 
@@ -1281,16 +1283,20 @@ __global__ __launch_bounds__(256) void k_encode_c(const EncImage *__restrict__ i
  *            constants keep the bits), 2x2 means in the reference's order, staged as floats in LDS in
  *            the same row-pair order
  *   DCT      waves 0 / 1 their luma unit; wave 2: lane = (mcu, U|V), unit read back from the float stage
- *   store    units staged in LDS at a 144-byte pitch over the dead pixel rows, then the strip's 32 x 768
+ *   store    units staged in LDS (swizzled 16-byte chunks) over the dead pixel rows, then the strip's 32 x 768
  *            contiguous output bytes written with coalesced 16-byte stores.
  * Pixels are read once and converted once: algorithmic traffic only.
  */
 #define MIJ_ENC_STRIP 32
 #define MIJ_ENC_PIXROW (MIJ_ENC_STRIP * 48)
-#define MIJ_ENC_DUPITCH 144
-#define MIJ_ENC_CPITCH 272
-#define MIJ_ENC_LDS_A (MIJ_ENC_STRIP * 6 * MIJ_ENC_DUPITCH) /* >= 16 * MIJ_ENC_PIXROW */
+/* staged units are unpadded; the 16-byte chunk index is XOR-swizzled with the unit index instead, so that
+ * 16-byte accesses of neighbouring lanes fall in different banks: 24 KiB + 16 KiB = 40 KiB, 4 workgroups per CU */
+#define MIJ_ENC_DUPITCH 128
+#define MIJ_ENC_CPITCH 256
+#define MIJ_ENC_LDS_A (16 * MIJ_ENC_PIXROW) /* == MIJ_ENC_STRIP * 6 * MIJ_ENC_DUPITCH */
 #define MIJ_ENC_LDS (MIJ_ENC_LDS_A + MIJ_ENC_STRIP * 2 * MIJ_ENC_CPITCH)
+__device__ __forceinline__ int enc_du_chunk(int u, int k) { return u * MIJ_ENC_DUPITCH + ((k ^ (u & 7)) << 4); }
+__device__ __forceinline__ int enc_cf_chunk(int u, int h) { return u * MIJ_ENC_CPITCH + ((h ^ (u & 15)) << 4); }
 
 /* byte k of a row of dwords as float, for a (top, bottom) row pair */
 template <int K>
@@ -1346,8 +1352,6 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(MIJ_ENC_WAV
 		const f2 KR = {-0.16874f, +0.50000f}, KG = {-0.33126f, -0.41869f}, KB = {+0.50000f, -0.08131f};
 		const int j = lane >> 1, bx = lane & 1;
 		const uint8_t *src = spx + (8 * wave) * MIJ_ENC_PIXROW + lane * 24;
-		float *cu = reinterpret_cast<float *>(scf + (2 * j) * MIJ_ENC_CPITCH) + bx * 8;
-		float *cv = reinterpret_cast<float *>(scf + (2 * j + 1) * MIJ_ENC_CPITCH) + bx * 8;
 #pragma unroll
 		for (int kk = 0; kk < 2; ++kk) {
 			f2 M[2][4]; /* [sample row & 1][sample column] = (U mean, V mean) */
@@ -1375,31 +1379,29 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(MIJ_ENC_WAV
 				enc_row_fence();
 			}
 			/* sample rows 4*wave + 2*kk (+1) of the chroma unit = its row pair 2*wave + kk, columns 4*bx .. 4*bx+3 */
-			float4 *du4 = reinterpret_cast<float4 *>(cu + (2 * wave + kk) * 16);
-			float4 *dv4 = reinterpret_cast<float4 *>(cv + (2 * wave + kk) * 16);
-			du4[0] = make_float4(M[0][0].x, M[1][0].x, M[0][1].x, M[1][1].x);
-			du4[1] = make_float4(M[0][2].x, M[1][2].x, M[0][3].x, M[1][3].x);
-			dv4[0] = make_float4(M[0][0].y, M[1][0].y, M[0][1].y, M[1][1].y);
-			dv4[1] = make_float4(M[0][2].y, M[1][2].y, M[0][3].y, M[1][3].y);
+			const int h0 = (2 * wave + kk) * 4 + bx * 2; /* 16-byte chunk of the unit: 4 floats = 2 columns x (row, row + 1) */
+			*reinterpret_cast<float4 *>(scf + enc_cf_chunk(2 * j, h0)) = make_float4(M[0][0].x, M[1][0].x, M[0][1].x, M[1][1].x);
+			*reinterpret_cast<float4 *>(scf + enc_cf_chunk(2 * j, h0 + 1)) = make_float4(M[0][2].x, M[1][2].x, M[0][3].x, M[1][3].x);
+			*reinterpret_cast<float4 *>(scf + enc_cf_chunk(2 * j + 1, h0)) = make_float4(M[0][0].y, M[1][0].y, M[0][1].y, M[1][1].y);
+			*reinterpret_cast<float4 *>(scf + enc_cf_chunk(2 * j + 1, h0 + 1)) = make_float4(M[0][2].y, M[1][2].y, M[0][3].y, M[1][3].y);
 		}
 	}
 	__syncthreads(); /* pixel rows dead, chroma means staged */
 
 	if (wave < 2) {
 		const int u = (lane >> 1) * 6 + 2 * wave + (lane & 1);
-		fdct_quant_store(V, im.fy, reinterpret_cast<int16_t *>(sdu + u * MIJ_ENC_DUPITCH));
+		fdct_quant_store<0>(V, im.fy, reinterpret_cast<int16_t *>(sdu + u * MIJ_ENC_DUPITCH), u & 7);
 	} else {
-		const float4 *cs = reinterpret_cast<const float4 *>(scf + lane * MIJ_ENC_CPITCH);
 #pragma unroll
 		for (int k = 0; k < 4; ++k)
 #pragma unroll
 			for (int h = 0; h < 4; ++h) {
-				const float4 f = cs[4 * k + h];
+				const float4 f = *reinterpret_cast<const float4 *>(scf + enc_cf_chunk(lane, 4 * k + h));
 				V[k][2 * h] = (f2){f.x, f.y};
 				V[k][2 * h + 1] = (f2){f.z, f.w};
 			}
 		const int u = (lane >> 1) * 6 + 4 + (lane & 1);
-		fdct_quant_store(V, im.fc, reinterpret_cast<int16_t *>(sdu + u * MIJ_ENC_DUPITCH));
+		fdct_quant_store<0>(V, im.fc, reinterpret_cast<int16_t *>(sdu + u * MIJ_ENC_DUPITCH), u & 7);
 	}
 	__syncthreads();
 
@@ -1409,7 +1411,7 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(MIJ_ENC_WAV
 		const int nchunk = (int)cnt * 48;
 		for (int g = tid; g < nchunk; g += 192)
 		{
-			const uint4 t = *reinterpret_cast<const uint4 *>(sdu + (g >> 3) * MIJ_ENC_DUPITCH + (g & 7) * 16);
+			const uint4 t = *reinterpret_cast<const uint4 *>(sdu + enc_du_chunk(g >> 3, g & 7));
 			__builtin_nontemporal_store((u4v){t.x, t.y, t.z, t.w}, reinterpret_cast<u4v *>(out + (size_t)g * 16u));
 		}
 	}
