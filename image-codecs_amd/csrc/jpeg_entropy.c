@@ -158,6 +158,7 @@ static const uint8_t k_dezigzag[64 + 15] = {
 
 /* zigzag index -> int16 offset inside the block's tile slot: (P>>3)*512 + (P&7) */
 static uint16_t k_tile_off[64 + 15];
+static uint8_t k_zig_of_pos[64]; /* in-tile position P = 8*chunk + slot -> zigzag index */
 static int k_tile_off_ready;
 
 static void init_tile_off(void)
@@ -169,6 +170,8 @@ static void init_tile_off(void)
 		int nat = k_dezigzag[k];
 		int P = 8 * (nat & 7) + mij_rowslot[nat >> 3];
 		k_tile_off[k] = (uint16_t)(((P >> 3) << 9) + (P & 7));
+		if (k < 64)
+			k_zig_of_pos[P] = (uint8_t)k;
 	}
 	k_tile_off_ready = 1;
 }
@@ -529,6 +532,27 @@ static inline void refine_nonzero(mjh_decoder *d, int16_t *p, int bit, bitreg *b
 		}
 }
 
+/* non-zero map of a block in zigzag order: eight 16-byte chunks (one per column) compared against zero */
+static inline uint64_t block_nonzero_mask(const int16_t *blk)
+{
+	const __m128i zero = _mm_setzero_si128();
+	uint64_t pm = 0, zm = 0;
+	int c;
+	for (c = 0; c < 8; ++c) {
+		const __m128i v = _mm_loadu_si128((const __m128i *)(blk + (c << 9)));
+		const __m128i eq = _mm_cmpeq_epi16(v, zero);
+		const unsigned m8 = (unsigned)_mm_movemask_epi8(_mm_packs_epi16(eq, zero)) & 0xffu; /* 1 = zero */
+		pm |= (uint64_t)(m8 ^ 0xffu) << (8 * c);
+	}
+	while (pm) {
+		zm |= 1ull << k_zig_of_pos[__builtin_ctzll(pm)];
+		pm &= pm - 1;
+	}
+	return zm;
+}
+
+static inline uint64_t band_mask(int lo, int hi) { return (hi >= 63 ? ~0ull : ((1ull << (hi + 1)) - 1)) & ~((1ull << lo) - 1); }
+
 /* codec/jpeg.c:406-558 */
 static int decode_block_prog_ac(mjh_decoder *d, int16_t *blk, const mjh_huff *hac, const int16_t *fac)
 {
@@ -586,13 +610,17 @@ static int decode_block_prog_ac(mjh_decoder *d, int16_t *blk, const mjh_huff *ha
 		reg_store(d, &b);
 	} else {
 		int bit = (int16_t)(1 << d->succ_low);
+		/* bit k set <=> coefficient k (zigzag order) of this block is already non-zero.  The reference
+		 * walks all positions of the band and tests each (codec/jpeg.c:497-505, :536-553); visiting only
+		 * the set bits, in the same ascending order, reads the same correction bits for the same
+		 * coefficients.  Coefficients placed by this call lie behind the walk and are never revisited. */
+		uint64_t nz = block_nonzero_mask(blk) & band_mask(d->spec_start, spec_end);
 		b = reg_load(d);
 		if (d->eob_run) {
 			--d->eob_run;
-			for (k = d->spec_start; k <= spec_end; ++k) {
-				int16_t *p = &blk[k_tile_off[k]];
-				if (*p != 0)
-					refine_nonzero(d, p, bit, &b);
+			while (nz) {
+				refine_nonzero(d, &blk[k_tile_off[__builtin_ctzll(nz)]], bit, &b);
+				nz &= nz - 1;
 			}
 		} else {
 			k = d->spec_start;
@@ -620,17 +648,24 @@ static int decode_block_prog_ac(mjh_decoder *d, int16_t *blk, const mjh_huff *ha
 					}
 					s = get_bit_r(d, &b) ? bit : -bit;
 				}
+				/* skip r zero-history coefficients, refining the non-zero ones passed on the way, then put
+				 * s into the next zero one */
 				while (k <= spec_end) {
-					int16_t *p = &blk[k_tile_off[k++]];
-					if (*p != 0) {
-						refine_nonzero(d, p, bit, &b);
-					} else {
-						if (r == 0) {
-							*p = (int16_t)s;
-							break;
-						}
-						--r;
+					const uint64_t ahead = nz >> k;
+					const int gap = ahead ? __builtin_ctzll(ahead) : 64;
+					const int avail = gap < spec_end + 1 - k ? gap : spec_end + 1 - k;
+					if (r < avail) {
+						k += r;
+						blk[k_tile_off[k]] = (int16_t)s;
+						++k;
+						break;
 					}
+					r -= avail;
+					k += avail;
+					if (k > spec_end)
+						break;
+					refine_nonzero(d, &blk[k_tile_off[k]], bit, &b);
+					++k;
 				}
 			} while (k <= spec_end);
 		}
