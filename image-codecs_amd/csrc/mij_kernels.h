@@ -350,7 +350,7 @@ __device__ __forceinline__ RowSel select_rows(int r, int vs, int ycomp)
 {
 	int half = vs >> 1;
 	int q = r + half;
-	int g = q / vs, phase = q - g * vs;
+	int g = vs == 1 ? q : (vs == 2 ? q >> 1 : (vs == 4 ? q >> 2 : q / vs)), phase = q - g * vs;
 	int l1 = min(g, ycomp - 1);
 	int l0 = g ? min(g - 1, ycomp - 1) : 0;
 	RowSel s;
@@ -362,39 +362,6 @@ __device__ __forceinline__ RowSel select_rows(int r, int vs, int ycomp)
 		s.far = l1;
 	}
 	return s;
-}
-
-/* one up-sampled component sample at output pixel (r, col); P = u8 plane with row pitch w2.
- * Follows resample_row_1 / _v_2 / _h_2 / _hv_2 / _generic (codec/jpeg.c:1765-1840,1962-1971). */
-template <typename Fetch>
-__device__ __forceinline__ int upsample_at(Fetch P, int hs, int vs, int ycomp, int width, int r, int col)
-{
-	RowSel rs = select_rows(r, vs, ycomp);
-	int w = (width + hs - 1) / hs; /* w_lores, :2276 */
-	if (hs == 1 && vs == 1)
-		return P(rs.near, col);
-	if (hs == 1 && vs == 2)
-		return (3 * P(rs.near, col) + P(rs.far, col) + 2) >> 2;
-	if (hs == 2 && vs == 1) {
-		int i = col >> 1;
-		if (w == 1 || col == 0)
-			return P(rs.near, 0);
-		if (col == 2 * w - 1)
-			return P(rs.near, w - 1);
-		if (col == 2 * w - 2) /* the reference's right-edge form, :1805 */
-			return (3 * P(rs.near, w - 2) + P(rs.near, w - 1) + 2) >> 2;
-		if (col & 1)
-			return (3 * P(rs.near, i) + P(rs.near, i + 1) + 2) >> 2;
-		return (3 * P(rs.near, i) + P(rs.near, i - 1) + 2) >> 2;
-	}
-	if (hs == 2 && vs == 2) {
-		int i = col >> 1;
-		int j = (col & 1) ? min(i + 1, w - 1) : max(i - 1, 0);
-		int ti = 3 * P(rs.near, i) + P(rs.far, i);
-		int tj = 3 * P(rs.near, j) + P(rs.far, j);
-		return (3 * ti + tj + 8) >> 4; /* == (t+2)>>2 at both ends and for w == 1, :1820-1835 */
-	}
-	return P(rs.near, col / hs);
 }
 
 /* the colour branches of load_jpeg_image (codec/jpeg.c:2320-2431); s[] = up-sampled components */
@@ -489,38 +456,134 @@ __global__ __launch_bounds__(256) void k_idct_planes(const DevImage *__restrict_
 
 /* ------------------------------------------------------------------ two-pass path, pass 2 */
 
-struct PlaneFetch {
+/* Four up-sampled samples of one component: output row r, columns x0 .. x0+3 (x0 % 4 == 0, columns past the
+ * image clamp to W-1).  Follows resample_row_1 / _v_2 / _h_2 / _hv_2 / _generic
+ * (codec/jpeg.c:1765-1840, 1962-1971); row selection and shared neighbour loads once per strip, 32-bit indices. */
+struct CompView {
 	const uint8_t *p;
-	int w2;
-	long limit; /* last valid byte index (fractional sampling ratios read past a row, as the reference does) */
-	__device__ __forceinline__ int operator()(int row, int col) const
+	int w2, limit, hs, vs, y;
+	__device__ __forceinline__ int at(int row, int col) const
 	{
-		long idx = (long)row * w2 + col;
-		idx = idx < 0 ? 0 : (idx > limit ? limit : idx);
-		return p[idx];
+		const int idx = row * w2 + col; /* hs == 1 planes narrower than the image are read past the row end, as the reference does */
+		return p[idx > limit ? limit : idx];
 	}
 };
 
-__global__ __launch_bounds__(256) void k_resample_color(const DevImage *__restrict__ imgs, uint32_t img, const uint8_t *__restrict__ planes,
+__device__ __forceinline__ void upsample_strip(const CompView &c, int W, int r, int x0, int (&o)[4])
+{
+	const RowSel rs = select_rows(r, c.vs, c.y);
+	if (c.hs == 2 && (c.vs == 1 || c.vs == 2)) {
+		const int w = (W + 1) >> 1; /* w_lores, codec/jpeg.c:2276 */
+		const int i0 = x0 >> 1;
+		const int ca = max(i0 - 1, 0), cb = min(i0, w - 1), cc = min(i0 + 1, w - 1), cd = min(i0 + 2, w - 1);
+		if (c.vs == 2) { /* hv_2 :1816-1840; the end cases are the general form with the neighbour clamped */
+			const int na = c.at(rs.near, ca), nb = c.at(rs.near, cb), nc = c.at(rs.near, cc), nd = c.at(rs.near, cd);
+			const int ta = 3 * na + c.at(rs.far, ca), tb = 3 * nb + c.at(rs.far, cb), tc = 3 * nc + c.at(rs.far, cc), td = 3 * nd + c.at(rs.far, cd);
+			o[0] = (3 * tb + ta + 8) >> 4;
+			o[1] = (3 * tb + tc + 8) >> 4;
+			o[2] = (3 * tc + tb + 8) >> 4;
+			o[3] = (3 * tc + td + 8) >> 4;
+		} else { /* h_2 :1784-1812, with its first / last / last-but-one column forms */
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				const int col = min(x0 + j, W - 1), i = col >> 1;
+				int v;
+				if (w == 1 || col == 0)
+					v = c.at(rs.near, 0);
+				else if (col == 2 * w - 1)
+					v = c.at(rs.near, w - 1);
+				else if (col == 2 * w - 2) /* the reference's right-edge form, :1805 */
+					v = (3 * c.at(rs.near, w - 2) + c.at(rs.near, w - 1) + 2) >> 2;
+				else if (col & 1)
+					v = (3 * c.at(rs.near, i) + c.at(rs.near, i + 1) + 2) >> 2;
+				else
+					v = (3 * c.at(rs.near, i) + c.at(rs.near, i - 1) + 2) >> 2;
+				o[j] = v;
+			}
+		}
+		return;
+	}
+	if (c.hs == 1 && c.vs == 1 && x0 + 3 < W && rs.near * c.w2 + x0 + 3 <= c.limit) { /* row_1 on a whole strip: one dword */
+		const uint32_t v = *reinterpret_cast<const uint32_t *>(c.p + rs.near * c.w2 + x0);
+		o[0] = v & 255;
+		o[1] = (v >> 8) & 255;
+		o[2] = (v >> 16) & 255;
+		o[3] = v >> 24;
+		return;
+	}
+#pragma unroll
+	for (int j = 0; j < 4; ++j) {
+		const int col = min(x0 + j, W - 1);
+		if (c.hs == 1 && c.vs == 2)
+			o[j] = (3 * c.at(rs.near, col) + c.at(rs.far, col) + 2) >> 2; /* v_2 :1774-1782 */
+		else if (c.hs == 1)
+			o[j] = c.at(rs.near, col); /* row_1, or the generic resampler with hs == 1 */
+		else
+			o[j] = c.at(rs.near, col / c.hs); /* generic :1962-1971 */
+	}
+}
+
+/* Pass 2: work item = MIJ_RESAMPLE_ROWS output rows of one image; a thread takes 4-pixel strips, so that
+ * the usual case (whole strip, dword-aligned address) leaves as n_out dwords instead of 4*n_out byte stores. */
+#define MIJ_RESAMPLE_ROWS 4
+__global__ __launch_bounds__(256) void k_resample_color(const DevImage *__restrict__ imgs, const WorkIdct *__restrict__ work, const uint8_t *__restrict__ planes,
 																		  uint8_t *__restrict__ outbase)
 {
-	const DevImage &im = imgs[img];
-	const int col = blockIdx.x * 256 + threadIdx.x;
-	const int r = blockIdx.y;
-	if (col >= im.width)
-		return;
-	const int need = comps_needed(im.color, im.n_out, im.ncomp);
-	int s[4] = {0, 0, 0, 0};
-	for (int k = 0; k < need; ++k) {
-		const DevComp &cp = im.comp[k];
-		PlaneFetch P;
-		P.p = planes + cp.plane_off;
-		P.w2 = cp.bw * 8;
-		P.limit = (long)cp.bw * 8 * cp.bh * 8 - 1;
-		s[k] = upsample_at(P, cp.hs, cp.vs, cp.y, im.width, r, col);
+	const WorkIdct wk = work[blockIdx.x];
+	const DevImage &im = imgs[wk.img];
+	const int W = im.width, n = im.n_out;
+	const int r0 = (int)wk.first, r1 = min(r0 + MIJ_RESAMPLE_ROWS, im.height);
+	const int spr = (W + 3) >> 2; /* strips per row */
+	const int need = comps_needed(im.color, n, im.ncomp);
+	CompView C[4];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		const DevComp &cp = im.comp[k < need ? k : 0];
+		C[k].p = planes + cp.plane_off;
+		C[k].w2 = cp.bw * 8;
+		C[k].limit = cp.bw * 8 * cp.bh * 8 - 1;
+		C[k].hs = cp.hs;
+		C[k].vs = cp.vs;
+		C[k].y = cp.y;
 	}
-	uint8_t *out = outbase + im.out_off + ((size_t)r * im.width + col) * im.n_out;
-	store_pixel(out, im.n_out, im.color, s);
+	uint8_t *const out = outbase + im.out_off;
+	for (int r = r0; r < r1; ++r)
+	for (int t = threadIdx.x; t < spr; t += 256) {
+		const int x0 = 4 * t, cnt = min(4, W - x0);
+		int smp[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}; /* [component][pixel] */
+#pragma unroll
+		for (int k = 0; k < 4; ++k) /* unrolled with static indices: a run-time bound would put C[] and smp[] in scratch */
+			if (k < need)
+				upsample_strip(C[k], W, r, x0, smp[k]);
+		uint8_t px[4][4];
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			const int s[4] = {smp[0][j], smp[1][j], smp[2][j], smp[3][j]};
+			store_pixel(px[j], n, im.color, s);
+		}
+		const size_t off = ((size_t)r * W + x0) * n;
+		uint8_t *dst = out + off;
+		if (cnt == 4 && ((im.out_off + off) & 3) == 0) {
+			uint32_t *q = reinterpret_cast<uint32_t *>(dst);
+			if (n == 4) {
+				for (int j = 0; j < 4; ++j)
+					q[j] = px[j][0] | px[j][1] << 8 | px[j][2] << 16 | (uint32_t)px[j][3] << 24;
+			} else if (n == 3) {
+				q[0] = px[0][0] | px[0][1] << 8 | px[0][2] << 16 | (uint32_t)px[1][0] << 24;
+				q[1] = px[1][1] | px[1][2] << 8 | px[2][0] << 16 | (uint32_t)px[2][1] << 24;
+				q[2] = px[2][2] | px[3][0] << 8 | px[3][1] << 16 | (uint32_t)px[3][2] << 24;
+			} else if (n == 2) {
+				q[0] = px[0][0] | px[0][1] << 8 | px[1][0] << 16 | (uint32_t)px[1][1] << 24;
+				q[1] = px[2][0] | px[2][1] << 8 | px[3][0] << 16 | (uint32_t)px[3][1] << 24;
+			} else {
+				q[0] = px[0][0] | px[1][0] << 8 | px[2][0] << 16 | (uint32_t)px[3][0] << 24;
+			}
+		} else {
+			for (int j = 0; j < cnt; ++j)
+				for (int c = 0; c < n; ++c)
+					dst[j * n + c] = px[j][c];
+		}
+	}
 }
 
 /* ------------------------------------------------------------------ fused h2v2 YCbCr kernel
@@ -549,7 +612,7 @@ __device__ __forceinline__ void store_rgb_px(uint8_t *__restrict__ p, int r, int
 }
 
 /* careful per-pixel path for the image's left/right edge strips and unaligned widths:
- * the same closed form as upsample_at(hs=2,vs=2) with the chroma rows already resolved */
+ * the same closed form as upsample_strip's hv_2 case with the chroma rows already resolved */
 template <int NOUT>
 __device__ __forceinline__ void fused420_pixel(const uint8_t *yrow, const uint8_t *cbA, const uint8_t *cbB, const uint8_t *crA, const uint8_t *crB, int nearIsB,
 															  int wc, int x, uint8_t *__restrict__ dst)

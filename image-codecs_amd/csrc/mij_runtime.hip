@@ -510,7 +510,7 @@ extern "C" int mij_batch_upload(mij_batch *b)
 
 	/* ---- plan: group fused images by (n_out, wide); everything else goes two-pass */
 	std::vector<WorkBand> bands[4];
-	std::vector<WorkIdct> idct[6]; /* 0,1: two-pass (narrow, wide); 2..5: fused 4:4:4 (n_out 3/4 x narrow/wide) */
+	std::vector<WorkIdct> idct[7]; /* 0,1: two-pass (narrow, wide); 2..5: fused 4:4:4 (n_out 3/4 x narrow/wide); 6: two-pass pass 2 (row groups) */
 	size_t band_lds[4] = {0, 0, 0, 0};
 	b->twopass_slots.clear();
 	size_t planes_need = 0, planes_off = 0;
@@ -591,6 +591,14 @@ extern "C" int mij_batch_upload(mij_batch *b)
 		} else {
 			s.path = 2;
 			b->twopass_slots.push_back((int)i);
+			for (uint32_t r = 0; r < (uint32_t)d.height; r += MIJ_RESAMPLE_ROWS) {
+				WorkIdct w;
+				w.img = (uint32_t)i;
+				w.comp = 0;
+				w.first = r;
+				w.pad = 0;
+				idct[6].push_back(w);
+			}
 			for (int c = 0; c < d.ncomp; ++c) {
 				const uint32_t nblk = (uint32_t)(d.comp[c].bw * d.comp[c].bh);
 				for (uint32_t f = 0; f < nblk; f += 256) {
@@ -630,7 +638,7 @@ extern "C" int mij_batch_upload(mij_batch *b)
 	size_t nb_total = 0, ni_total = 0;
 	for (int g = 0; g < 4; ++g)
 		nb_total += bands[g].size();
-	for (int g = 0; g < 6; ++g)
+	for (int g = 0; g < 7; ++g)
 		ni_total += idct[g].size();
 	int rc;
 	if ((nb_total > b->bands_cap || ni_total > b->idct_cap))
@@ -660,12 +668,12 @@ extern "C" int mij_batch_upload(mij_batch *b)
 		pos += bands[g].size();
 	}
 	pos = 0;
-	for (int g = 0; g < 6; ++g) {
+	for (int g = 0; g < 7; ++g) {
 		if (idct[g].empty())
 			continue;
 		memcpy(b->h_idct + pos, idct[g].data(), idct[g].size() * sizeof(WorkIdct));
 		mij_batch::IdctLaunch L;
-		L.kind = g >= 2 ? 1 : 0;
+		L.kind = g == 6 ? 2 : (g >= 2 ? 1 : 0);
 		L.nout = (g >= 4) ? 4 : 3;
 		L.wide = g & 1;
 		L.first = pos;
@@ -734,7 +742,9 @@ extern "C" int mij_batch_launch(mij_batch *b)
 	for (const auto &L : b->idct_launches) {
 		const dim3 grid((unsigned)L.count), block(256);
 		const WorkIdct *wk = b->d_idct + L.first;
-		if (L.kind == 1) {
+		if (L.kind == 2) /* pass 2 of the two-pass family: after every k_idct_planes launch (stream order) */
+			hipLaunchKernelGGL(k_resample_color, grid, block, 0, b->stream, b->d_imgs, wk, b->d_planes, b->d_out);
+		else if (L.kind == 1) {
 			if (L.nout == 3 && !L.wide)
 				hipLaunchKernelGGL((k_fused444<3, false>), grid, block, 0, b->stream, b->d_imgs, wk, b->d_coef, b->d_out);
 			else if (L.nout == 3)
@@ -747,12 +757,6 @@ extern "C" int mij_batch_launch(mij_batch *b)
 			hipLaunchKernelGGL((k_idct_planes<true>), grid, block, 0, b->stream, b->d_imgs, wk, b->d_coef, b->d_planes);
 		else
 			hipLaunchKernelGGL((k_idct_planes<false>), grid, block, 0, b->stream, b->d_imgs, wk, b->d_coef, b->d_planes);
-		HIP_TRY(hipGetLastError());
-	}
-	for (int slot : b->twopass_slots) {
-		const mij_image_desc &d = b->slots[(size_t)slot].desc;
-		const dim3 grid((unsigned)((d.width + 255) / 256), (unsigned)d.height), block(256);
-		hipLaunchKernelGGL(k_resample_color, grid, block, 0, b->stream, b->d_imgs, (uint32_t)slot, b->d_planes, b->d_out);
 		HIP_TRY(hipGetLastError());
 	}
 	b->launched = true;
