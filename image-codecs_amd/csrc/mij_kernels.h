@@ -947,6 +947,153 @@ __global__ __launch_bounds__(256) void k_fused420(const DevImage *__restrict__ i
 	}
 }
 
+/* ------------------------------------------------------------------ fused h2v1 (4:2:2) YCbCr kernel
+ *
+ * MCU = 16x8 pixels: two luma blocks side by side, one Cb, one Cr block.  Chroma is only stretched
+ * horizontally (resample_row_h_2, codec/jpeg.c:1784-1812), so there is no vertical neighbourhood: no halo,
+ * no saved rows, any range of MCU rows is an independent band.  Same two phases as k_fused420 on a smaller
+ * LDS footprint (Y[8][16*mcu_x], Cb/Cr[8][8*mcu_x] = 256*mcu_x bytes).
+ * h_2 in one v_dot4_u32_u8 per sample: (3c[i] + c[i+-1] + 2) >> 2 == (64*(3c[i] + c[i+-1]) + 128) >> 8 on the
+ * byte window (c[i0-1], c[i0], c[i0+1], c[i0+2]) of a 4-pixel strip; the first / last columns are the same form
+ * with the neighbour clamped, and the reference's last-but-one column (:1805: 3*in[w-2] + in[w-1]) is the
+ * odd-pixel weight vector used once more.
+ */
+__device__ __forceinline__ size_t fused422_lds_bytes(int mcu_x) { return (size_t)mcu_x * 256 + 16; } /* + the dword a last strip reads past the last row */
+
+/* careful per-pixel path for widths that are not a multiple of 4 */
+template <int NOUT>
+__device__ __forceinline__ void fused422_pixel(const uint8_t *yrow, const uint8_t *cb, const uint8_t *cr, int wc, int x, uint8_t *__restrict__ dst)
+{
+	const int i = x >> 1;
+	int vb, vr;
+	if (wc == 1 || x == 0) {
+		vb = cb[0];
+		vr = cr[0];
+	} else if (x == 2 * wc - 1) {
+		vb = cb[wc - 1];
+		vr = cr[wc - 1];
+	} else if (x == 2 * wc - 2) {
+		vb = (3 * cb[wc - 2] + cb[wc - 1] + 2) >> 2;
+		vr = (3 * cr[wc - 2] + cr[wc - 1] + 2) >> 2;
+	} else {
+		const int j = (x & 1) ? i + 1 : i - 1;
+		vb = (3 * cb[i] + cb[j] + 2) >> 2;
+		vr = (3 * cr[i] + cr[j] + 2) >> 2;
+	}
+	int r, g, b;
+	ycbcr_to_rgb(yrow[x], vb, vr, r, g, b);
+	store_rgb_px<NOUT>(dst + (size_t)x * NOUT, r, g, b);
+}
+
+template <int NOUT, bool WIDE>
+__global__ __launch_bounds__(256) void k_fused422(const DevImage *__restrict__ imgs, const WorkBand *__restrict__ work, const uint8_t *__restrict__ coef,
+																  uint8_t *__restrict__ outbase)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	const WorkBand wk = work[blockIdx.x];
+	const DevImage &im = imgs[wk.img];
+	const int tid = threadIdx.x;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+	const int mcu_x = im.mcu_x, W = im.width, H = im.height;
+	const int YP = 16 * mcu_x, CP = 8 * mcu_x;
+	const int wc = (W + 1) >> 1;
+	uint8_t *const sY = lds;
+	uint8_t *const sCb = sY + 8 * YP;
+	uint8_t *const sCr = sCb + 8 * CP;
+	const uint8_t *const coefY = coef + im.comp[0].coef_off;
+	const uint8_t *const coefCb = coef + im.comp[1].coef_off;
+	const uint8_t *const coefCr = coef + im.comp[2].coef_off;
+	uint8_t *const out = outbase + im.out_off;
+	const uint32_t opitch = (uint32_t)W * NOUT;
+	const int bwY = 2 * mcu_x, bwC = mcu_x;
+	const int nYw = (bwY + 63) >> 6, nCw = (bwC + 63) >> 6;
+	const int nstrip = (W + 3) >> 2;
+	const bool aligned = ((NOUT == 4) || ((W & 3) == 0)) && ((uint64_t)opitch * (uint32_t)H < 0xfffffff0ull);
+	const int nfast = aligned ? (W >> 2) : 0;
+
+	IdctK KI;
+	KI.init();
+	ColorK KC;
+	KC.init();
+	const uint32_t wE0 = vreg(0x0000c040u); /* pixel x0   : 64*c[i0-1] + 192*c[i0]   */
+	const uint32_t wO0 = vreg(0x0040c000u); /* pixel x0+1 : 192*c[i0]  + 64*c[i0+1]  */
+	const uint32_t wE1 = vreg(0x00c04000u); /* pixel x0+2 : 64*c[i0]   + 192*c[i0+1] */
+	const uint32_t wO1 = vreg(0x40c00000u); /* pixel x0+3 : 192*c[i0+1] + 64*c[i0+2] */
+
+	for (int m = (int)wk.m0; m < (int)wk.m1; ++m) {
+		__syncthreads(); /* previous phase B done with the planes */
+		/* ---- phase A: IDCT of MCU row m, one block per lane, component uniform per wave */
+		for (int ww = wave; ww < nYw + 2 * nCw; ww += 4) {
+			uint4 c[8];
+			uint2 rows[8];
+			if (ww < nYw) {
+				const int bx = ww * 64 + lane;
+				if (bx < bwY) {
+					load_block(coefY, (uint32_t)(m * bwY + bx), c);
+					idct_block<WIDE>(KI, c, im.dq[0], rows);
+					uint8_t *dst = sY + 8 * bx;
+#pragma unroll
+					for (int r = 0; r < 8; ++r)
+						*reinterpret_cast<uint2 *>(dst + r * YP) = rows[r];
+				}
+			} else {
+				const int comp = (ww - nYw) < nCw ? 1 : 2;
+				const int bx = ((ww - nYw) - (comp == 2 ? nCw : 0)) * 64 + lane;
+				if (bx < bwC) {
+					load_block(comp == 1 ? coefCb : coefCr, (uint32_t)(m * bwC + bx), c);
+					idct_block<WIDE>(KI, c, im.dq[comp], rows);
+					uint8_t *dst = (comp == 1 ? sCb : sCr) + 8 * bx;
+#pragma unroll
+					for (int r = 0; r < 8; ++r)
+						*reinterpret_cast<uint2 *>(dst + r * CP) = rows[r];
+				}
+			}
+		}
+		__syncthreads();
+
+		/* ---- phase B: the 8 pixel rows of the MCU row, 4-pixel strips */
+		const int rows_here = min(8, H - 8 * m);
+		for (int rr = 0; rr < rows_here; ++rr) {
+			const uint8_t *cbR = sCb + rr * CP, *crR = sCr + rr * CP, *yR = sY + rr * YP;
+			const uint32_t rowoff = (uint32_t)(8 * m + rr) * opitch;
+			for (int s0 = tid; s0 < nfast; s0 += 256) {
+				const int i0 = 2 * s0;
+				const int d0 = (i0 - 1) >> 2; /* strip 0 reads the dword in front of the row (inside LDS); the edge fix discards it */
+				const uint32_t *pb = reinterpret_cast<const uint32_t *>(cbR) + d0, *pr = reinterpret_cast<const uint32_t *>(crR) + d0;
+				const uint32_t b0 = pb[0], b1 = pb[1], r0 = pr[0], r1 = pr[1];
+				const uint32_t yv = *reinterpret_cast<const uint32_t *>(yR + 4 * s0);
+				const uint32_t sh = (uint32_t)(i0 - 1) & 3u;
+				uint32_t vb = __builtin_amdgcn_alignbyte(b1, b0, sh), vr = __builtin_amdgcn_alignbyte(r1, r0, sh);
+				uint32_t w2 = wE1;
+				if (i0 == 0 || i0 + 2 > wc - 1) {
+					uint32_t sel = 0x03020100u;
+					if (i0 == 0)
+						sel = (sel & 0xffffff00u) | 0x01u; /* column -1 -> 0 */
+					if (i0 + 2 > wc - 1) {
+						sel = (sel & 0x00ffffffu) | 0x02000000u; /* column wc -> wc-1 */
+						if (wc > 1)
+							w2 = wO0; /* pixel 2*(wc-1): 3*c[wc-2] + c[wc-1], codec/jpeg.c:1805 */
+					}
+					vb = __builtin_amdgcn_perm(0, vb, sel);
+					vr = __builtin_amdgcn_perm(0, vr, sel);
+				}
+				const uint32_t cb0 = dot4(vb, wE0, KC.w128), cb1 = dot4(vb, wO0, KC.w128), cb2 = dot4(vb, w2, KC.w128), cb3 = dot4(vb, wO1, KC.w128);
+				const uint32_t cr0 = dot4(vr, wE0, KC.w128), cr1 = dot4(vr, wO0, KC.w128), cr2 = dot4(vr, w2, KC.w128), cr3 = dot4(vr, wO1, KC.w128);
+				const Rgb12 p0 = color_px(KC, __builtin_amdgcn_perm(cr0, yv, KC.p0), __builtin_amdgcn_perm(cb0, yv, KC.p0));
+				const Rgb12 p1 = color_px(KC, __builtin_amdgcn_perm(cr1, yv, KC.p1), __builtin_amdgcn_perm(cb1, yv, KC.p1));
+				const Rgb12 p2 = color_px(KC, __builtin_amdgcn_perm(cr2, yv, KC.p2), __builtin_amdgcn_perm(cb2, yv, KC.p2));
+				const Rgb12 p3 = color_px(KC, __builtin_amdgcn_perm(cr3, yv, KC.p3), __builtin_amdgcn_perm(cb3, yv, KC.p3));
+				store_px4<NOUT>(out + (rowoff + (uint32_t)(4 * s0) * NOUT), p0, p1, p2, p3);
+			}
+			for (int s0 = nfast + tid; s0 < nstrip; s0 += 256) {
+				const int x0 = 4 * s0, xe = min(x0 + 4, W);
+				for (int x = x0; x < xe; ++x)
+					fused422_pixel<NOUT>(yR, cbR, crR, wc, x, out + (size_t)(8 * m + rr) * opitch);
+			}
+		}
+	}
+}
+
 /* ------------------------------------------------------------------ fused 1x1 (4:4:4) YCbCr kernel
  *
  * No sub-sampling means no neighbourhood: one lane owns one 8x8 MCU -- three blocks, one per

@@ -92,6 +92,10 @@ extern "C" int mij_ctx_create(int device, mij_ctx **out)
 	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused420<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
 	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused420<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
 	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_encode420), hipFuncAttributeMaxDynamicSharedMemorySize, MIJ_ENC_LDS);
+	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused422<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused422<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused422<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused422<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
 	(void)hipGetLastError();
 	*out = c;
 	return MIJ_OK;
@@ -155,10 +159,10 @@ struct mij_batch {
 	};
 	std::vector<BandLaunch> band_launches;
 	struct IdctLaunch {
-		int kind; /* 0 two-pass pass 1, 1 fused 4:4:4 */
+		int kind; /* 0 two-pass pass 1, 1 fused 4:4:4, 2 two-pass pass 2, 3 fused 4:2:2 */
 		int nout;
 		int wide;
-		size_t first, count;
+		size_t first, count, lds;
 	};
 	std::vector<IdctLaunch> idct_launches;
 	std::vector<int> twopass_slots;
@@ -467,6 +471,21 @@ static bool fused420_ok(const mij_batch *b, const mij_image_desc &d)
 	return lds <= (size_t)b->ctx->max_dyn_lds;
 }
 
+/* can the fused h2v1 kernel take this image? */
+static bool fused422_ok(const mij_batch *b, const mij_image_desc &d)
+{
+	if (b->force_generic || (d.flags & MIJ_FLAG_SKIP))
+		return false;
+	if (d.ncomp != 3 || d.color != MIJ_COLOR_YCBCR || (d.n_out != 3 && d.n_out != 4))
+		return false;
+	if (d.comp[0].h != 2 || d.comp[0].v != 1)
+		return false;
+	for (int c = 1; c < 3; ++c)
+		if (d.comp[c].h != 1 || d.comp[c].v != 1)
+			return false;
+	return (size_t)d.mcu_x * 256 + 16 <= (size_t)b->ctx->max_dyn_lds;
+}
+
 /* can the register-resident 4:4:4 kernel take this image? */
 static bool fused444_ok(const mij_batch *b, const mij_image_desc &d)
 {
@@ -510,7 +529,9 @@ extern "C" int mij_batch_upload(mij_batch *b)
 
 	/* ---- plan: group fused images by (n_out, wide); everything else goes two-pass */
 	std::vector<WorkBand> bands[4];
-	std::vector<WorkIdct> idct[7]; /* 0,1: two-pass (narrow, wide); 2..5: fused 4:4:4 (n_out 3/4 x narrow/wide); 6: two-pass pass 2 (row groups) */
+	std::vector<WorkIdct> idct[11]; /* 0,1: two-pass (narrow, wide); 2..5: fused 4:4:4 (n_out 3/4 x narrow/wide); 6: two-pass pass 2 (row groups);
+	                                  7..10: fused 4:2:2 bands (n_out 3/4 x narrow/wide; comp = first MCU row, first = end MCU row) */
+	size_t lds422[4] = {0, 0, 0, 0};
 	size_t band_lds[4] = {0, 0, 0, 0};
 	b->twopass_slots.clear();
 	size_t planes_need = 0, planes_off = 0;
@@ -576,6 +597,22 @@ extern "C" int mij_batch_upload(mij_batch *b)
 			size_t lds = (size_t)d.mcu_x * (16 * 16 + 2 * 8 * 8 + 2 * 16 + 4 * 8);
 			if (lds > band_lds[g])
 				band_lds[g] = lds;
+		} else if (fused422_ok(b, d)) {
+			s.path = 4;
+			const int g = (d.n_out == 4 ? 2 : 0) + wide;
+			const size_t lds = (size_t)d.mcu_x * 256 + 16;
+			if (lds > lds422[g])
+				lds422[g] = lds;
+			/* no halo: bands of about eight MCU rows keep the grid deep without making workgroups short */
+			const int nb = (d.mcu_y + 7) / 8;
+			for (int k = 0; k < nb; ++k) {
+				WorkIdct w;
+				w.img = (uint32_t)i;
+				w.comp = (uint32_t)((long)d.mcu_y * k / nb);
+				w.first = (uint32_t)((long)d.mcu_y * (k + 1) / nb);
+				w.pad = 0;
+				idct[7 + g].push_back(w);
+			}
 		} else if (fused444_ok(b, d)) {
 			s.path = 3;
 			const int g = 2 + (d.n_out == 4 ? 2 : 0) + wide;
@@ -638,7 +675,7 @@ extern "C" int mij_batch_upload(mij_batch *b)
 	size_t nb_total = 0, ni_total = 0;
 	for (int g = 0; g < 4; ++g)
 		nb_total += bands[g].size();
-	for (int g = 0; g < 7; ++g)
+	for (int g = 0; g < 11; ++g)
 		ni_total += idct[g].size();
 	int rc;
 	if ((nb_total > b->bands_cap || ni_total > b->idct_cap))
@@ -668,14 +705,15 @@ extern "C" int mij_batch_upload(mij_batch *b)
 		pos += bands[g].size();
 	}
 	pos = 0;
-	for (int g = 0; g < 7; ++g) {
+	for (int g = 0; g < 11; ++g) {
 		if (idct[g].empty())
 			continue;
 		memcpy(b->h_idct + pos, idct[g].data(), idct[g].size() * sizeof(WorkIdct));
 		mij_batch::IdctLaunch L;
-		L.kind = g == 6 ? 2 : (g >= 2 ? 1 : 0);
-		L.nout = (g >= 4) ? 4 : 3;
-		L.wide = g & 1;
+		L.kind = g >= 7 ? 3 : (g == 6 ? 2 : (g >= 2 ? 1 : 0));
+		L.nout = g >= 7 ? ((g - 7) & 2 ? 4 : 3) : ((g >= 4) ? 4 : 3);
+		L.lds = g >= 7 ? lds422[g - 7] : 0;
+		L.wide = g >= 7 ? ((g - 7) & 1) : (g & 1);
 		L.first = pos;
 		L.count = idct[g].size();
 		b->idct_launches.push_back(L);
@@ -742,7 +780,17 @@ extern "C" int mij_batch_launch(mij_batch *b)
 	for (const auto &L : b->idct_launches) {
 		const dim3 grid((unsigned)L.count), block(256);
 		const WorkIdct *wk = b->d_idct + L.first;
-		if (L.kind == 2) /* pass 2 of the two-pass family: after every k_idct_planes launch (stream order) */
+		if (L.kind == 3) {
+			const WorkBand *wb = reinterpret_cast<const WorkBand *>(wk); /* same four-u32 layout */
+			if (L.nout == 3 && !L.wide)
+				hipLaunchKernelGGL((k_fused422<3, false>), grid, block, L.lds, b->stream, b->d_imgs, wb, b->d_coef, b->d_out);
+			else if (L.nout == 3)
+				hipLaunchKernelGGL((k_fused422<3, true>), grid, block, L.lds, b->stream, b->d_imgs, wb, b->d_coef, b->d_out);
+			else if (!L.wide)
+				hipLaunchKernelGGL((k_fused422<4, false>), grid, block, L.lds, b->stream, b->d_imgs, wb, b->d_coef, b->d_out);
+			else
+				hipLaunchKernelGGL((k_fused422<4, true>), grid, block, L.lds, b->stream, b->d_imgs, wb, b->d_coef, b->d_out);
+		} else if (L.kind == 2) /* pass 2 of the two-pass family: after every k_idct_planes launch (stream order) */
 			hipLaunchKernelGGL(k_resample_color, grid, block, 0, b->stream, b->d_imgs, wk, b->d_planes, b->d_out);
 		else if (L.kind == 1) {
 			if (L.nout == 3 && !L.wide)

@@ -260,3 +260,33 @@ def progressive_from_du(plan, du, script=1):
     n = L.pw_write_progressive(ptrs, 3, plan.width, plan.height, hs, vs, qt.ctypes.data_as(C.c_void_p), int(script), out.ctypes.data_as(C.c_void_p), cap)
     assert 0 < n <= cap, n
     return out[:n].tobytes()
+
+
+def progressive_422_from_444(plan, du, script=1):
+    """A 4:2:2 (h2v1) progressive stream from the 4:4:4 data units of the same picture size: full luma,
+    every other chroma block column.  The chroma content is not a faithful down-sampling -- only a valid
+    stream of that layout is needed (no libjpeg on the GPU box); parity is always against the oracle's
+    decode of the same bytes."""
+    assert plan.du_per_mcu == 3
+    L = C.CDLL(build_prog_writer())
+    L.pw_write_progressive.restype = C.c_long
+    L.pw_write_progressive.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, P_INT, P_INT, C.c_void_p, C.c_int, C.c_void_p, C.c_long]
+    planes444, _ = du_to_planes(plan, du)
+    mcu_x, mcu_y = (plan.width + 15) // 16, (plan.height + 7) // 8
+    y = np.zeros((mcu_y, 2 * mcu_x, 64), np.int16)
+    y[:, :planes444[0].shape[1]] = planes444[0]
+    planes = [y]
+    for c in (1, 2):
+        sub = planes444[c][:, 0::2]
+        p = np.zeros((mcu_y, mcu_x, 64), np.int16)
+        p[:, :sub.shape[1]] = sub
+        planes.append(p)
+    ptrs = (C.c_void_p * 3)(*[p.ctypes.data for p in planes])
+    hs = (C.c_int * 3)(2, 1, 1)
+    vs = (C.c_int * 3)(1, 1, 1)
+    qt = np.concatenate([np.frombuffer(bytes(plan.ytab), np.uint8), np.frombuffer(bytes(plan.ctab), np.uint8)])
+    cap = 1024 + sum(p.size for p in planes) * 3
+    out = np.empty(cap, np.uint8)
+    n = L.pw_write_progressive(ptrs, 3, plan.width, plan.height, hs, vs, qt.ctypes.data_as(C.c_void_p), int(script), out.ctypes.data_as(C.c_void_p), cap)
+    assert 0 < n <= cap, n
+    return out[:n].tobytes()

@@ -321,3 +321,26 @@ def test_progressive_420_full_hd_takes_the_fused_kernel(ica, oracle, gpu_ctx):
         assert b.slot_path(slots[0]) == 1
         assert np.array_equal(b.fetch(slots[0]), oracle.load(prog, req)[1]), req
         b.close()
+
+
+def test_fused_422_kernel_vs_oracle_and_two_pass(ica, oracle, gpu_ctx, golden):
+    """h2v1 streams (libjpeg-made fixtures and seeded ones re-emitted by the test-side writer) through the
+    fused 4:2:2 kernel and through the two-pass family: both equal to the oracle, including the
+    reference's last-but-one-column form (codec/jpeg.c:1805), odd widths and one-MCU images."""
+    for name in ("big_b422_320x240",):
+        assert np.array_equal(ica.stbi_load_from_memory(golden.jpg(name), 3)[0], golden.expect(name, 3)[1]), name
+    datas = []
+    for i, (w, h) in enumerate(((16, 8), (17, 9), (1, 1), (2, 2), (4, 4), (33, 7), (64, 64), (250, 131), (640, 480), (1920, 1080), (36, 20), (18, 40))):
+        plan, du = ica.host_transform(ica.synth_rgb(w, h, 20 + i), 95)
+        datas.append(helpers.progressive_422_from_444(plan, du, i & 1))
+    for req in (3, 4):
+        wants = [oracle.load(d, req)[1] for d in datas]
+        for generic in (False, True):
+            b, slots = _batch_for(ica, gpu_ctx, datas, req)
+            b.force_generic(generic)
+            b.submit()
+            for s, want in zip(slots, wants):
+                assert b.slot_path(s) == (2 if generic else 4)
+                got = b.fetch(s)
+                assert np.array_equal(got, want), (s, req, generic, want.shape, int((got != want).sum()))
+            b.close()
