@@ -456,6 +456,82 @@ __global__ __launch_bounds__(256) void k_idct_planes(const DevImage *__restrict_
 
 /* ------------------------------------------------------------------ two-pass path, pass 2 */
 
+/* ------------------------------------------------------------------ fused single-component (grey) kernel
+ * One block per lane: IDCT, then the 8x8 samples go straight to the pixel buffer, replicated to n_out
+ * channels (codec/jpeg.c:2373-2378, :2380-2430: grey -> y | y,255 | y,y,y | y,y,y,255).  No sample plane. */
+template <bool WIDE>
+__global__ __launch_bounds__(256) void k_fused_grey(const DevImage *__restrict__ imgs, const WorkIdct *__restrict__ work, const uint8_t *__restrict__ coef,
+																	 uint8_t *__restrict__ outbase)
+{
+	const WorkIdct wk = work[blockIdx.x];
+	const DevImage &im = imgs[wk.img];
+	const DevComp &cp = im.comp[0];
+	const uint32_t nblk = (uint32_t)(cp.bw * cp.bh);
+	const uint32_t L = wk.first + threadIdx.x;
+	if (L >= nblk)
+		return;
+	IdctK K;
+	K.init();
+	uint4 c[8];
+	load_block(coef + cp.coef_off, L, c);
+	uint2 rows[8];
+	idct_block<WIDE>(K, c, im.dq[0], rows);
+	const int by = (int)(L / (uint32_t)cp.bw), bx = (int)(L - (uint32_t)by * (uint32_t)cp.bw);
+	const int W = im.width, H = im.height, n = im.n_out;
+	const int x0 = 8 * bx, y0 = 8 * by;
+	if (x0 >= W || y0 >= H)
+		return;
+	uint8_t *const out = outbase + im.out_off;
+	const bool whole = x0 + 8 <= W && ((uint32_t)(W * n) & 3u) == 0; /* dword-aligned rows, all eight columns inside */
+#pragma unroll
+	for (int i = 0; i < 8; ++i) {
+		if (y0 + i >= H)
+			break;
+		const uint32_t lo = rows[i].x, hi = rows[i].y;
+		uint8_t *dst = out + ((size_t)(y0 + i) * W + x0) * n;
+		if (whole) {
+			uint32_t *q = reinterpret_cast<uint32_t *>(dst);
+			if (n == 1) {
+				q[0] = lo;
+				q[1] = hi;
+			} else if (n == 2) { /* selector 0x0d..: constant 0xff */
+				q[0] = __builtin_amdgcn_perm(0, lo, 0x0d010d00u);
+				q[1] = __builtin_amdgcn_perm(0, lo, 0x0d030d02u);
+				q[2] = __builtin_amdgcn_perm(0, hi, 0x0d010d00u);
+				q[3] = __builtin_amdgcn_perm(0, hi, 0x0d030d02u);
+			} else if (n == 3) {
+				q[0] = __builtin_amdgcn_perm(0, lo, 0x01000000u);
+				q[1] = __builtin_amdgcn_perm(0, lo, 0x02020101u);
+				q[2] = __builtin_amdgcn_perm(0, lo, 0x03030302u);
+				q[3] = __builtin_amdgcn_perm(0, hi, 0x01000000u);
+				q[4] = __builtin_amdgcn_perm(0, hi, 0x02020101u);
+				q[5] = __builtin_amdgcn_perm(0, hi, 0x03030302u);
+			} else {
+				q[0] = __builtin_amdgcn_perm(0, lo, 0x0d000000u);
+				q[1] = __builtin_amdgcn_perm(0, lo, 0x0d010101u);
+				q[2] = __builtin_amdgcn_perm(0, lo, 0x0d020202u);
+				q[3] = __builtin_amdgcn_perm(0, lo, 0x0d030303u);
+				q[4] = __builtin_amdgcn_perm(0, hi, 0x0d000000u);
+				q[5] = __builtin_amdgcn_perm(0, hi, 0x0d010101u);
+				q[6] = __builtin_amdgcn_perm(0, hi, 0x0d020202u);
+				q[7] = __builtin_amdgcn_perm(0, hi, 0x0d030303u);
+			}
+		} else {
+			const int cnt = min(8, W - x0);
+			for (int j = 0; j < cnt; ++j) {
+				const uint8_t v = (uint8_t)((j < 4 ? lo >> (8 * j) : hi >> (8 * (j - 4))) & 255u);
+				dst[j * n] = v;
+				if (n >= 3) {
+					dst[j * n + 1] = v;
+					dst[j * n + 2] = v;
+				}
+				if (n == 2 || n == 4)
+					dst[j * n + n - 1] = 255;
+			}
+		}
+	}
+}
+
 /* Four up-sampled samples of one component: output row r, columns x0 .. x0+3 (x0 % 4 == 0, columns past the
  * image clamp to W-1).  Follows resample_row_1 / _v_2 / _h_2 / _hv_2 / _generic
  * (codec/jpeg.c:1765-1840, 1962-1971); row selection and shared neighbour loads once per strip, 32-bit indices. */

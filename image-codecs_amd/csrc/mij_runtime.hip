@@ -159,7 +159,7 @@ struct mij_batch {
 	};
 	std::vector<BandLaunch> band_launches;
 	struct IdctLaunch {
-		int kind; /* 0 two-pass pass 1, 1 fused 4:4:4, 2 two-pass pass 2, 3 fused 4:2:2 */
+		int kind; /* 0 two-pass pass 1, 1 fused 4:4:4, 2 two-pass pass 2, 3 fused 4:2:2, 4 fused grey */
 		int nout;
 		int wide;
 		size_t first, count, lds;
@@ -471,6 +471,14 @@ static bool fused420_ok(const mij_batch *b, const mij_image_desc &d)
 	return lds <= (size_t)b->ctx->max_dyn_lds;
 }
 
+/* single-component images: IDCT straight into the pixel buffer */
+static bool fused_grey_ok(const mij_batch *b, const mij_image_desc &d)
+{
+	if (b->force_generic || (d.flags & MIJ_FLAG_SKIP))
+		return false;
+	return d.ncomp == 1 && d.color == MIJ_COLOR_GREY && d.n_out >= 1 && d.n_out <= 4 && (uint64_t)d.width * d.height * d.n_out < 0xfffffff0ull;
+}
+
 /* can the fused h2v1 kernel take this image? */
 static bool fused422_ok(const mij_batch *b, const mij_image_desc &d)
 {
@@ -529,8 +537,9 @@ extern "C" int mij_batch_upload(mij_batch *b)
 
 	/* ---- plan: group fused images by (n_out, wide); everything else goes two-pass */
 	std::vector<WorkBand> bands[4];
-	std::vector<WorkIdct> idct[11]; /* 0,1: two-pass (narrow, wide); 2..5: fused 4:4:4 (n_out 3/4 x narrow/wide); 6: two-pass pass 2 (row groups);
-	                                  7..10: fused 4:2:2 bands (n_out 3/4 x narrow/wide; comp = first MCU row, first = end MCU row) */
+	std::vector<WorkIdct> idct[13]; /* 0,1: two-pass (narrow, wide); 2..5: fused 4:4:4 (n_out 3/4 x narrow/wide); 6: two-pass pass 2 (row groups);
+	                                  7..10: fused 4:2:2 bands (n_out 3/4 x narrow/wide; comp = first MCU row, first = end MCU row);
+	                                  11,12: fused grey (narrow, wide) */
 	size_t lds422[4] = {0, 0, 0, 0};
 	size_t band_lds[4] = {0, 0, 0, 0};
 	b->twopass_slots.clear();
@@ -597,6 +606,17 @@ extern "C" int mij_batch_upload(mij_batch *b)
 			size_t lds = (size_t)d.mcu_x * (16 * 16 + 2 * 8 * 8 + 2 * 16 + 4 * 8);
 			if (lds > band_lds[g])
 				band_lds[g] = lds;
+		} else if (fused_grey_ok(b, d)) {
+			s.path = 5;
+			const uint32_t nblk = (uint32_t)(d.comp[0].bw * d.comp[0].bh);
+			for (uint32_t f = 0; f < nblk; f += 256) {
+				WorkIdct w;
+				w.img = (uint32_t)i;
+				w.comp = 0;
+				w.first = f;
+				w.pad = 0;
+				idct[11 + wide].push_back(w);
+			}
 		} else if (fused422_ok(b, d)) {
 			s.path = 4;
 			const int g = (d.n_out == 4 ? 2 : 0) + wide;
@@ -675,7 +695,7 @@ extern "C" int mij_batch_upload(mij_batch *b)
 	size_t nb_total = 0, ni_total = 0;
 	for (int g = 0; g < 4; ++g)
 		nb_total += bands[g].size();
-	for (int g = 0; g < 11; ++g)
+	for (int g = 0; g < 13; ++g)
 		ni_total += idct[g].size();
 	int rc;
 	if ((nb_total > b->bands_cap || ni_total > b->idct_cap))
@@ -705,14 +725,14 @@ extern "C" int mij_batch_upload(mij_batch *b)
 		pos += bands[g].size();
 	}
 	pos = 0;
-	for (int g = 0; g < 11; ++g) {
+	for (int g = 0; g < 13; ++g) {
 		if (idct[g].empty())
 			continue;
 		memcpy(b->h_idct + pos, idct[g].data(), idct[g].size() * sizeof(WorkIdct));
 		mij_batch::IdctLaunch L;
-		L.kind = g >= 7 ? 3 : (g == 6 ? 2 : (g >= 2 ? 1 : 0));
-		L.nout = g >= 7 ? ((g - 7) & 2 ? 4 : 3) : ((g >= 4) ? 4 : 3);
-		L.lds = g >= 7 ? lds422[g - 7] : 0;
+		L.kind = g >= 11 ? 4 : (g >= 7 ? 3 : (g == 6 ? 2 : (g >= 2 ? 1 : 0)));
+		L.nout = (g >= 7 && g < 11) ? ((g - 7) & 2 ? 4 : 3) : ((g >= 4) ? 4 : 3);
+		L.lds = (g >= 7 && g < 11) ? lds422[g - 7] : 0;
 		L.wide = g >= 7 ? ((g - 7) & 1) : (g & 1);
 		L.first = pos;
 		L.count = idct[g].size();
@@ -780,7 +800,12 @@ extern "C" int mij_batch_launch(mij_batch *b)
 	for (const auto &L : b->idct_launches) {
 		const dim3 grid((unsigned)L.count), block(256);
 		const WorkIdct *wk = b->d_idct + L.first;
-		if (L.kind == 3) {
+		if (L.kind == 4) {
+			if (L.wide)
+				hipLaunchKernelGGL((k_fused_grey<true>), grid, block, 0, b->stream, b->d_imgs, wk, b->d_coef, b->d_out);
+			else
+				hipLaunchKernelGGL((k_fused_grey<false>), grid, block, 0, b->stream, b->d_imgs, wk, b->d_coef, b->d_out);
+		} else if (L.kind == 3) {
 			const WorkBand *wb = reinterpret_cast<const WorkBand *>(wk); /* same four-u32 layout */
 			if (L.nout == 3 && !L.wide)
 				hipLaunchKernelGGL((k_fused422<3, false>), grid, block, L.lds, b->stream, b->d_imgs, wb, b->d_coef, b->d_out);

@@ -188,7 +188,7 @@ int mij_batch_timer_elapsed_ms(mij_batch *b, float *ms);
 int mij_batch_hash_out(mij_batch *b, int slot, uint64_t *hash);
 
 /* which kernel family the last upload chose for a slot: 0 none (skipped), 1 fused 4:2:0, 2 generic two-pass,
- * 3 fused 4:4:4, 4 fused 4:2:2 */
+ * 3 fused 4:4:4, 4 fused 4:2:2, 5 fused grey */
 int mij_batch_slot_path(const mij_batch *b, int slot);
 /* force the generic (unfused) path for every image of a batch: parity tests compare both */
 int mij_batch_force_generic(mij_batch *b, int on);

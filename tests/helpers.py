@@ -290,3 +290,21 @@ def progressive_422_from_444(plan, du, script=1):
     n = L.pw_write_progressive(ptrs, 3, plan.width, plan.height, hs, vs, qt.ctypes.data_as(C.c_void_p), int(script), out.ctypes.data_as(C.c_void_p), cap)
     assert 0 < n <= cap, n
     return out[:n].tobytes()
+
+
+def progressive_grey_from_444(plan, du, script=1):
+    """A single-component (grey) progressive stream carrying the luma data units of a 4:4:4 plan."""
+    assert plan.du_per_mcu == 3
+    L = C.CDLL(build_prog_writer())
+    L.pw_write_progressive.restype = C.c_long
+    L.pw_write_progressive.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, P_INT, P_INT, C.c_void_p, C.c_int, C.c_void_p, C.c_long]
+    planes444, _ = du_to_planes(plan, du)
+    y = np.ascontiguousarray(planes444[0])
+    ptrs = (C.c_void_p * 1)(y.ctypes.data)
+    one = (C.c_int * 1)(1)
+    qt = np.concatenate([np.frombuffer(bytes(plan.ytab), np.uint8), np.frombuffer(bytes(plan.ctab), np.uint8)])
+    cap = 1024 + y.size * 3
+    out = np.empty(cap, np.uint8)
+    n = L.pw_write_progressive(ptrs, 1, plan.width, plan.height, one, one, qt.ctypes.data_as(C.c_void_p), int(script), out.ctypes.data_as(C.c_void_p), cap)
+    assert 0 < n <= cap, n
+    return out[:n].tobytes()

@@ -344,3 +344,23 @@ def test_fused_422_kernel_vs_oracle_and_two_pass(ica, oracle, gpu_ctx, golden):
                 got = b.fetch(s)
                 assert np.array_equal(got, want), (s, req, generic, want.shape, int((got != want).sum()))
             b.close()
+
+
+def test_fused_grey_kernel_vs_oracle_and_two_pass(ica, oracle, gpu_ctx, golden):
+    """Single-component streams: IDCT straight into the pixel buffer for every req_comp (y | y,255 | y,y,y |
+    y,y,y,255), aligned and unaligned widths, against the oracle and the two-pass family."""
+    datas = [golden.jpg("grey_33x20")]
+    for i, (w, h) in enumerate(((8, 8), (16, 9), (1, 1), (7, 3), (64, 64), (250, 131), (640, 480), (1920, 1080), (36, 20))):
+        plan, du = ica.host_transform(ica.synth_rgb(w, h, 40 + i), 95)
+        datas.append(helpers.progressive_grey_from_444(plan, du, i & 1))
+    for req in (0, 1, 2, 3, 4):
+        wants = [oracle.load(d, req)[1] for d in datas]
+        for generic in (False, True):
+            b, slots = _batch_for(ica, gpu_ctx, datas, req)
+            b.force_generic(generic)
+            b.submit()
+            for s, want in zip(slots, wants):
+                assert b.slot_path(s) == (2 if generic else 5)
+                got = b.fetch(s)
+                assert np.array_equal(got.reshape(-1), want.reshape(-1)), (s, req, generic, want.shape)
+            b.close()
