@@ -43,6 +43,19 @@ class ImageDesc(C.Structure):
         return sum(self.plane_elems(c) for c in range(self.ncomp))
 
 
+class GpuHuff(C.Structure):
+    """mjg_huff (include/mij.h)."""
+    _fields_ = [("fast", C.c_uint8 * 512), ("size", C.c_uint8 * 256), ("values", C.c_uint8 * 256), ("maxcode", C.c_uint32 * 18),
+                ("delta", C.c_int32 * 18)]
+
+
+class GpuScan(C.Structure):
+    """mjg_scan (include/mij.h): what the GPU entropy stage needs to walk one baseline scan."""
+    _fields_ = [("desc", ImageDesc), ("nblocks", C.c_uint32), ("blocks_per_mcu", C.c_uint32), ("blk_comp", C.c_uint8 * 12),
+                ("blk_dx", C.c_uint8 * 12), ("blk_dy", C.c_uint8 * 12), ("dc_tab", C.c_uint8 * 4), ("ac_tab", C.c_uint8 * 4),
+                ("huff", GpuHuff * 8), ("qz", (C.c_uint16 * 64) * 4)]
+
+
 _lib = None
 
 
@@ -310,6 +323,62 @@ class Batch:
         n = d.coef_elems()
         return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int16)), shape=(n,))
 
+    # ---- GPU entropy stage (experimental)
+    def entropy_reserve(self, stream_bytes):
+        L = lib()
+        L.mij_batch_entropy_reserve.argtypes = [C.c_void_p, C.c_size_t]
+        _check(L.mij_batch_entropy_reserve(self._h, C.c_size_t(stream_bytes)), "mij_batch_entropy_reserve")
+        L.mij_batch_entropy_stage.restype = C.c_void_p
+        L.mij_batch_entropy_stage.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+        cap = C.c_size_t()
+        self._es_base = L.mij_batch_entropy_stage(self._h, C.byref(cap))
+        self._es_cap, self._es_used = cap.value, 0
+
+    def add_jpeg_stream(self, data, req_comp=0):
+        """mjh_extract_scan + mij_batch_add_stream: -> (status, slot).  status 1: the GPU walks this image;
+        2: not a layout the GPU walk takes (nothing added); 0: rejected (reason in .last_reason)."""
+        L = lib()
+        L.mjh_extract_scan.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(GpuScan), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_char_p)]
+        L.mij_batch_add_stream.argtypes = [C.c_void_p, C.POINTER(GpuScan), C.c_void_p, C.c_size_t]
+        scan, n, why = GpuScan(), C.c_size_t(), C.c_char_p()
+        dst = self._es_base + self._es_used
+        st = L.mjh_extract_scan(bytes(data), len(data), int(req_comp), C.byref(scan), C.c_void_p(dst), C.c_size_t(self._es_cap - self._es_used), C.byref(n), C.byref(why))
+        self.last_reason = why.value.decode() if why.value else None
+        if st != 1:
+            return st, -1
+        slot = _check(L.mij_batch_add_stream(self._h, C.byref(scan), C.c_void_p(dst), n), "mij_batch_add_stream")
+        self._es_used += (n.value + 32 + 255) // 256 * 256
+        d = ImageDesc()
+        C.memmove(C.byref(d), C.byref(scan.desc), C.sizeof(ImageDesc))
+        self.descs.append(d)
+        return 1, slot
+
+    def entropy_run(self):
+        """-> list of slots the host walk must redo."""
+        L = lib()
+        n = max(1, len(self.descs))
+        fb = (C.c_int * n)()
+        cnt = C.c_int()
+        L.mij_batch_entropy_run.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]
+        _check(L.mij_batch_entropy_run(self._h, fb, n, C.byref(cnt)), "mij_batch_entropy_run")
+        return list(fb[:cnt.value])
+
+    def entropy_rounds(self):
+        L = lib()
+        L.mij_batch_entropy_rounds.argtypes = [C.c_void_p]
+        return L.mij_batch_entropy_rounds(self._h)
+
+    def fallback_prepare(self, slot):
+        _check(lib().mij_batch_fallback_prepare(self._h, int(slot)), "mij_batch_fallback_prepare")
+
+    def fetch_coef(self, slot):
+        d = self.descs[slot]
+        out = np.empty(d.coef_elems(), dtype=np.int16)
+        L = lib()
+        L.mij_batch_fetch_coef.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        _check(L.mij_batch_fetch_coef(self._h, int(slot), out.ctypes.data_as(C.c_void_p), C.c_size_t(out.size)), "mij_batch_fetch_coef")
+        return out
+
     def add_jpeg(self, data, req_comp=0):
         """Host stage of one image straight into a new slot's pinned staging; returns the slot."""
         d = HostDecoder.probe(data, req_comp)
@@ -401,6 +470,7 @@ class Batch:
         return ms.value
 
     def reset(self):
+        self._es_used = 0
         _check(lib().mij_batch_reset(self._h), "mij_batch_reset")
         self.descs = []
 

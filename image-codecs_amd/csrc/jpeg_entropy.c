@@ -1271,3 +1271,113 @@ done:
 		*reason = why;
 	return ok;
 }
+
+/* ------------------------------------------------------------------ scan extraction for the GPU entropy stage
+ *
+ * Header parsing as above; then, if the file is what the GPU walk takes -- one baseline scan carrying all
+ * components interleaved in frame order, no restart interval, the entropy segment followed by EOI -- the
+ * segment is copied out with its 0xFF00 stuffing removed (codec/jpeg.c:171-184) together with the tables.
+ * Everything else returns 2 ("use the host walk"): that path then reproduces the reference's behaviour,
+ * including its failure reasons, so nothing about odd files is decided here.
+ */
+int mjh_extract_scan(const uint8_t *buf, int len, int req_comp, mjg_scan *scan, uint8_t *stream, size_t stream_cap, size_t *stream_len, const char **reason)
+{
+	const char *why = NULL;
+	mjh_reader r;
+	mjh_decoder *d = (mjh_decoder *)calloc(1, sizeof(*d));
+	int rc = 2, ci, k, c;
+	unsigned m;
+	if (reason)
+		*reason = NULL;
+	if (!d) {
+		if (reason)
+			*reason = "outofmem";
+		return 0;
+	}
+	if (!probe_common(d, &r, buf, len, req_comp, &scan->desc, &why)) {
+		if (reason)
+			*reason = why;
+		rc = 0;
+		goto done;
+	}
+	m = get_marker(d);
+	while (m != 0xda) {
+		if (m == 0xd9 || m == 0xdc || m == MARKER_NONE)
+			goto done;
+		if (!process_marker(d, m))
+			goto done;
+		m = get_marker(d);
+	}
+	if (!process_scan_header(d))
+		goto done;
+	if (d->progressive || d->restart_interval != 0 || d->scan_n != d->img_n || (d->img_n != 1 && d->img_n != 3))
+		goto done;
+	for (ci = 0; ci < d->scan_n; ++ci)
+		if (d->order[ci] != ci)
+			goto done;
+	if (d->img_n == 1 && (d->comp[0].h != 1 || d->comp[0].v != 1))
+		goto done; /* a lone component is walked over its own block grid (codec/jpeg.c:1160-1190), not over MCUs */
+	{
+		/* the entropy segment: up to the first 0xff that is not followed by 0x00 */
+		const uint8_t *p = r.p, *end = r.end, *q;
+		size_t n = 0;
+		int bpm = 0;
+		for (q = p;;) {
+			const uint8_t *f = (const uint8_t *)memchr(q, 0xff, (size_t)(end - q));
+			if (!f || f + 1 >= end)
+				goto done; /* no marker behind the data: truncated file, the host walk knows what the reference does */
+			if (f[1] == 0x00) {
+				q = f + 2;
+				continue;
+			}
+			if (f[1] != 0xd9)
+				goto done; /* fill bytes, a restart marker, another scan, ...: host walk */
+			end = f;
+			break;
+		}
+		if ((size_t)(end - p) + 32 > stream_cap)
+			goto done;
+		for (q = p; q < end;) {
+			const uint8_t *f = (const uint8_t *)memchr(q, 0xff, (size_t)(end - q));
+			const size_t run = (size_t)((f ? f + 1 : end) - q);
+			memcpy(stream + n, q, run);
+			n += run;
+			q += run;
+			if (f)
+				++q; /* the stuffed zero */
+		}
+		*stream_len = n;
+		for (ci = 0; ci < d->img_n; ++ci) {
+			int x, y;
+			for (y = 0; y < d->comp[ci].v; ++y)
+				for (x = 0; x < d->comp[ci].h; ++x) {
+					if (bpm >= 10)
+						goto done;
+					scan->blk_comp[bpm] = (uint8_t)ci;
+					scan->blk_dx[bpm] = (uint8_t)x;
+					scan->blk_dy[bpm] = (uint8_t)y;
+					++bpm;
+				}
+			scan->dc_tab[ci] = (uint8_t)d->comp[ci].hd;
+			scan->ac_tab[ci] = (uint8_t)(4 + d->comp[ci].ha);
+			for (k = 0; k < 64; ++k)
+				scan->qz[ci][k] = d->dequant[d->comp[ci].tq][k_dezigzag[k]];
+		}
+		scan->blocks_per_mcu = (uint32_t)bpm;
+		scan->nblocks = (uint32_t)bpm * (uint32_t)d->mcu_x * (uint32_t)d->mcu_y;
+		for (c = 0; c < 8; ++c) {
+			const mjh_huff *h = c < 4 ? &d->huff_dc[c] : &d->huff_ac[c - 4];
+			mjg_huff *g = &scan->huff[c];
+			memcpy(g->fast, h->fast, sizeof(g->fast));
+			memcpy(g->size, h->size, sizeof(g->size));
+			memcpy(g->values, h->values, sizeof(g->values));
+			memcpy(g->maxcode, h->maxcode, sizeof(g->maxcode));
+			memset(g->delta, 0, sizeof(g->delta));
+			memcpy(g->delta, h->delta, sizeof(h->delta));
+		}
+		rc = 1;
+	}
+done:
+	free(d);
+	return rc;
+}

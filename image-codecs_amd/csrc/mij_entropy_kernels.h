@@ -1,0 +1,457 @@
+/*
+ * mij_entropy_kernels.h -- the baseline Huffman walk on the GPU ("self-synchronising
+ * GPU Huffman"), for the one layout that makes up batch work: a single interleaved baseline scan without
+ * restart markers (what the reference's own writer emits, codec/jpeg_write.c:283-352).
+ *
+ * A JPEG entropy segment has no entry points, but Huffman codes re-synchronise: a decoder started at a
+ * wrong bit position falls into step with the true symbol sequence after a few symbols.  The unstuffed
+ * bitstream of an image is cut into subsequences of MIJ_ES_BITS bits, one thread each:
+ *   1. k_es_cold     every thread decodes its subsequence from a guessed state (block start, at its first bit)
+ *                    and records the state it is in when it crosses into the next subsequence
+ *   2. k_es_sync     rounds: thread i restarts from the end state of thread i-1 if that differs from what it
+ *                    started from last time; the true chain from subsequence 0 wins; stops changing after a
+ *                    few rounds because wrong starts re-synchronise inside one subsequence
+ *   3. k_es_offsets  prefix sum of the blocks completed per subsequence -> the block ordinal each one starts at
+ *   4. k_es_write    decode once more, now knowing where every coefficient goes: quantised coefficients into
+ *                    the tile-layout planes (mij.h) the IDCT kernels read, DC differences aside
+ *   5. k_es_dc       per component running sum of the DC differences (codec/jpeg.c:323-325), per-block L1
+ *                    bound (MIJ_FLAG_WIDE_IDCT), completion checks
+ * Symbol decoding is the reference's (codec/jpeg.c:193-265: 9-bit fast table, maxcode/delta slow path,
+ * extend_receive), so a well-formed stream yields exactly the host walk's coefficients.  Anything else --
+ * an invalid code, a run past coefficient 63, a DC category above 11, a stream that ends early, no
+ * convergence -- raises the image's anomaly flag and the caller re-does that image on the host, whose
+ * behaviour on malformed input is the reference's.
+ */
+#ifndef MIJ_ENTROPY_KERNELS_H
+#define MIJ_ENTROPY_KERNELS_H
+
+#include "mij_kernels.h"
+
+namespace mij {
+
+/* Bits per subsequence.  A wrong start has to fall into step not only with the bit position but with the place in
+ * the MCU as well (the luma and chroma tables differ), which takes a few MCUs: 4096 bits hold about six 4:2:0 MCUs
+ * at 1.8 bit/px, so most wrong starts are right again before their subsequence ends. */
+#ifndef MIJ_ES_BITS
+#define MIJ_ES_BITS 4096u
+#endif
+#define MIJ_ES_DEAD 127u  /* z of a state whose decode hit an invalid code */
+
+struct DevHuff { /* stbi__huffman without the code[] array (codec/jpeg.c:21-32) */
+	uint8_t fast[512];
+	uint8_t size[256];
+	uint8_t values[256];
+	uint32_t maxcode[18];
+	int32_t delta[18];
+};
+
+struct DevScan {
+	uint64_t stream_off; /* unstuffed entropy bytes in the stream arena (16 zero bytes follow) */
+	uint32_t nbits;      /* 8 * bytes */
+	uint32_t nsub, sub_off; /* subsequences and where their state slots start */
+	uint32_t img;        /* DevImage index */
+	uint32_t nblocks;    /* blocks the scan must produce: mcu_x * mcu_y * bpm */
+	uint32_t blk_off;    /* where this image's per-block arrays (DC differences, L1) start */
+	uint32_t bpm, mcu_x;
+	uint8_t blk_comp[12], blk_dx[12], blk_dy[12]; /* block-in-MCU -> component and position inside the MCU */
+	uint8_t dc_tab[4], ac_tab[4];                 /* component -> table index (0..3 DC, 4..7 AC) of this scan's eight tables */
+	uint32_t tab_off;    /* first of the eight DevHuff of this scan */
+	uint16_t qz[4][64];  /* quantisation tables, zigzag order, per component (L1 bound only) */
+};
+
+struct EsState {
+	uint32_t p; /* bit position */
+	uint32_t z; /* next coefficient index 0..63, or MIJ_ES_DEAD */
+	uint32_t c; /* block inside the MCU */
+};
+__device__ __forceinline__ uint64_t es_pack(const EsState &s) { return (uint64_t)s.p | ((uint64_t)s.z << 32) | ((uint64_t)s.c << 40); }
+__device__ __forceinline__ EsState es_unpack(uint64_t v)
+{
+	EsState s;
+	s.p = (uint32_t)v;
+	s.z = (uint32_t)(v >> 32) & 255u;
+	s.c = (uint32_t)(v >> 40) & 255u;
+	return s;
+}
+
+/* 57+ valid bits starting at bit position p (big-endian bit order), from aligned dwords */
+__device__ __forceinline__ uint64_t es_window(const uint8_t *__restrict__ stream, uint32_t p)
+{
+	const uint32_t *w = reinterpret_cast<const uint32_t *>(stream) + (p >> 5);
+	const uint32_t d0 = __builtin_bswap32(w[0]), d1 = __builtin_bswap32(w[1]), d2 = __builtin_bswap32(w[2]);
+	const uint32_t sh = p & 31u;
+	const uint64_t hi = ((uint64_t)d0 << 32) | d1;
+	return sh ? (hi << sh) | ((uint64_t)d2 >> (32u - sh)) : hi;
+}
+
+/* codec/jpeg.c:193-243: returns the symbol and its code length, or -1 */
+__device__ __forceinline__ int es_symbol(const DevHuff &h, uint64_t win, uint32_t &len)
+{
+	const uint32_t top16 = (uint32_t)(win >> 48);
+	const uint32_t k = h.fast[top16 >> 7];
+	if (k < 255u) {
+		len = h.size[k];
+		return h.values[k];
+	}
+	uint32_t l = 10;
+	while (l < 17u && top16 >= h.maxcode[l])
+		++l; /* maxcode[17] = 0xffffffff ends the search in a table that was defined */
+	if (l >= 17u)
+		return -1;
+	const int c = (int)((top16 >> (16u - l)) & ((1u << l) - 1u)) + h.delta[l];
+	if (c < 0 || c > 255)
+		return -1;
+	len = l;
+	return h.values[c];
+}
+
+/* codec/jpeg.c:250-265 on the n bits that follow the code */
+__device__ __forceinline__ int es_extend(uint64_t win, uint32_t len, uint32_t n)
+{
+	const uint32_t bits = (uint32_t)((win << len) >> (64u - n));
+	const int neg = !(bits >> (n - 1u));
+	return neg ? (int)bits - (int)((1u << n) - 1u) : (int)bits;
+}
+
+struct EsWriter { /* where the blocks of the write pass go */
+	const DevScan *sc;
+	const DevImage *im;
+	int16_t *coef;       /* coefficient arena (tile layout) */
+	int16_t *dcdiff;     /* per block */
+	uint32_t *l1;        /* per block */
+	const uint16_t *toff; /* zigzag index -> element offset inside the block's tile slot */
+	uint32_t ord;        /* ordinal of the current block */
+	uint32_t mx, my;     /* its MCU */
+	int16_t *blk;        /* its tile slot */
+	uint32_t acc;        /* L1 of the AC coefficients written by this thread into it */
+	__device__ __forceinline__ void locate(uint32_t c)
+	{
+		const uint32_t ci = sc->blk_comp[c];
+		const DevComp &cp = im->comp[ci];
+		const uint32_t bx = mx * (uint32_t)cp.h + sc->blk_dx[c], by = my * (uint32_t)cp.v + sc->blk_dy[c];
+		const uint32_t L = bx + by * (uint32_t)cp.bw;
+		blk = reinterpret_cast<int16_t *>(reinterpret_cast<uint8_t *>(coef) + cp.coef_off) + ((size_t)(L >> 6) << 12) + ((L & 63u) << 3);
+	}
+};
+
+/*
+ * Decode from state s until the bit position reaches p_end (a symbol that starts before p_end is finished).
+ * WRITE = false: only the state and the number of completed blocks.  WRITE = true: coefficients are stored,
+ * decoding stops at block ordinal sc.nblocks, malformed input sets *anom.
+ */
+template <bool WRITE>
+__device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const DevHuff *__restrict__ tabs, const uint8_t *__restrict__ stream, EsState &s, uint32_t p_end,
+															 EsWriter *wr, uint32_t *anom)
+{
+	uint32_t done = 0, guard = 0;
+	const uint32_t limit = sc.nbits + 64u; /* the arena is zero padded: never read far past the data */
+	while (s.p < p_end && s.z != MIJ_ES_DEAD) {
+		if (++guard > MIJ_ES_BITS + 64u) { /* every symbol takes at least one bit: cannot happen, but a wave must always end */
+			s.z = MIJ_ES_DEAD;
+			break;
+		}
+		if (WRITE && wr->ord >= sc.nblocks)
+			break;
+		const uint64_t win = es_window(stream, s.p);
+		const uint32_t ci = sc.blk_comp[s.c];
+		uint32_t len = 0;
+		if (s.z == 0) {
+			const int t = es_symbol(tabs[sc.dc_tab[ci]], win, len);
+			if (t < 0 || t > 11 || len == 0) { /* the reference takes categories up to 16; nothing a conforming stream uses */
+				if (!WRITE) { /* a guessed start ran into a non-code: slip one bit and keep looking for the true sequence */
+					s.p += 1;
+					continue;
+				}
+				atomicOr(anom, 1u);
+				s.z = MIJ_ES_DEAD;
+				break;
+			}
+			const int diff = t ? es_extend(win, len, (uint32_t)t) : 0;
+			if (WRITE)
+				wr->dcdiff[wr->ord] = (int16_t)diff;
+			s.p += len + (uint32_t)t;
+			s.z = 1;
+		} else {
+			const int rs = es_symbol(tabs[sc.ac_tab[ci]], win, len);
+			if (rs < 0 || len == 0) {
+				if (!WRITE) {
+					s.p += 1;
+					continue;
+				}
+				atomicOr(anom, 1u);
+				s.z = MIJ_ES_DEAD;
+				break;
+			}
+			const uint32_t r = (uint32_t)rs >> 4, n = (uint32_t)rs & 15u;
+			if (n == 0) {
+				s.p += len;
+				if (r == 15u)
+					s.z += 16; /* ZRL */
+				else if (r == 0u)
+					s.z = 64; /* EOB */
+				else { /* EOBn only exists in progressive scans; the reference treats it like EOB here (:355) */
+					s.z = 64;
+				}
+			} else {
+				const uint32_t k = s.z + r;
+				if (k > 63u) { /* the reference would write through its padded de-zigzag table: leave that to the host */
+					if (WRITE)
+						atomicOr(anom, 1u);
+					s.p += len + n;
+					s.z = 64;
+				} else {
+					const int v = es_extend(win, len, n);
+					if (WRITE) {
+						wr->blk[wr->toff[k]] = (int16_t)v;
+						const int dq = (int)(int16_t)((uint32_t)v * sc.qz[ci][k]);
+						wr->acc += (uint32_t)(dq < 0 ? -dq : dq);
+					}
+					s.p += len + n;
+					s.z = k + 1;
+				}
+			}
+		}
+		if (s.z >= 64u) { /* block complete (ZRL past the end ends it too: same as the host loop's k < 64 test) */
+			s.z = 0;
+			++done;
+			if (WRITE) {
+				if (s.p > sc.nbits)
+					atomicOr(anom, 16u); /* the data ran out inside this block: the reference decodes on with zero bits */
+				if (wr->acc)
+					atomicAdd(&wr->l1[wr->ord], wr->acc);
+				wr->acc = 0;
+				++wr->ord;
+			}
+			if (++s.c == sc.bpm) {
+				s.c = 0;
+				if (WRITE) {
+					if (++wr->mx == sc.mcu_x) {
+						wr->mx = 0;
+						++wr->my;
+					}
+				}
+			}
+			if (WRITE && wr->ord < sc.nblocks)
+				wr->locate(s.c);
+		}
+		if (s.p > limit) {
+			s.z = MIJ_ES_DEAD;
+			break;
+		}
+	}
+	if (WRITE && wr->acc && wr->ord < sc.nblocks)
+		atomicAdd(&wr->l1[wr->ord], wr->acc);
+	return done;
+}
+
+/* every kernel below: grid.x = blocks of 256 subsequences over a (scan, first subsequence) work list */
+struct EsWork {
+	uint32_t scan, first;
+};
+
+__device__ __forceinline__ void es_load_tables(const DevHuff *__restrict__ g, DevHuff *l)
+{
+	const uint32_t *src = reinterpret_cast<const uint32_t *>(g);
+	uint32_t *dst = reinterpret_cast<uint32_t *>(l);
+	for (uint32_t i = threadIdx.x; i < 8u * sizeof(DevHuff) / 4u; i += blockDim.x)
+		dst[i] = src[i];
+	__syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_es_cold(const DevScan *__restrict__ scans, const EsWork *__restrict__ work, const DevHuff *__restrict__ huff,
+																 const uint8_t *__restrict__ streams, uint64_t *__restrict__ start, uint64_t *__restrict__ end, uint32_t *__restrict__ cnt)
+{
+	__shared__ DevHuff tabs[8];
+	const EsWork wk = work[blockIdx.x];
+	const DevScan &sc = scans[wk.scan];
+	es_load_tables(huff + sc.tab_off, tabs);
+	const uint32_t i = wk.first + threadIdx.x;
+	if (i >= sc.nsub)
+		return;
+	EsState s;
+	s.p = i * MIJ_ES_BITS;
+	s.z = 0;
+	s.c = 0;
+	start[sc.sub_off + i] = es_pack(s);
+	const uint32_t pe = min((i + 1u) * MIJ_ES_BITS, sc.nbits);
+	cnt[sc.sub_off + i] = es_decode<false>(sc, tabs, streams + sc.stream_off, s, pe, nullptr, nullptr);
+	end[sc.sub_off + i] = es_pack(s);
+}
+
+/* one synchronisation round: end_in is the previous round's result, end_out this round's */
+__global__ __launch_bounds__(256) void k_es_sync(const DevScan *__restrict__ scans, const EsWork *__restrict__ work, const DevHuff *__restrict__ huff,
+																 const uint8_t *__restrict__ streams, uint64_t *__restrict__ start, const uint64_t *__restrict__ end_in,
+																 uint64_t *__restrict__ end_out, uint32_t *__restrict__ cnt, uint32_t *__restrict__ changed)
+{
+	__shared__ DevHuff tabs[8];
+	const EsWork wk = work[blockIdx.x];
+	const DevScan &sc = scans[wk.scan];
+	es_load_tables(huff + sc.tab_off, tabs);
+	const uint32_t i = wk.first + threadIdx.x;
+	if (i >= sc.nsub)
+		return;
+	const uint32_t slot = sc.sub_off + i;
+	if (i == 0) {
+		end_out[slot] = end_in[slot];
+		return;
+	}
+	const uint64_t want = end_in[slot - 1];
+	if (want == start[slot]) {
+		end_out[slot] = end_in[slot];
+		return;
+	}
+	start[slot] = want;
+	EsState s = es_unpack(want);
+	const uint32_t pe = min((i + 1u) * MIJ_ES_BITS, sc.nbits);
+	cnt[slot] = es_decode<false>(sc, tabs, streams + sc.stream_off, s, pe, nullptr, nullptr);
+	end_out[slot] = es_pack(s);
+	atomicAdd(&changed[wk.scan], 1u);
+}
+
+/* exclusive prefix sum of cnt over a scan's subsequences (one workgroup per scan), in place */
+__global__ __launch_bounds__(256) void k_es_offsets(const DevScan *__restrict__ scans, uint32_t *__restrict__ cnt, uint32_t *__restrict__ total)
+{
+	__shared__ uint32_t part[256];
+	const DevScan &sc = scans[blockIdx.x];
+	const uint32_t per = (sc.nsub + 255u) / 256u;
+	const uint32_t lo = min(threadIdx.x * per, sc.nsub), hi = min(lo + per, sc.nsub);
+	uint32_t sum = 0;
+	for (uint32_t i = lo; i < hi; ++i)
+		sum += cnt[sc.sub_off + i];
+	part[threadIdx.x] = sum;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t run = 0;
+		for (int t = 0; t < 256; ++t) {
+			const uint32_t v = part[t];
+			part[t] = run;
+			run += v;
+		}
+		total[blockIdx.x] = run;
+	}
+	__syncthreads();
+	uint32_t run = part[threadIdx.x];
+	for (uint32_t i = lo; i < hi; ++i) {
+		const uint32_t v = cnt[sc.sub_off + i];
+		cnt[sc.sub_off + i] = run;
+		run += v;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_es_write(const DevScan *__restrict__ scans, const EsWork *__restrict__ work, const DevHuff *__restrict__ huff,
+																  const uint8_t *__restrict__ streams, const DevImage *__restrict__ imgs, const uint64_t *__restrict__ start,
+																  const uint32_t *__restrict__ base, int16_t *__restrict__ coef, int16_t *__restrict__ dcdiff, uint32_t *__restrict__ l1,
+																  uint32_t *__restrict__ anom)
+{
+	__shared__ DevHuff tabs[8];
+	__shared__ uint16_t toff[64];
+	const EsWork wk = work[blockIdx.x];
+	const DevScan &sc = scans[wk.scan];
+	if (threadIdx.x < 64) {
+		const uint32_t P = mij_zigzag_pos[threadIdx.x];
+		toff[threadIdx.x] = (uint16_t)(((P >> 3) << 9) + (P & 7u));
+	}
+	es_load_tables(huff + sc.tab_off, tabs);
+	const uint32_t i = wk.first + threadIdx.x;
+	if (i >= sc.nsub)
+		return;
+	const uint32_t slot = sc.sub_off + i;
+	EsState s = es_unpack(start[slot]);
+	EsWriter wr;
+	wr.sc = &sc;
+	wr.im = &imgs[sc.img];
+	wr.coef = coef;
+	wr.dcdiff = dcdiff + sc.blk_off;
+	wr.l1 = l1 + sc.blk_off;
+	wr.toff = toff;
+	wr.ord = base[slot];
+	wr.acc = 0;
+	if (wr.ord >= sc.nblocks)
+		return;
+	const uint32_t m = wr.ord / sc.bpm;
+	if (wr.ord - m * sc.bpm != s.c) { /* the chain is inconsistent: cannot happen after convergence */
+		atomicOr(&anom[wk.scan], 2u);
+		return;
+	}
+	wr.my = m / sc.mcu_x;
+	wr.mx = m - wr.my * sc.mcu_x;
+	wr.locate(s.c);
+	const uint32_t pe = min((i + 1u) * MIJ_ES_BITS, sc.nbits);
+	es_decode<true>(sc, tabs, streams + sc.stream_off, s, pe, &wr, &anom[wk.scan]);
+}
+
+/* DC prediction (codec/jpeg.c:323-325), L1 bound and the completion checks; one workgroup per scan */
+__global__ __launch_bounds__(256) void k_es_dc(const DevScan *__restrict__ scans, const DevImage *__restrict__ imgs, const uint64_t *__restrict__ end,
+															  const uint32_t *__restrict__ total, const uint32_t *__restrict__ changed, int16_t *__restrict__ coef,
+															  const int16_t *__restrict__ dcdiff, const uint32_t *__restrict__ l1, uint32_t *__restrict__ anom,
+															  uint32_t *__restrict__ l1max)
+{
+	__shared__ int part[256][4];
+	__shared__ uint32_t wmax[256];
+	const DevScan &sc = scans[blockIdx.x];
+	const DevImage &im = imgs[sc.img];
+	const uint32_t nmcu = sc.nblocks / sc.bpm;
+	const uint32_t per = (nmcu + 255u) / 256u;
+	const uint32_t lo = min(threadIdx.x * per, nmcu), hi = min(lo + per, nmcu);
+	const int16_t *dd = dcdiff + sc.blk_off;
+	const uint32_t *bl1 = l1 + sc.blk_off;
+	if (threadIdx.x == 0) {
+		const EsState last = es_unpack(end[sc.sub_off + sc.nsub - 1u]);
+		(void)last;
+		if (total[blockIdx.x] < sc.nblocks)
+			atomicOr(&anom[blockIdx.x], 4u); /* the stream ends before the last block */
+		if (changed[blockIdx.x])
+			atomicOr(&anom[blockIdx.x], 8u); /* the last synchronisation round still moved something */
+	}
+	int sum[4] = {0, 0, 0, 0};
+	for (uint32_t m = lo; m < hi; ++m)
+		for (uint32_t c = 0; c < sc.bpm; ++c)
+			sum[sc.blk_comp[c]] += dd[m * sc.bpm + c];
+	for (int k = 0; k < 4; ++k)
+		part[threadIdx.x][k] = sum[k];
+	__syncthreads();
+	if (threadIdx.x < 4) {
+		int run = 0;
+		for (int t = 0; t < 256; ++t) {
+			const int v = part[t][threadIdx.x];
+			part[t][threadIdx.x] = run;
+			run = (int)((unsigned)run + (unsigned)v);
+		}
+	}
+	__syncthreads();
+	int pred[4];
+	for (int k = 0; k < 4; ++k)
+		pred[k] = part[threadIdx.x][k];
+	uint32_t mymax = 0;
+	uint32_t my = lo / sc.mcu_x, mx = lo - my * sc.mcu_x;
+	for (uint32_t m = lo; m < hi; ++m) {
+		for (uint32_t c = 0; c < sc.bpm; ++c) {
+			const uint32_t ci = sc.blk_comp[c];
+			const DevComp &cp = im.comp[ci];
+			pred[ci] = (int)((unsigned)pred[ci] + (unsigned)(int)dd[m * sc.bpm + c]);
+			const uint32_t bx = mx * (uint32_t)cp.h + sc.blk_dx[c], by = my * (uint32_t)cp.v + sc.blk_dy[c];
+			const uint32_t L = bx + by * (uint32_t)cp.bw;
+			int16_t *blk = reinterpret_cast<int16_t *>(reinterpret_cast<uint8_t *>(coef) + cp.coef_off) + ((size_t)(L >> 6) << 12) + ((L & 63u) << 3);
+			blk[0] = (int16_t)pred[ci];
+			const int dq = (int)(int16_t)((uint32_t)pred[ci] * sc.qz[ci][0]);
+			const uint32_t tot = bl1[m * sc.bpm + c] + (uint32_t)(dq < 0 ? -dq : dq);
+			mymax = tot > mymax ? tot : mymax;
+		}
+		if (++mx == sc.mcu_x) {
+			mx = 0;
+			++my;
+		}
+	}
+	wmax[threadIdx.x] = mymax;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t mxv = 0;
+		for (int t = 0; t < 256; ++t)
+			mxv = wmax[t] > mxv ? wmax[t] : mxv;
+		l1max[blockIdx.x] = mxv;
+	}
+}
+
+} /* namespace mij */
+
+#endif

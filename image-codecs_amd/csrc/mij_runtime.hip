@@ -127,6 +127,8 @@ struct Slot {
 	size_t stage_off;  /* byte offset in the staging arena (clones: the source's) */
 	size_t coef_bytes; /* bytes of this image's coefficient planes */
 	int clone_of;      /* -1: own staging */
+	int dev_coef;      /* 1: the GPU entropy stage wrote the coefficient planes in HBM; nothing to upload */
+	int es_index;      /* index into the entropy arena's scan list, or -1 */
 	int path;          /* 0 none, 1 fused 4:2:0, 2 two-pass, 3 fused 4:4:4 */
 };
 
@@ -168,9 +170,12 @@ struct mij_batch {
 	std::vector<int> twopass_slots;
 	bool uploaded, launched, force_generic;
 	int band_rows; /* MCU rows per fused workgroup; 0 = automatic */
+	struct EsArena *es; /* GPU entropy stage, allocated by mij_batch_entropy_reserve */
 };
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static void es_free_fwd(struct EsArena *e);
+static void es_reset_fwd(struct EsArena *e);
 
 extern "C" size_t mij_image_coef_bytes(const mij_image_desc *d)
 {
@@ -206,6 +211,7 @@ extern "C" int mij_batch_create(mij_ctx *ctx, int max_images, size_t stage_bytes
 	b->bands_cap = b->idct_cap = 0;
 	b->uploaded = b->launched = b->force_generic = false;
 	b->band_rows = 0;
+	b->es = nullptr;
 	b->stream = nullptr;
 	b->ev_begin = b->ev_end = nullptr;
 	const char *env = getenv("MIJ_BAND_ROWS");
@@ -265,6 +271,8 @@ extern "C" void mij_batch_destroy(mij_batch *b)
 		(void)hipHostFree(b->h_idct);
 	if (b->d_idct)
 		(void)hipFree(b->d_idct);
+	if (b->es)
+		es_free_fwd(b->es);
 	if (b->ev_begin)
 		(void)hipEventDestroy(b->ev_begin);
 	if (b->ev_end)
@@ -286,6 +294,7 @@ extern "C" int mij_batch_reset(mij_batch *b)
 	b->band_launches.clear();
 	b->idct_launches.clear();
 	b->twopass_slots.clear();
+	es_reset_fwd(b->es);
 	return MIJ_OK;
 }
 
@@ -374,6 +383,8 @@ static int add_common(mij_batch *b, const mij_image_desc *d, int clone_of)
 	Slot s;
 	s.desc = *d;
 	s.clone_of = clone_of;
+	s.dev_coef = 0;
+	s.es_index = -1;
 	s.coef_bytes = cbytes;
 	s.path = 0;
 	if (clone_of < 0) {
@@ -752,13 +763,13 @@ extern "C" int mij_batch_upload(mij_batch *b)
 	 * them go up in one copy each */
 	size_t i = 0;
 	while (i < n) {
-		if (b->slots[i].clone_of >= 0) {
+		if (b->slots[i].clone_of >= 0 || b->slots[i].dev_coef) {
 			++i;
 			continue;
 		}
 		size_t j = i, bytes = 0;
 		const size_t s0 = b->slots[i].stage_off, c0 = b->slots[i].dev.comp[0].coef_off;
-		while (j < n && b->slots[j].clone_of < 0 && b->slots[j].stage_off == s0 + bytes && b->slots[j].dev.comp[0].coef_off == c0 + bytes) {
+		while (j < n && b->slots[j].clone_of < 0 && !b->slots[j].dev_coef && b->slots[j].stage_off == s0 + bytes && b->slots[j].dev.comp[0].coef_off == c0 + bytes) {
 			bytes += b->slots[j].coef_bytes;
 			++j;
 		}
@@ -962,6 +973,314 @@ extern "C" int mij_batch_hash_out(mij_batch *b, int slot, uint64_t *hash)
 	*hash = h;
 	return MIJ_OK;
 }
+
+/* ------------------------------------------------------------------ GPU entropy stage (mij_batch_entropy_*)
+ *
+ * See mij_entropy_kernels.h for the algorithm.  The arena holds everything the five kernels touch besides the
+ * coefficient planes: the unstuffed streams, per-scan descriptors and Huffman tables, three state words and a
+ * counter per subsequence, a DC difference and an L1 accumulator per block, and four verdict words per scan.
+ */
+#include "mij_entropy_kernels.h"
+
+struct EsArena {
+	uint8_t *stage, *d_stream; /* pinned / device, stream_cap bytes */
+	size_t stream_cap;
+	DevScan *h_scans, *d_scans;
+	DevHuff *h_huff, *d_huff;
+	EsWork *h_work, *d_work;
+	size_t work_cap;
+	uint64_t *d_start, *d_end[2];
+	uint32_t *d_cnt;
+	size_t sub_cap;
+	int16_t *d_dcdiff;
+	uint32_t *d_l1;
+	size_t blk_cap;
+	uint32_t *d_verdict, *h_verdict; /* [4][max_images]: anomaly, changed, total, l1max */
+	uint32_t *d_rounds_changed, *h_rounds_changed; /* [MAX_ROUNDS] sum over scans, for tuning */
+	std::vector<int> scan_slot; /* scan index -> batch slot */
+	size_t sub_used, blk_used, work_used;
+	int last_rounds;
+};
+
+static const int ES_MAX_ROUNDS = 96;
+
+static void es_free(EsArena *e)
+{
+	if (!e)
+		return;
+	if (e->stage) (void)hipHostFree(e->stage);
+	if (e->d_stream) (void)hipFree(e->d_stream);
+	if (e->h_scans) (void)hipHostFree(e->h_scans);
+	if (e->d_scans) (void)hipFree(e->d_scans);
+	if (e->h_huff) (void)hipHostFree(e->h_huff);
+	if (e->d_huff) (void)hipFree(e->d_huff);
+	if (e->h_work) (void)hipHostFree(e->h_work);
+	if (e->d_work) (void)hipFree(e->d_work);
+	if (e->d_start) (void)hipFree(e->d_start);
+	if (e->d_end[0]) (void)hipFree(e->d_end[0]);
+	if (e->d_end[1]) (void)hipFree(e->d_end[1]);
+	if (e->d_cnt) (void)hipFree(e->d_cnt);
+	if (e->d_dcdiff) (void)hipFree(e->d_dcdiff);
+	if (e->d_l1) (void)hipFree(e->d_l1);
+	if (e->d_verdict) (void)hipFree(e->d_verdict);
+	if (e->h_verdict) (void)hipHostFree(e->h_verdict);
+	if (e->d_rounds_changed) (void)hipFree(e->d_rounds_changed);
+	if (e->h_rounds_changed) (void)hipHostFree(e->h_rounds_changed);
+	delete e;
+}
+
+static void es_free_fwd(EsArena *e) { es_free(e); }
+static void es_reset_fwd(EsArena *e)
+{
+	if (!e)
+		return;
+	e->scan_slot.clear();
+	e->sub_used = e->blk_used = e->work_used = 0;
+}
+
+extern "C" int mij_batch_entropy_reserve(mij_batch *b, size_t stream_bytes)
+{
+	if (!b || !stream_bytes)
+		return set_err(MIJ_E_ARG, "mij_batch_entropy_reserve: bad argument");
+	if (b->es)
+		return set_err(MIJ_E_STATE, "the entropy arena exists already");
+	HIP_TRY(hipSetDevice(b->ctx->device));
+	EsArena *e = new (std::nothrow) EsArena();
+	if (!e)
+		return set_err(MIJ_E_NOMEM, "out of host memory");
+	memset(static_cast<void *>(e), 0, offsetof(EsArena, scan_slot));
+	const size_t n = (size_t)b->max_images;
+	e->stream_cap = align_up(stream_bytes + 64 * n, 256);
+	e->sub_cap = e->stream_cap * 8 / MIJ_ES_BITS + 2 * n;
+	e->blk_cap = b->coef_cap / 128 + n;
+	e->work_cap = e->sub_cap / 256 + 2 * n;
+	hipError_t r = hipHostMalloc(reinterpret_cast<void **>(&e->stage), e->stream_cap, hipHostMallocDefault);
+	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_stream), e->stream_cap);
+	if (r == hipSuccess) r = hipHostMalloc(reinterpret_cast<void **>(&e->h_scans), sizeof(DevScan) * n, hipHostMallocDefault);
+	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_scans), sizeof(DevScan) * n);
+	if (r == hipSuccess) r = hipHostMalloc(reinterpret_cast<void **>(&e->h_huff), sizeof(DevHuff) * 8 * n, hipHostMallocDefault);
+	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_huff), sizeof(DevHuff) * 8 * n);
+	if (r == hipSuccess) r = hipHostMalloc(reinterpret_cast<void **>(&e->h_work), sizeof(EsWork) * e->work_cap, hipHostMallocDefault);
+	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_work), sizeof(EsWork) * e->work_cap);
+	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_start), sizeof(uint64_t) * e->sub_cap);
+	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_end[0]), sizeof(uint64_t) * e->sub_cap);
+	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_end[1]), sizeof(uint64_t) * e->sub_cap);
+	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_cnt), sizeof(uint32_t) * e->sub_cap);
+	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_dcdiff), sizeof(int16_t) * e->blk_cap);
+	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_l1), sizeof(uint32_t) * e->blk_cap);
+	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_verdict), sizeof(uint32_t) * 4 * n);
+	if (r == hipSuccess) r = hipHostMalloc(reinterpret_cast<void **>(&e->h_verdict), sizeof(uint32_t) * 4 * n, hipHostMallocDefault);
+	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_rounds_changed), sizeof(uint32_t) * ES_MAX_ROUNDS);
+	if (r == hipSuccess) r = hipHostMalloc(reinterpret_cast<void **>(&e->h_rounds_changed), sizeof(uint32_t) * ES_MAX_ROUNDS, hipHostMallocDefault);
+	if (r != hipSuccess) {
+		es_free(e);
+		return set_err(r == hipErrorOutOfMemory ? MIJ_E_NOMEM : MIJ_E_HIP, "mij_batch_entropy_reserve: %s", hipGetErrorString(r));
+	}
+	b->es = e;
+	return MIJ_OK;
+}
+
+extern "C" uint8_t *mij_batch_entropy_stage(mij_batch *b, size_t *capacity)
+{
+	if (!b || !b->es)
+		return nullptr;
+	if (capacity)
+		*capacity = b->es->stream_cap;
+	return b->es->stage;
+}
+
+extern "C" int mij_batch_add_stream(mij_batch *b, const mjg_scan *scan, uint8_t *stream, size_t stream_len)
+{
+	if (!b || !b->es || !scan || !stream)
+		return set_err(MIJ_E_ARG, "mij_batch_add_stream: bad argument (entropy arena reserved?)");
+	EsArena *e = b->es;
+	if (stream < e->stage || stream + stream_len + 32 > e->stage + e->stream_cap || ((size_t)(stream - e->stage) & 3u))
+		return set_err(MIJ_E_ARG, "the stream must lie 4-byte aligned inside the pinned entropy region with 32 spare bytes behind it");
+	if (scan->blocks_per_mcu < 1 || scan->blocks_per_mcu > 10 || scan->nblocks == 0 || stream_len >= (1u << 28))
+		return set_err(MIJ_E_ARG, "bad scan description");
+	const size_t nsub = (stream_len * 8 + MIJ_ES_BITS - 1) / MIJ_ES_BITS;
+	if (e->sub_used + nsub + 1 > e->sub_cap || e->blk_used + scan->nblocks > e->blk_cap || e->work_used + nsub / 256 + 1 > e->work_cap)
+		return set_err(MIJ_E_NOMEM, "entropy arena exhausted");
+	const int slot = add_common(b, &scan->desc, -1);
+	if (slot < 0)
+		return slot;
+	Slot &s = b->slots[(size_t)slot];
+	const size_t k = e->scan_slot.size();
+	s.dev_coef = 1;
+	s.es_index = (int)k;
+	memset(stream + stream_len, 0, 32);
+	DevScan &d = e->h_scans[k];
+	memset(&d, 0, sizeof(d));
+	d.stream_off = (uint64_t)(stream - e->stage);
+	d.nbits = (uint32_t)(stream_len * 8);
+	d.nsub = (uint32_t)(nsub ? nsub : 1);
+	d.sub_off = (uint32_t)e->sub_used;
+	d.img = (uint32_t)slot;
+	d.nblocks = scan->nblocks;
+	d.blk_off = (uint32_t)e->blk_used;
+	d.bpm = scan->blocks_per_mcu;
+	d.mcu_x = (uint32_t)scan->desc.mcu_x;
+	memcpy(d.blk_comp, scan->blk_comp, 12);
+	memcpy(d.blk_dx, scan->blk_dx, 12);
+	memcpy(d.blk_dy, scan->blk_dy, 12);
+	memcpy(d.dc_tab, scan->dc_tab, 4);
+	memcpy(d.ac_tab, scan->ac_tab, 4);
+	d.tab_off = (uint32_t)(8 * k);
+	memcpy(d.qz, scan->qz, sizeof(d.qz));
+	static_assert(sizeof(DevHuff) == sizeof(mjg_huff), "mjg_huff and DevHuff must match");
+	memcpy(&e->h_huff[8 * k], scan->huff, sizeof(mjg_huff) * 8);
+	for (uint32_t f = 0; f < d.nsub; f += 256) {
+		EsWork w = {(uint32_t)k, f};
+		e->h_work[e->work_used++] = w;
+	}
+	e->sub_used += d.nsub;
+	e->blk_used += d.nblocks;
+	e->scan_slot.push_back(slot);
+	return slot;
+}
+
+extern "C" int mij_batch_entropy_run(mij_batch *b, int *fallback, int cap, int *n_fallback)
+{
+	if (!b || !b->es || !n_fallback)
+		return set_err(MIJ_E_ARG, "mij_batch_entropy_run: bad argument");
+	EsArena *e = b->es;
+	*n_fallback = 0;
+	const size_t ns = e->scan_slot.size();
+	if (!ns)
+		return MIJ_OK;
+	HIP_TRY(hipSetDevice(b->ctx->device));
+	hipStream_t st = b->stream;
+	const size_t n = b->slots.size();
+	for (size_t i = 0; i < n; ++i)
+		b->h_imgs[i] = b->slots[i].dev;
+	HIP_TRY(hipMemcpyAsync(b->d_imgs, b->h_imgs, sizeof(DevImage) * n, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(e->d_scans, e->h_scans, sizeof(DevScan) * ns, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(e->d_huff, e->h_huff, sizeof(DevHuff) * 8 * ns, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(e->d_work, e->h_work, sizeof(EsWork) * e->work_used, hipMemcpyHostToDevice, st));
+	/* streams: one copy from the first to the last byte in use */
+	size_t lo = (size_t)-1, hi = 0;
+	for (size_t k = 0; k < ns; ++k) {
+		const DevScan &d = e->h_scans[k];
+		lo = d.stream_off < lo ? (size_t)d.stream_off : lo;
+		const size_t end = (size_t)d.stream_off + d.nbits / 8 + 32;
+		hi = end > hi ? end : hi;
+	}
+	HIP_TRY(hipMemcpyAsync(e->d_stream + lo, e->stage + lo, hi - lo, hipMemcpyHostToDevice, st));
+	/* zero the coefficient planes the walk will fill (runs of adjacent slots in one memset), the L1 accumulators, the verdicts */
+	for (size_t k = 0; k < ns;) {
+		const Slot &s0 = b->slots[(size_t)e->scan_slot[k]];
+		size_t bytes = s0.coef_bytes, j = k + 1;
+		while (j < ns && b->slots[(size_t)e->scan_slot[j]].dev.comp[0].coef_off == s0.dev.comp[0].coef_off + bytes) {
+			bytes += b->slots[(size_t)e->scan_slot[j]].coef_bytes;
+			++j;
+		}
+		HIP_TRY(hipMemsetAsync(b->d_coef + s0.dev.comp[0].coef_off, 0, bytes, st));
+		k = j;
+	}
+	HIP_TRY(hipMemsetAsync(e->d_l1, 0, sizeof(uint32_t) * e->blk_used, st));
+	HIP_TRY(hipMemsetAsync(e->d_verdict, 0, sizeof(uint32_t) * 4 * (size_t)b->max_images, st));
+	HIP_TRY(hipMemsetAsync(e->d_rounds_changed, 0, sizeof(uint32_t) * ES_MAX_ROUNDS, st));
+	uint32_t *v_anom = e->d_verdict, *v_changed = e->d_verdict + b->max_images, *v_total = e->d_verdict + 2 * (size_t)b->max_images,
+				*v_l1 = e->d_verdict + 3 * (size_t)b->max_images;
+	const dim3 gw((unsigned)e->work_used), gs((unsigned)ns), blk(256);
+	hipLaunchKernelGGL(k_es_cold, gw, blk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, e->d_start, e->d_end[0], e->d_cnt);
+	HIP_TRY(hipGetLastError());
+	int rounds = ES_MAX_ROUNDS;
+	if (const char *env = getenv("MIJ_ES_ROUNDS"))
+		rounds = atoi(env) > 0 && atoi(env) <= ES_MAX_ROUNDS ? atoi(env) : rounds;
+	int cur = 0;
+	for (int r = 0; r < rounds; ++r) {
+		HIP_TRY(hipMemsetAsync(v_changed, 0, sizeof(uint32_t) * ns, st));
+		hipLaunchKernelGGL(k_es_sync, gw, blk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, e->d_start, e->d_end[cur], e->d_end[cur ^ 1], e->d_cnt, v_changed);
+		HIP_TRY(hipGetLastError());
+		cur ^= 1;
+		/* every fourth round: stop as soon as a round moved nothing (one small D2H + wait) */
+		if ((r & 3) == 3 || r == rounds - 1) {
+			HIP_TRY(hipMemcpyAsync(e->h_verdict + b->max_images, v_changed, sizeof(uint32_t) * ns, hipMemcpyDeviceToHost, st));
+			HIP_TRY(hipStreamSynchronize(st));
+			uint32_t any = 0;
+			for (size_t k = 0; k < ns; ++k)
+				any |= e->h_verdict[(size_t)b->max_images + k];
+			e->last_rounds = r + 1;
+			if (!any)
+				break;
+		}
+	}
+	hipLaunchKernelGGL(k_es_offsets, gs, blk, 0, st, e->d_scans, e->d_cnt, v_total);
+	HIP_TRY(hipGetLastError());
+	hipLaunchKernelGGL(k_es_write, gw, blk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, b->d_imgs, e->d_start, e->d_cnt,
+							 reinterpret_cast<int16_t *>(b->d_coef), e->d_dcdiff, e->d_l1, v_anom);
+	HIP_TRY(hipGetLastError());
+	hipLaunchKernelGGL(k_es_dc, gs, blk, 0, st, e->d_scans, b->d_imgs, e->d_end[cur], v_total, v_changed, reinterpret_cast<int16_t *>(b->d_coef), e->d_dcdiff, e->d_l1,
+							 v_anom, v_l1);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(e->h_verdict, e->d_verdict, sizeof(uint32_t) * 4 * (size_t)b->max_images, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	if (getenv("MIJ_ES_DEBUG"))
+		for (size_t k = 0; k < ns; ++k)
+			fprintf(stderr, "es scan %zu slot %d: anomaly %u changed %u blocks %u/%u l1max %u nsub %u rounds %d\n", k, e->scan_slot[k], e->h_verdict[k],
+					  e->h_verdict[(size_t)b->max_images + k], e->h_verdict[2 * (size_t)b->max_images + k], e->h_scans[k].nblocks,
+					  e->h_verdict[3 * (size_t)b->max_images + k], e->h_scans[k].nsub, e->last_rounds);
+	for (size_t k = 0; k < ns; ++k) {
+		Slot &s = b->slots[(size_t)e->scan_slot[k]];
+		if (e->h_verdict[k]) {
+			if (*n_fallback < cap && fallback)
+				fallback[*n_fallback] = e->scan_slot[k];
+			++*n_fallback;
+			continue;
+		}
+		if (e->h_verdict[3 * (size_t)b->max_images + k] > MIJ_BLOCK_L1_LIMIT)
+			s.desc.flags |= MIJ_FLAG_WIDE_IDCT;
+	}
+	b->uploaded = b->launched = false;
+	if (*n_fallback > cap)
+		return set_err(MIJ_E_ARG, "fallback list too small (%d > %d)", *n_fallback, cap);
+	return MIJ_OK;
+}
+
+extern "C" int mij_batch_fallback_prepare(mij_batch *b, int slot)
+{
+	if (!b || slot < 0 || slot >= (int)b->slots.size())
+		return set_err(MIJ_E_ARG, "bad slot");
+	Slot &s = b->slots[(size_t)slot];
+	if (!s.dev_coef)
+		return MIJ_OK;
+	s.dev_coef = 0;
+	s.desc.flags &= ~(uint32_t)MIJ_FLAG_WIDE_IDCT;
+	memset(b->stage + s.stage_off, 0, s.coef_bytes);
+	b->uploaded = b->launched = false;
+	return MIJ_OK;
+}
+
+extern "C" int mij_batch_fetch_coef(mij_batch *b, int slot, int16_t *dst, size_t dst_elems)
+{
+	if (!b || slot < 0 || slot >= (int)b->slots.size() || !dst)
+		return set_err(MIJ_E_ARG, "bad slot or destination");
+	const Slot &s = b->slots[(size_t)slot];
+	if (dst_elems * sizeof(int16_t) < s.coef_bytes)
+		return set_err(MIJ_E_ARG, "destination too small");
+	HIP_TRY(hipSetDevice(b->ctx->device));
+	HIP_TRY(hipMemcpyAsync(dst, b->d_coef + s.dev.comp[0].coef_off, s.coef_bytes, hipMemcpyDeviceToHost, b->stream));
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	return MIJ_OK;
+}
+
+/* debugging aid (not in mij.h): the state words of a slot's subsequences after the last entropy_run */
+extern "C" int mij_batch_entropy_debug_states(mij_batch *b, int slot, uint64_t *start, uint64_t *end0, uint64_t *end1, uint32_t *cnt, size_t cap)
+{
+	if (!b || !b->es || slot < 0 || slot >= (int)b->slots.size() || b->slots[(size_t)slot].es_index < 0)
+		return -1;
+	const DevScan &d = b->es->h_scans[b->slots[(size_t)slot].es_index];
+	if (cap < d.nsub)
+		return -2;
+	(void)hipMemcpy(start, b->es->d_start + d.sub_off, sizeof(uint64_t) * d.nsub, hipMemcpyDeviceToHost);
+	(void)hipMemcpy(end0, b->es->d_end[0] + d.sub_off, sizeof(uint64_t) * d.nsub, hipMemcpyDeviceToHost);
+	(void)hipMemcpy(end1, b->es->d_end[1] + d.sub_off, sizeof(uint64_t) * d.nsub, hipMemcpyDeviceToHost);
+	(void)hipMemcpy(cnt, b->es->d_cnt + d.sub_off, sizeof(uint32_t) * d.nsub, hipMemcpyDeviceToHost);
+	return (int)d.nsub;
+}
+
+extern "C" int mij_batch_entropy_rounds(const mij_batch *b) { return b && b->es ? b->es->last_rounds : 0; }
 
 /* ------------------------------------------------------------------ encoder (mij_enc_*)
  *

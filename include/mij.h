@@ -193,6 +193,44 @@ int mij_batch_slot_path(const mij_batch *b, int slot);
 /* force the generic (unfused) path for every image of a batch: parity tests compare both */
 int mij_batch_force_generic(mij_batch *b, int on);
 
+/* ---- GPU entropy stage (experimental): the baseline Huffman walk itself on the GPU, for single-scan interleaved
+ * baseline files without restart markers.  The host only parses headers and removes
+ * the 0xFF00 byte stuffing (mjh_extract_scan, mij_host.h); coefficients never cross PCIe.  Any stream the GPU
+ * walk does not like (invalid code, run past coefficient 63, early end, no convergence) is reported back and
+ * must be re-done with the host walk, whose behaviour on malformed input is the reference's. ---- */
+typedef struct { /* stbi__huffman without code[] (codec/jpeg.c:21-32) */
+	uint8_t fast[512];
+	uint8_t size[256];
+	uint8_t values[256];
+	uint32_t maxcode[18];
+	int32_t delta[18];
+} mjg_huff;
+
+typedef struct {
+	mij_image_desc desc;
+	uint32_t nblocks, blocks_per_mcu;
+	uint8_t blk_comp[12], blk_dx[12], blk_dy[12]; /* block inside the MCU -> component, block offset inside the MCU */
+	uint8_t dc_tab[4], ac_tab[4];                 /* component -> index into huff[] (0..3 DC tables, 4..7 AC tables) */
+	mjg_huff huff[8];
+	uint16_t qz[4][64];                           /* per component, zigzag order */
+} mjg_scan;
+
+/* pinned + device arenas for stream_bytes of unstuffed entropy data; once per batch */
+int mij_batch_entropy_reserve(mij_batch *b, size_t stream_bytes);
+/* pinned region where the caller writes streams (capacity as reserved; reset by mij_batch_reset) */
+uint8_t *mij_batch_entropy_stage(mij_batch *b, size_t *capacity);
+/* new slot whose coefficients the GPU walk will produce; stream = pointer into the pinned region, followed by
+ * at least 32 writable bytes (zeroed here).  Returns the slot or a negative code. */
+int mij_batch_add_stream(mij_batch *b, const mjg_scan *scan, uint8_t *stream, size_t stream_len);
+/* H2D of the streams, the five kernels, D2H of the verdicts; waits.  fallback[0..*n_fallback) = slots the host
+ * walk must redo (mij_batch_fallback_prepare, then decode into mij_batch_coef as usual). */
+int mij_batch_entropy_run(mij_batch *b, int *fallback, int cap, int *n_fallback);
+int mij_batch_fallback_prepare(mij_batch *b, int slot);
+/* tests: the coefficient planes of a slot as they sit in HBM (tile layout), after entropy_run or upload */
+int mij_batch_fetch_coef(mij_batch *b, int slot, int16_t *dst, size_t dst_elems);
+/* tests / tuning: synchronisation rounds the last entropy_run needed for its slowest image */
+int mij_batch_entropy_rounds(const mij_batch *b);
+
 /*
  * Encoder half (BASELINE config 5): the JPEG writer's colour transform, edge replication, 2x2
  * chroma mean, float AAN forward DCT and quantiser (codec/jpeg_write.c:24-74, :96-118, :283-352)

@@ -34,6 +34,12 @@ int mjh_probe_memory(const uint8_t *buf, int len, int req_comp, mij_image_desc *
  */
 int mjh_decode_memory(const uint8_t *buf, int len, int req_comp, mij_image_desc *desc, int16_t *arena, size_t arena_elems, const char **reason);
 
+/* Header parse + extraction of the entropy segment for the GPU entropy stage (mij.h: mjg_scan,
+ * mij_batch_add_stream).  Returns 1: *scan filled, the segment without its 0xFF00 stuffing written to stream
+ * (stream_cap must leave 32 spare bytes); 2: a valid header but not a layout the GPU walk takes (use
+ * mjh_decode_memory); 0: rejected like mjh_probe_memory, *reason set. */
+int mjh_extract_scan(const uint8_t *buf, int len, int req_comp, mjg_scan *scan, uint8_t *stream, size_t stream_cap, size_t *stream_len, const char **reason);
+
 /*
  * Batch front end: the host stage of n JPEGs on `threads` host threads (one image per task),
  * straight into a mij batch's pinned staging.  Images are added to the batch in input order

@@ -1,0 +1,81 @@
+"""GPU entropy stage (experimental): the baseline Huffman walk on the GPU.
+The coefficient planes it leaves in HBM must equal, element for element, what the host walk stages; the
+decoded pixels must equal the oracle's; streams it refuses must come back in the fallback list."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _host_planes(ica, data, req):
+    return ica.HostDecoder.decode(data, req)
+
+
+def test_gpu_walk_equals_host_walk(ica, oracle, gpu_ctx, golden):
+    datas = [ica.synth_jpeg(w, h, i, q) for i, (w, h, q) in enumerate(((64, 48, 90), (16, 16, 50), (200, 120, 90), (33, 17, 75), (640, 480, 90), (1920, 1080, 90),
+                                                                        (8, 8, 95), (250, 131, 95), (1, 1, 90), (1024, 768, 30)))]
+    rng = np.random.default_rng(3)
+    datas.append(ica.stbi_write_jpg_to_memory(rng.integers(0, 256, (211, 307, 3)).astype(np.uint8), 92))   # noise: long codes, big coefficients
+    datas.append(ica.stbi_write_jpg_to_memory(rng.integers(0, 256, (120, 160, 3)).astype(np.uint8), 100))  # q=100: WIDE candidates
+    b = ica.Batch(gpu_ctx, len(datas), 64 << 20, 64 << 20, 64 << 20)
+    b.entropy_reserve(16 << 20)
+    slots = []
+    for d in datas:
+        st, slot = b.add_jpeg_stream(d, 3)
+        assert st == 1, (st, b.last_reason)
+        slots.append(slot)
+    fallback = b.entropy_run()
+    assert fallback == [], fallback
+    assert 1 <= b.entropy_rounds() <= 24
+    for d, s in zip(datas, slots):
+        desc, want = _host_planes(ica, d, 3)
+        got = b.fetch_coef(s)
+        assert np.array_equal(got, want), (s, int((got != want).sum()))
+    b.submit()
+    b.wait()
+    for d, s in zip(datas, slots):
+        assert np.array_equal(b.fetch(s), oracle.load(d, 3)[1]), s
+    b.close()
+
+
+def test_gpu_walk_refuses_what_it_should(ica, oracle, gpu_ctx, golden):
+    """Layouts outside its scope are not taken (status 2), damaged entropy data is reported for the host walk,
+    and the host walk's result for those slots is what the oracle says."""
+    b = ica.Batch(gpu_ctx, 16, 64 << 20, 64 << 20, 64 << 20)
+    b.entropy_reserve(8 << 20)
+    for name in ("prog_420_64x64", "big_b444_rst_250x130"):
+        st, _ = b.add_jpeg_stream(golden.jpg(name), 3)
+        assert st == 2, name
+    st, _ = b.add_jpeg_stream(golden.jpg("garbage"), 3)
+    assert st == 0 and b.last_reason == "unknown image type"
+    good = ica.synth_jpeg(320, 200, 5, 90)
+    bad = bytearray(good)
+    pos = len(bad) // 2
+    for k in range(24):  # a burst of damage in the middle of the entropy segment, no 0xff created or destroyed
+        if bad[pos + k] != 0xFF and bad[pos + k - 1] != 0xFF:
+            bad[pos + k] = (bad[pos + k] * 7 + 13) % 255
+    bad = bytes(bad)
+    s_good = b.add_jpeg_stream(good, 3)[1]
+    st, s_bad = b.add_jpeg_stream(bad, 3)
+    assert st == 1
+    fallback = b.entropy_run()
+    assert s_good not in fallback
+    kind, want, reason = oracle.load(bad, 3)
+    if s_bad in fallback:
+        b.fallback_prepare(s_bad)
+        try:
+            d2, _ = ica.HostDecoder.decode(bad, 3, out=b.staging(s_bad))
+            if d2.flags:
+                b.set_flags(s_bad, d2.flags)
+            host_ok = True
+        except ica.MijError:
+            host_ok = False
+        assert host_ok == (kind == "ok")
+        if not host_ok:
+            b.set_flags(s_bad, 2)  # MIJ_FLAG_SKIP
+    b.submit()
+    b.wait()
+    assert np.array_equal(b.fetch(s_good), oracle.load(good, 3)[1])
+    if kind == "ok":
+        assert np.array_equal(b.fetch(s_bad), want)
+    b.close()
