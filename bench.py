@@ -242,6 +242,38 @@ def main():
             got = pins[side].array[off:off + W * H * 3]
             assert np.array_equal(got, ebs[side].fetch(slot).reshape(-1)), "D2H copy differs from the device image"
         e2e["value_with_d2h"] = round(n_e * W * H / t_d2h / 1e6, 1)
+        # experimental: the Huffman walk itself on the GPU (mjh_decode_batch_gpu): the host threads only parse
+        # headers and remove byte stuffing, 0.45 MB of bitstream per image crosses PCIe instead of 6.3 MB of
+        # coefficients; images the GPU walk refuses are walked on the host
+        try:
+            for eb in ebs:
+                eb.reset()
+                eb.entropy_reserve(sum(len(x) + 512 for x in jl[:chunk]) * 2)
+            for eb in ebs:  # warm-up
+                eb.reset()
+                eb.decode_jpegs(jl[:chunk], 3, threads, gpu_entropy=True)
+                eb.submit()
+                eb.wait()
+            t0 = time.perf_counter()
+            n_gpu_ok = 0
+            for k, lo in enumerate(range(0, n_e, chunk)):
+                eb = ebs[k & 1]
+                eb.reset()
+                part = jl[lo:lo + chunk]
+                ok, slots, reasons = eb.decode_jpegs(part, 3, threads, gpu_entropy=True)
+                assert ok == len(part), reasons
+                eb.submit()
+                last[k & 1] = (lo + len(part) - 1, slots[len(part) - 1])
+            for eb in ebs:
+                eb.wait()
+            t_gpu = time.perf_counter() - t0
+            for side, (img, slot) in last.items():
+                assert ebs[side].hash_out(slot) == src_hash[img % distinct], "GPU-walked image differs"
+            e2e["value_gpu_entropy"] = round(n_e * W * H / t_gpu / 1e6, 1)
+            e2e["gpu_entropy_sync_rounds"] = ebs[0].entropy_rounds()
+        except ica.MijError as exc:
+            e2e["value_gpu_entropy"] = None
+            e2e["gpu_entropy_error"] = str(exc)
         for pb in pins:
             pb.close()
         for eb in ebs:

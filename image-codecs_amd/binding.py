@@ -388,8 +388,9 @@ class Batch:
             _check(lib().mij_batch_set_flags(self._h, slot, d2.flags), "mij_batch_set_flags")
         return slot
 
-    def decode_jpegs(self, datas, req_comp=0, threads=1):
-        """mjh_decode_batch: host stage of many JPEGs on a thread pool into this batch's staging.
+    def decode_jpegs(self, datas, req_comp=0, threads=1, gpu_entropy=False):
+        """mjh_decode_batch: host stage of many JPEGs on a thread pool into this batch's staging
+        (gpu_entropy: mjh_decode_batch_gpu -- the Huffman walk itself on the GPU where it applies).
         -> (n_ok, slots, reasons); slots[i] < 0 marks a rejected image (reasons[i] says why)."""
         n = len(datas)
         bufs = (C.c_char_p * n)(*[bytes(d) for d in datas])
@@ -397,7 +398,9 @@ class Batch:
         slots = (C.c_int * n)()
         reasons = (C.c_char_p * n)()
         first = len(self.descs)
-        rc = lib().mjh_decode_batch(self._h, bufs, lens, n, int(req_comp), int(threads), slots, reasons)
+        fn = lib().mjh_decode_batch_gpu if gpu_entropy else lib().mjh_decode_batch
+        fn.argtypes = lib().mjh_decode_batch.argtypes
+        rc = fn(self._h, bufs, lens, n, int(req_comp), int(threads), slots, reasons)
         if rc < 0:
             raise MijError("mjh_decode_batch: %s" % lib().mij_last_error().decode())
         out_slots = list(slots)

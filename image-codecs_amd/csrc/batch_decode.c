@@ -24,6 +24,12 @@ typedef struct {
 	mij_image_desc *descs;
 	int next, ok;
 	pthread_mutex_t lock;
+	/* GPU entropy front end */
+	mjg_scan *scans;
+	uint8_t *stage;
+	size_t *off, *cap, *slen;
+	int *status;      /* mjh_extract_scan's verdict per image */
+	const char *todo; /* per image: 1 = the host walk has to do it */
 } pool_t;
 
 static void *worker(void *arg)
@@ -40,7 +46,7 @@ static void *worker(void *arg)
 		if (i >= p->n)
 			break;
 		slot = p->slots[i];
-		if (slot < 0)
+		if (slot < 0 || (p->todo && !p->todo[i]))
 			continue;
 		d = p->descs[i];
 		{
@@ -102,6 +108,7 @@ int mjh_decode_batch(mij_batch *b, const uint8_t *const *bufs, const int *lens, 
 	p.reasons = reasons;
 	p.next = 0;
 	p.ok = 0;
+	p.todo = NULL;
 	pthread_mutex_init(&p.lock, NULL);
 	if (threads > n)
 		threads = n > 0 ? n : 1;
@@ -114,4 +121,150 @@ int mjh_decode_batch(mij_batch *b, const uint8_t *const *bufs, const int *lens, 
 	pthread_mutex_destroy(&p.lock);
 	free(p.descs);
 	return p.ok;
+}
+
+/* ------------------------------------------------------------------ the same with the Huffman walk on the GPU */
+
+static void *extract_worker(void *arg)
+{
+	pool_t *p = (pool_t *)arg;
+	for (;;) {
+		int i;
+		const char *why = NULL;
+		pthread_mutex_lock(&p->lock);
+		i = p->next++;
+		pthread_mutex_unlock(&p->lock);
+		if (i >= p->n)
+			break;
+		p->status[i] = mjh_extract_scan(p->bufs[i], p->lens[i], p->req_comp, &p->scans[i], p->stage + p->off[i], p->cap[i], &p->slen[i], &why);
+		p->reasons[i] = why;
+	}
+	return NULL;
+}
+
+static void run_pool(pool_t *p, void *(*fn)(void *), int threads)
+{
+	pthread_t tid[256];
+	int i, started = 0;
+	p->next = 0;
+	if (threads > p->n)
+		threads = p->n > 0 ? p->n : 1;
+	for (i = 1; i < threads; ++i)
+		if (pthread_create(&tid[started], NULL, fn, p) == 0)
+			++started;
+	fn(p);
+	for (i = 0; i < started; ++i)
+		pthread_join(tid[i], NULL);
+}
+
+int mjh_decode_batch_gpu(mij_batch *b, const uint8_t *const *bufs, const int *lens, int n, int req_comp, int threads, int *slots, const char **reasons)
+{
+	pool_t p;
+	size_t cap = 0, used = 0;
+	uint8_t *stage;
+	int i, rc = MIJ_OK, n_fb = 0, *fb = NULL, *img_of_slot = NULL, gpu_ok = 0, max_slot = -1;
+	char *todo = NULL;
+	if (!b || !bufs || !lens || !slots || !reasons || n < 0)
+		return MIJ_E_ARG;
+	stage = mij_batch_entropy_stage(b, &cap);
+	if (!stage)
+		return mjh_decode_batch(b, bufs, lens, n, req_comp, threads, slots, reasons); /* no entropy arena reserved */
+	if (threads < 1)
+		threads = 1;
+	if (threads > 256)
+		threads = 256;
+	memset(&p, 0, sizeof p);
+	p.b = b;
+	p.bufs = bufs;
+	p.lens = lens;
+	p.n = n;
+	p.req_comp = req_comp;
+	p.slots = slots;
+	p.reasons = reasons;
+	p.stage = stage;
+	p.scans = (mjg_scan *)malloc(sizeof(mjg_scan) * (size_t)(n > 0 ? n : 1));
+	p.descs = (mij_image_desc *)malloc(sizeof(mij_image_desc) * (size_t)(n > 0 ? n : 1));
+	p.off = (size_t *)malloc(sizeof(size_t) * 3 * (size_t)(n > 0 ? n : 1));
+	p.status = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+	todo = (char *)calloc((size_t)(n > 0 ? n : 1), 1);
+	fb = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+	if (!p.scans || !p.descs || !p.off || !p.status || !todo || !fb) {
+		rc = MIJ_E_NOMEM;
+		goto out;
+	}
+	p.cap = p.off + n;
+	p.slen = p.cap + n;
+	/* every image gets a region as large as its file: the unstuffed segment cannot be longer */
+	for (i = 0; i < n; ++i) {
+		const size_t need = ((size_t)(lens[i] > 0 ? lens[i] : 0) + 64 + 255) / 256 * 256;
+		p.off[i] = used;
+		p.cap[i] = need;
+		used += need;
+	}
+	if (used > cap) {
+		rc = MIJ_E_NOMEM;
+		goto out;
+	}
+	pthread_mutex_init(&p.lock, NULL);
+	run_pool(&p, extract_worker, threads);
+	/* slots in input order */
+	for (i = 0; i < n; ++i) {
+		p.descs[i] = p.scans[i].desc;
+		if (p.status[i] == 0) {
+			slots[i] = -1;
+			continue;
+		}
+		reasons[i] = NULL;
+		if (p.status[i] == 1)
+			slots[i] = mij_batch_add_stream(b, &p.scans[i], stage + p.off[i], p.slen[i]);
+		else {
+			slots[i] = mij_batch_add(b, &p.descs[i]);
+			todo[i] = 1;
+		}
+		if (slots[i] < 0) {
+			rc = slots[i];
+			pthread_mutex_destroy(&p.lock);
+			goto out;
+		}
+		if (slots[i] > max_slot)
+			max_slot = slots[i];
+	}
+	rc = mij_batch_entropy_run(b, fb, n, &n_fb);
+	if (rc != MIJ_OK) {
+		pthread_mutex_destroy(&p.lock);
+		goto out;
+	}
+	if (n_fb > 0) {
+		img_of_slot = (int *)malloc(sizeof(int) * (size_t)(max_slot + 1));
+		if (!img_of_slot) {
+			rc = MIJ_E_NOMEM;
+			pthread_mutex_destroy(&p.lock);
+			goto out;
+		}
+		for (i = 0; i < n; ++i)
+			if (slots[i] >= 0)
+				img_of_slot[slots[i]] = i;
+		for (i = 0; i < n_fb; ++i) {
+			mij_batch_fallback_prepare(b, fb[i]);
+			todo[img_of_slot[fb[i]]] = 1;
+		}
+	}
+	for (i = 0; i < n; ++i)
+		if (p.status[i] == 1 && !todo[i])
+			++gpu_ok;
+	/* the host walk for what the GPU did not take */
+	p.todo = todo;
+	p.ok = 0;
+	run_pool(&p, worker, threads);
+	pthread_mutex_destroy(&p.lock);
+	rc = gpu_ok + p.ok;
+out:
+	free(p.scans);
+	free(p.descs);
+	free(p.off);
+	free(p.status);
+	free(todo);
+	free(fb);
+	free(img_of_slot);
+	return rc;
 }

@@ -52,6 +52,12 @@ int mjh_extract_scan(const uint8_t *buf, int len, int req_comp, mjg_scan *scan, 
  */
 int mjh_decode_batch(mij_batch *b, const uint8_t *const *bufs, const int *lens, int n, int req_comp, int threads, int *slots, const char **reasons);
 
+/* The same contract with the Huffman walk on the GPU where it applies (mij_batch_entropy_reserve must have
+ * been called, otherwise this is mjh_decode_batch): the host threads only parse headers and remove byte
+ * stuffing, mij_batch_entropy_run walks the streams, and whatever it does not take or refuses is walked on
+ * the host as above.  Waits for the GPU walk; follow with mij_batch_submit(). */
+int mjh_decode_batch_gpu(mij_batch *b, const uint8_t *const *bufs, const int *lens, int n, int req_comp, int threads, int *slots, const char **reasons);
+
 /*
  * JPEG writer in three steps (stbi_write_jpg_to_func = plan + transform + emit); step 2 also exists
  * on the GPU (mij_enc_* in mij.h) and must produce the same data units bit for bit.

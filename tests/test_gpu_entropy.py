@@ -79,3 +79,41 @@ def test_gpu_walk_refuses_what_it_should(ica, oracle, gpu_ctx, golden):
     if kind == "ok":
         assert np.array_equal(b.fetch(s_bad), want)
     b.close()
+
+
+def test_batch_front_end_with_gpu_walk(golden, ica, oracle, gpu_ctx):
+    """mjh_decode_batch_gpu: same contract as the host-only front end -- rejected headers cost no slot, rejected
+    streams keep theirs and are skipped, layouts the GPU walk does not take (progressive, restart markers,
+    grey 4-component ...) and streams it refuses go through the host walk; every decoded image equals the oracle."""
+    datas = [ica.synth_jpeg(96 + 16 * i, 64 + 8 * i, i) for i in range(8)]
+    datas.insert(2, golden.jpg("garbage"))
+    datas.insert(5, golden.jpg("trunc_noeoi"))
+    datas.append(golden.jpg("prog_420_64x64"))
+    datas.append(golden.jpg("grey_33x20"))
+    datas.append(golden.jpg("big_b444_rst_250x130"))
+    datas.append(golden.jpg("big_b422_320x240"))
+    datas.append(ica.synth_jpeg(640, 480, 9, 95))
+    good = ica.synth_jpeg(320, 200, 5, 90)
+    bad = bytearray(good)
+    for k in range(len(bad) // 2, len(bad) // 2 + 24):
+        if bad[k] != 0xFF and bad[k - 1] != 0xFF:
+            bad[k] = (bad[k] * 7 + 13) % 255
+    datas.append(bytes(bad))
+    for req in (3, 4):
+        b = ica.Batch(gpu_ctx, len(datas), 64 << 20, 64 << 20, 64 << 20)
+        b.entropy_reserve(8 << 20)
+        ok, slots, reasons = b.decode_jpegs(datas, req, threads=4, gpu_entropy=True)
+        assert slots[2] == -1 and reasons[2] == "unknown image type"
+        b.submit()
+        b.wait()
+        n_ok = 0
+        for i, d in enumerate(datas):
+            kind, want, why = oracle.load(d, req)
+            if slots[i] >= 0:
+                assert kind == "ok", (i, why)
+                assert np.array_equal(b.fetch(slots[i]), want), (i, req)
+                n_ok += 1
+            elif slots[i] < -1:
+                assert kind == "fail" and reasons[i] == want, (i, reasons[i], want)
+        assert n_ok == ok
+        b.close()
