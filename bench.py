@@ -247,19 +247,23 @@ def main():
         # coefficients; images the GPU walk refuses are walked on the host
         try:
             for eb in ebs:
-                eb.reset()
-                eb.entropy_reserve(sum(len(x) + 512 for x in jl[:chunk]) * 2)
+                eb.close()
+            gchunk = max(1, min(int(os.environ.get("MIJ_BENCH_GPU_CHUNK", "128")), n_e // 2))
+            # no coefficient staging to speak of: it is only needed for images the GPU walk hands back
+            ebs = [ica.Batch(ctx, gchunk, cbytes * 4, cbytes * gchunk, obytes * gchunk) for _ in range(2)]
+            for eb in ebs:
+                eb.entropy_reserve(sum(len(x) + 512 for x in jl[:gchunk]) * 2)
             for eb in ebs:  # warm-up
                 eb.reset()
-                eb.decode_jpegs(jl[:chunk], 3, threads, gpu_entropy=True)
+                eb.decode_jpegs(jl[:gchunk], 3, threads, gpu_entropy=True)
                 eb.submit()
                 eb.wait()
             t0 = time.perf_counter()
-            n_gpu_ok = 0
-            for k, lo in enumerate(range(0, n_e, chunk)):
+            last = {}
+            for k, lo in enumerate(range(0, n_e, gchunk)):
                 eb = ebs[k & 1]
                 eb.reset()
-                part = jl[lo:lo + chunk]
+                part = jl[lo:lo + gchunk]
                 ok, slots, reasons = eb.decode_jpegs(part, 3, threads, gpu_entropy=True)
                 assert ok == len(part), reasons
                 eb.submit()
@@ -271,6 +275,7 @@ def main():
                 assert ebs[side].hash_out(slot) == src_hash[img % distinct], "GPU-walked image differs"
             e2e["value_gpu_entropy"] = round(n_e * W * H / t_gpu / 1e6, 1)
             e2e["gpu_entropy_sync_rounds"] = ebs[0].entropy_rounds()
+            e2e["gpu_entropy_chunk_images"] = gchunk
         except ica.MijError as exc:
             e2e["value_gpu_entropy"] = None
             e2e["gpu_entropy_error"] = str(exc)

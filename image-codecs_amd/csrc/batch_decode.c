@@ -245,7 +245,10 @@ int mjh_decode_batch_gpu(mij_batch *b, const uint8_t *const *bufs, const int *le
 			if (slots[i] >= 0)
 				img_of_slot[slots[i]] = i;
 		for (i = 0; i < n_fb; ++i) {
-			mij_batch_fallback_prepare(b, fb[i]);
+			if ((rc = mij_batch_fallback_prepare(b, fb[i])) != MIJ_OK) { /* no staging planes left for the host walk */
+				pthread_mutex_destroy(&p.lock);
+				goto out;
+			}
 			todo[img_of_slot[fb[i]]] = 1;
 		}
 	}

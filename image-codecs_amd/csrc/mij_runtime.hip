@@ -371,7 +371,11 @@ static void fill_dev_image(Slot &s, size_t coef_off, size_t out_off)
 	v.plane_bytes_total = plane_off;
 }
 
-static int add_common(mij_batch *b, const mij_image_desc *d, int clone_of)
+#define MIJ_NO_STAGE ((size_t)-1)
+
+/* lazy_stage: a slot of the GPU entropy stage -- its staging planes are only needed if the host walk has to
+ * redo it, so they are neither required nor cleared here (mij_batch_fallback_prepare does that) */
+static int add_common(mij_batch *b, const mij_image_desc *d, int clone_of, bool lazy_stage = false)
 {
 	if ((int)b->slots.size() >= b->max_images)
 		return set_err(MIJ_E_NOMEM, "batch is full (%d images)", b->max_images);
@@ -388,11 +392,16 @@ static int add_common(mij_batch *b, const mij_image_desc *d, int clone_of)
 	s.coef_bytes = cbytes;
 	s.path = 0;
 	if (clone_of < 0) {
-		if (b->stage_used + cbytes > b->stage_cap)
-			return set_err(MIJ_E_NOMEM, "staging arena exhausted");
-		s.stage_off = b->stage_used;
-		memset(b->stage + s.stage_off, 0, cbytes);
-		b->stage_used += cbytes;
+		if (b->stage_used + cbytes > b->stage_cap) {
+			if (!lazy_stage)
+				return set_err(MIJ_E_NOMEM, "staging arena exhausted");
+			s.stage_off = MIJ_NO_STAGE;
+		} else {
+			s.stage_off = b->stage_used;
+			if (!lazy_stage)
+				memset(b->stage + s.stage_off, 0, cbytes);
+			b->stage_used += cbytes;
+		}
 	} else {
 		s.stage_off = b->slots[(size_t)clone_of].stage_off;
 	}
@@ -430,7 +439,7 @@ extern "C" int16_t *mij_batch_coef(mij_batch *b, int slot, int comp)
 		return nullptr;
 	}
 	const Slot &s = b->slots[(size_t)slot];
-	if (comp < 0 || comp >= s.desc.ncomp || s.clone_of >= 0 || !b->stage) {
+	if (comp < 0 || comp >= s.desc.ncomp || s.clone_of >= 0 || !b->stage || s.stage_off == MIJ_NO_STAGE) {
 		set_err(MIJ_E_ARG, "bad component, or slot has no staging of its own");
 		return nullptr;
 	}
@@ -1101,7 +1110,7 @@ extern "C" int mij_batch_add_stream(mij_batch *b, const mjg_scan *scan, uint8_t 
 	const size_t nsub = (stream_len * 8 + MIJ_ES_BITS - 1) / MIJ_ES_BITS;
 	if (e->sub_used + nsub + 1 > e->sub_cap || e->blk_used + scan->nblocks > e->blk_cap || e->work_used + nsub / 256 + 1 > e->work_cap)
 		return set_err(MIJ_E_NOMEM, "entropy arena exhausted");
-	const int slot = add_common(b, &scan->desc, -1);
+	const int slot = add_common(b, &scan->desc, -1, true);
 	if (slot < 0)
 		return slot;
 	Slot &s = b->slots[(size_t)slot];
@@ -1245,6 +1254,8 @@ extern "C" int mij_batch_fallback_prepare(mij_batch *b, int slot)
 	Slot &s = b->slots[(size_t)slot];
 	if (!s.dev_coef)
 		return MIJ_OK;
+	if (s.stage_off == MIJ_NO_STAGE)
+		return set_err(MIJ_E_NOMEM, "slot %d has no staging planes (the staging arena was too small when it was added)", slot);
 	s.dev_coef = 0;
 	s.desc.flags &= ~(uint32_t)MIJ_FLAG_WIDE_IDCT;
 	memset(b->stage + s.stage_off, 0, s.coef_bytes);
