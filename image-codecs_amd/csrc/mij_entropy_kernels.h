@@ -124,6 +124,7 @@ struct EsWriter { /* where the blocks of the write pass go */
 	uint32_t mx, my;     /* its MCU */
 	int16_t *blk;        /* its tile slot */
 	uint32_t acc;        /* L1 of the AC coefficients written by this thread into it */
+	uint32_t *pfinal;    /* where the bit position after the scan's last block is recorded */
 	__device__ __forceinline__ void locate(uint32_t c)
 	{
 		const uint32_t ci = sc->blk_comp[c];
@@ -220,7 +221,8 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const DevHuff *
 				if (wr->acc)
 					atomicAdd(&wr->l1[wr->ord], wr->acc);
 				wr->acc = 0;
-				++wr->ord;
+				if (++wr->ord == sc.nblocks)
+					*wr->pfinal = s.p;
 			}
 			if (++s.c == sc.bpm) {
 				s.c = 0;
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(256) void k_es_offsets(const DevScan *__restrict__ 
 __global__ __launch_bounds__(256) void k_es_write(const DevScan *__restrict__ scans, const EsWork *__restrict__ work, const DevHuff *__restrict__ huff,
 																  const uint8_t *__restrict__ streams, const DevImage *__restrict__ imgs, const uint64_t *__restrict__ start,
 																  const uint32_t *__restrict__ base, int16_t *__restrict__ coef, int16_t *__restrict__ dcdiff, uint32_t *__restrict__ l1,
-																  uint32_t *__restrict__ anom)
+																  uint32_t *__restrict__ anom, uint32_t *__restrict__ pfinal)
 {
 	__shared__ DevHuff tabs[8];
 	__shared__ uint16_t toff[64];
@@ -366,6 +368,7 @@ __global__ __launch_bounds__(256) void k_es_write(const DevScan *__restrict__ sc
 	wr.toff = toff;
 	wr.ord = base[slot];
 	wr.acc = 0;
+	wr.pfinal = &pfinal[wk.scan];
 	if (wr.ord >= sc.nblocks)
 		return;
 	const uint32_t m = wr.ord / sc.bpm;
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(256) void k_es_write(const DevScan *__restrict__ sc
 __global__ __launch_bounds__(256) void k_es_dc(const DevScan *__restrict__ scans, const DevImage *__restrict__ imgs, const uint64_t *__restrict__ end,
 															  const uint32_t *__restrict__ total, const uint32_t *__restrict__ changed, int16_t *__restrict__ coef,
 															  const int16_t *__restrict__ dcdiff, const uint32_t *__restrict__ l1, uint32_t *__restrict__ anom,
-															  uint32_t *__restrict__ l1max)
+															  uint32_t *__restrict__ l1max, const uint32_t *__restrict__ pfinal, const uint8_t *__restrict__ streams)
 {
 	__shared__ int part[256][4];
 	__shared__ uint32_t wmax[256];
@@ -402,6 +405,19 @@ __global__ __launch_bounds__(256) void k_es_dc(const DevScan *__restrict__ scans
 			atomicOr(&anom[blockIdx.x], 4u); /* the stream ends before the last block */
 		if (changed[blockIdx.x])
 			atomicOr(&anom[blockIdx.x], 8u); /* the last synchronisation round still moved something */
+	}
+	/* After its last block the reference skips ahead to the next 0xff and takes the byte behind it for a marker
+	 * (codec/jpeg.c:1727-1737): a stuffed 0xff00 left over in unread data makes it fail with "unknown marker".
+	 * How many bytes its 32-bit look-ahead had already taken is not tracked here, so any 0xff data byte behind
+	 * the byte of the final bit position sends the image to the host walk. */
+	{
+		const uint8_t *st = streams + sc.stream_off;
+		const uint32_t nbytes = sc.nbits >> 3;
+		uint32_t found = 0;
+		for (uint32_t q = ((pfinal[blockIdx.x] + 7u) >> 3) + threadIdx.x; q < nbytes; q += 256) /* the byte holding the last bit was certainly read */
+			found |= st[q] == 0xffu;
+		if (found)
+			atomicOr(&anom[blockIdx.x], 32u);
 	}
 	int sum[4] = {0, 0, 0, 0};
 	for (uint32_t m = lo; m < hi; ++m)

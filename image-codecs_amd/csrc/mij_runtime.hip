@@ -1004,7 +1004,7 @@ struct EsArena {
 	int16_t *d_dcdiff;
 	uint32_t *d_l1;
 	size_t blk_cap;
-	uint32_t *d_verdict, *h_verdict; /* [4][max_images]: anomaly, changed, total, l1max */
+	uint32_t *d_verdict, *h_verdict; /* [5][max_images]: anomaly, changed, total, l1max, final bit position */
 	uint32_t *d_rounds_changed, *h_rounds_changed; /* [MAX_ROUNDS] sum over scans, for tuning */
 	std::vector<int> scan_slot; /* scan index -> batch slot */
 	size_t sub_used, blk_used, work_used;
@@ -1077,8 +1077,8 @@ extern "C" int mij_batch_entropy_reserve(mij_batch *b, size_t stream_bytes)
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_cnt), sizeof(uint32_t) * e->sub_cap);
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_dcdiff), sizeof(int16_t) * e->blk_cap);
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_l1), sizeof(uint32_t) * e->blk_cap);
-	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_verdict), sizeof(uint32_t) * 4 * n);
-	if (r == hipSuccess) r = hipHostMalloc(reinterpret_cast<void **>(&e->h_verdict), sizeof(uint32_t) * 4 * n, hipHostMallocDefault);
+	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_verdict), sizeof(uint32_t) * 5 * n);
+	if (r == hipSuccess) r = hipHostMalloc(reinterpret_cast<void **>(&e->h_verdict), sizeof(uint32_t) * 5 * n, hipHostMallocDefault);
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_rounds_changed), sizeof(uint32_t) * ES_MAX_ROUNDS);
 	if (r == hipSuccess) r = hipHostMalloc(reinterpret_cast<void **>(&e->h_rounds_changed), sizeof(uint32_t) * ES_MAX_ROUNDS, hipHostMallocDefault);
 	if (r != hipSuccess) {
@@ -1187,10 +1187,10 @@ extern "C" int mij_batch_entropy_run(mij_batch *b, int *fallback, int cap, int *
 		k = j;
 	}
 	HIP_TRY(hipMemsetAsync(e->d_l1, 0, sizeof(uint32_t) * e->blk_used, st));
-	HIP_TRY(hipMemsetAsync(e->d_verdict, 0, sizeof(uint32_t) * 4 * (size_t)b->max_images, st));
+	HIP_TRY(hipMemsetAsync(e->d_verdict, 0, sizeof(uint32_t) * 5 * (size_t)b->max_images, st));
 	HIP_TRY(hipMemsetAsync(e->d_rounds_changed, 0, sizeof(uint32_t) * ES_MAX_ROUNDS, st));
 	uint32_t *v_anom = e->d_verdict, *v_changed = e->d_verdict + b->max_images, *v_total = e->d_verdict + 2 * (size_t)b->max_images,
-				*v_l1 = e->d_verdict + 3 * (size_t)b->max_images;
+				*v_l1 = e->d_verdict + 3 * (size_t)b->max_images, *v_pfinal = e->d_verdict + 4 * (size_t)b->max_images;
 	const dim3 gw((unsigned)e->work_used), gs((unsigned)ns), blk(256);
 	hipLaunchKernelGGL(k_es_cold, gw, blk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, e->d_start, e->d_end[0], e->d_cnt);
 	HIP_TRY(hipGetLastError());
@@ -1218,10 +1218,10 @@ extern "C" int mij_batch_entropy_run(mij_batch *b, int *fallback, int cap, int *
 	hipLaunchKernelGGL(k_es_offsets, gs, blk, 0, st, e->d_scans, e->d_cnt, v_total);
 	HIP_TRY(hipGetLastError());
 	hipLaunchKernelGGL(k_es_write, gw, blk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, b->d_imgs, e->d_start, e->d_cnt,
-							 reinterpret_cast<int16_t *>(b->d_coef), e->d_dcdiff, e->d_l1, v_anom);
+							 reinterpret_cast<int16_t *>(b->d_coef), e->d_dcdiff, e->d_l1, v_anom, v_pfinal);
 	HIP_TRY(hipGetLastError());
 	hipLaunchKernelGGL(k_es_dc, gs, blk, 0, st, e->d_scans, b->d_imgs, e->d_end[cur], v_total, v_changed, reinterpret_cast<int16_t *>(b->d_coef), e->d_dcdiff, e->d_l1,
-							 v_anom, v_l1);
+							 v_anom, v_l1, v_pfinal, e->d_stream);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipMemcpyAsync(e->h_verdict, e->d_verdict, sizeof(uint32_t) * 4 * (size_t)b->max_images, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));

@@ -117,3 +117,35 @@ def test_batch_front_end_with_gpu_walk(golden, ica, oracle, gpu_ctx):
                 assert kind == "fail" and reasons[i] == want, (i, reasons[i], want)
         assert n_ok == ok
         b.close()
+
+
+def test_gpu_walk_fuzzed_streams_vs_oracle(golden, ica, oracle, gpu_ctx):
+    """Damaged entropy segments through the GPU front end: whatever the GPU walk accepts must be what the
+    reference semantics give, everything else must have come back for the host walk -- accept/reject, reason
+    and pixels equal to the oracle for every stream."""
+    import helpers
+    bases = [ica.synth_jpeg(160, 120, 1, 90), ica.synth_jpeg(97, 131, 2, 75), ica.synth_jpeg(64, 64, 3, 95), golden.jpg("b420_64x64_q90"), golden.jpg("grey_33x20")]
+    datas = []
+    for k in range(180):
+        base = bases[k % len(bases)]
+        datas.append(helpers.mutate(base, 1000 + k, n_mut=1 + k % 4, allow_markers=(k % 3 == 0)))
+    n_gpu = n_fail = 0
+    for lo in range(0, len(datas), 60):
+        part = datas[lo:lo + 60]
+        b = ica.Batch(gpu_ctx, len(part), 16 << 20, 16 << 20, 16 << 20)
+        b.entropy_reserve(4 << 20)
+        ok, slots, reasons = b.decode_jpegs(part, 3, threads=4, gpu_entropy=True)
+        b.submit()
+        b.wait()
+        for i, d in enumerate(part):
+            kind, want, _ = oracle.load(d, 3)
+            if slots[i] >= 0:
+                assert kind == "ok", (lo + i, want)
+                assert np.array_equal(b.fetch(slots[i]), want), lo + i
+                n_gpu += 1
+            else:
+                assert kind == "fail", lo + i
+                assert reasons[i] == want, (lo + i, reasons[i], want)
+                n_fail += 1
+        b.close()
+    assert n_gpu > 100
