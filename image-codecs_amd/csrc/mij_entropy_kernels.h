@@ -119,7 +119,11 @@ struct EsWriter { /* where the blocks of the write pass go */
 	int16_t *coef;       /* coefficient arena (tile layout) */
 	int16_t *dcdiff;     /* per block */
 	uint32_t *l1;        /* per block */
-	const uint16_t *toff; /* zigzag index -> element offset inside the block's tile slot */
+	const uint16_t *toff; /* zigzag index -> element offset inside the block's tile slot (scatter mode) */
+	const uint8_t *zpos;  /* zigzag index -> position in the block's 64-element tile-order image (staged mode) */
+	int16_t *buf;         /* LDS: the current block in tile order, all zero between blocks; NULL = scatter mode */
+	bool skip;            /* the block in progress was begun by the previous subsequence: k_es_tails stores its rest */
+	bool stop_after_block;
 	uint32_t ord;        /* ordinal of the current block */
 	uint32_t mx, my;     /* its MCU */
 	int16_t *blk;        /* its tile slot */
@@ -132,6 +136,24 @@ struct EsWriter { /* where the blocks of the write pass go */
 		const uint32_t bx = mx * (uint32_t)cp.h + sc->blk_dx[c], by = my * (uint32_t)cp.v + sc->blk_dy[c];
 		const uint32_t L = bx + by * (uint32_t)cp.bw;
 		blk = reinterpret_cast<int16_t *>(reinterpret_cast<uint8_t *>(coef) + cp.coef_off) + ((size_t)(L >> 6) << 12) + ((L & 63u) << 3);
+	}
+	/* the staged block -> its eight 16-byte chunks in the tile (complete, zeros included: the planes need no clearing) */
+	__device__ __forceinline__ void flush()
+	{
+#pragma unroll
+		for (int c = 0; c < 8; ++c) {
+			uint4 *src = reinterpret_cast<uint4 *>(buf + 8 * c);
+			const uint4 v = *src;
+			*src = make_uint4(0, 0, 0, 0);
+			__builtin_nontemporal_store((u4v){v.x, v.y, v.z, v.w}, reinterpret_cast<u4v *>(blk + (c << 9)));
+		}
+	}
+	__device__ __forceinline__ void put(uint32_t k, int v)
+	{
+		if (buf)
+			buf[zpos[k]] = (int16_t)v;
+		else
+			blk[toff[k]] = (int16_t)v;
 	}
 };
 
@@ -202,8 +224,8 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const DevHuff *
 					s.z = 64;
 				} else {
 					const int v = es_extend(win, len, n);
-					if (WRITE) {
-						wr->blk[wr->toff[k]] = (int16_t)v;
+					if (WRITE && !wr->skip) {
+						wr->put(k, v);
 						const int dq = (int)(int16_t)((uint32_t)v * sc.qz[ci][k]);
 						wr->acc += (uint32_t)(dq < 0 ? -dq : dq);
 					}
@@ -218,9 +240,16 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const DevHuff *
 			if (WRITE) {
 				if (s.p > sc.nbits)
 					atomicOr(anom, 16u); /* the data ran out inside this block: the reference decodes on with zero bits */
+				if (!wr->skip && wr->buf)
+					wr->flush();
 				if (wr->acc)
 					atomicAdd(&wr->l1[wr->ord], wr->acc);
 				wr->acc = 0;
+				if (wr->stop_after_block) { /* k_es_tails: only the rest of the block the subsequence started in */
+					s.z = 0;
+					break;
+				}
+				wr->skip = false;
 				if (++wr->ord == sc.nblocks)
 					*wr->pfinal = s.p;
 			}
@@ -241,8 +270,12 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const DevHuff *
 			break;
 		}
 	}
-	if (WRITE && wr->acc && wr->ord < sc.nblocks)
-		atomicAdd(&wr->l1[wr->ord], wr->acc);
+	if (WRITE && wr->ord < sc.nblocks && !wr->skip) { /* a block that continues in the next subsequence: its head goes out now */
+		if (wr->buf && s.z != 0 && s.z != MIJ_ES_DEAD)
+			wr->flush();
+		if (wr->acc)
+			atomicAdd(&wr->l1[wr->ord], wr->acc);
+	}
 	return done;
 }
 
@@ -340,19 +373,22 @@ __global__ __launch_bounds__(256) void k_es_offsets(const DevScan *__restrict__ 
 	}
 }
 
+#define MIJ_ES_BUFPITCH 144 /* bytes per thread in the block staging area: 128 + 16 keeps 16-byte accesses of neighbours in different banks */
+
 __global__ __launch_bounds__(256) void k_es_write(const DevScan *__restrict__ scans, const EsWork *__restrict__ work, const DevHuff *__restrict__ huff,
 																  const uint8_t *__restrict__ streams, const DevImage *__restrict__ imgs, const uint64_t *__restrict__ start,
 																  const uint32_t *__restrict__ base, int16_t *__restrict__ coef, int16_t *__restrict__ dcdiff, uint32_t *__restrict__ l1,
 																  uint32_t *__restrict__ anom, uint32_t *__restrict__ pfinal)
 {
 	__shared__ DevHuff tabs[8];
-	__shared__ uint16_t toff[64];
+	__shared__ uint8_t zpos[64];
+	__shared__ __attribute__((aligned(16))) uint8_t stage[256 * MIJ_ES_BUFPITCH];
 	const EsWork wk = work[blockIdx.x];
 	const DevScan &sc = scans[wk.scan];
-	if (threadIdx.x < 64) {
-		const uint32_t P = mij_zigzag_pos[threadIdx.x];
-		toff[threadIdx.x] = (uint16_t)(((P >> 3) << 9) + (P & 7u));
-	}
+	if (threadIdx.x < 64)
+		zpos[threadIdx.x] = mij_zigzag_pos[threadIdx.x];
+	for (uint32_t i = threadIdx.x; i < 256u * MIJ_ES_BUFPITCH / 16u; i += 256)
+		reinterpret_cast<uint4 *>(stage)[i] = make_uint4(0, 0, 0, 0);
 	es_load_tables(huff + sc.tab_off, tabs);
 	const uint32_t i = wk.first + threadIdx.x;
 	if (i >= sc.nsub)
@@ -365,7 +401,11 @@ __global__ __launch_bounds__(256) void k_es_write(const DevScan *__restrict__ sc
 	wr.coef = coef;
 	wr.dcdiff = dcdiff + sc.blk_off;
 	wr.l1 = l1 + sc.blk_off;
-	wr.toff = toff;
+	wr.toff = nullptr;
+	wr.zpos = zpos;
+	wr.buf = reinterpret_cast<int16_t *>(stage + threadIdx.x * MIJ_ES_BUFPITCH);
+	wr.skip = s.z != 0; /* begun by the previous subsequence */
+	wr.stop_after_block = false;
 	wr.ord = base[slot];
 	wr.acc = 0;
 	wr.pfinal = &pfinal[wk.scan];
@@ -381,6 +421,55 @@ __global__ __launch_bounds__(256) void k_es_write(const DevScan *__restrict__ sc
 	wr.locate(s.c);
 	const uint32_t pe = min((i + 1u) * MIJ_ES_BITS, sc.nbits);
 	es_decode<true>(sc, tabs, streams + sc.stream_off, s, pe, &wr, &anom[wk.scan]);
+}
+
+/* the rest of every block that began in the previous subsequence: single coefficients into the block that the
+ * previous thread's k_es_write stored whole (stream order makes this the later write) */
+__global__ __launch_bounds__(256) void k_es_tails(const DevScan *__restrict__ scans, const EsWork *__restrict__ work, const DevHuff *__restrict__ huff,
+																  const uint8_t *__restrict__ streams, const DevImage *__restrict__ imgs, const uint64_t *__restrict__ start,
+																  const uint32_t *__restrict__ base, int16_t *__restrict__ coef, int16_t *__restrict__ dcdiff, uint32_t *__restrict__ l1,
+																  uint32_t *__restrict__ scratch)
+{
+	__shared__ DevHuff tabs[8];
+	__shared__ uint16_t toff[64];
+	const EsWork wk = work[blockIdx.x];
+	const DevScan &sc = scans[wk.scan];
+	if (threadIdx.x < 64) {
+		const uint32_t P = mij_zigzag_pos[threadIdx.x];
+		toff[threadIdx.x] = (uint16_t)(((P >> 3) << 9) + (P & 7u));
+	}
+	es_load_tables(huff + sc.tab_off, tabs);
+	const uint32_t i = wk.first + threadIdx.x;
+	if (i >= sc.nsub)
+		return;
+	const uint32_t slot = sc.sub_off + i;
+	EsState s = es_unpack(start[slot]);
+	if (s.z == 0 || s.z == MIJ_ES_DEAD)
+		return;
+	EsWriter wr;
+	wr.sc = &sc;
+	wr.im = &imgs[sc.img];
+	wr.coef = coef;
+	wr.dcdiff = dcdiff + sc.blk_off;
+	wr.l1 = l1 + sc.blk_off;
+	wr.toff = toff;
+	wr.zpos = nullptr;
+	wr.buf = nullptr;
+	wr.skip = false;
+	wr.stop_after_block = true;
+	wr.ord = base[slot];
+	wr.acc = 0;
+	wr.pfinal = scratch; /* never reached: the walk stops at the end of this block */
+	if (wr.ord >= sc.nblocks)
+		return;
+	const uint32_t m = wr.ord / sc.bpm;
+	if (wr.ord - m * sc.bpm != s.c)
+		return;
+	wr.my = m / sc.mcu_x;
+	wr.mx = m - wr.my * sc.mcu_x;
+	wr.locate(s.c);
+	/* k_es_write walked the same symbols and reported what there was to report: verdict bits go to a scratch word */
+	es_decode<true>(sc, tabs, streams + sc.stream_off, s, sc.nbits, &wr, scratch + 1);
 }
 
 /* DC prediction (codec/jpeg.c:323-325), L1 bound and the completion checks; one workgroup per scan */

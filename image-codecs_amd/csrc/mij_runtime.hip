@@ -1175,17 +1175,8 @@ extern "C" int mij_batch_entropy_run(mij_batch *b, int *fallback, int cap, int *
 		hi = end > hi ? end : hi;
 	}
 	HIP_TRY(hipMemcpyAsync(e->d_stream + lo, e->stage + lo, hi - lo, hipMemcpyHostToDevice, st));
-	/* zero the coefficient planes the walk will fill (runs of adjacent slots in one memset), the L1 accumulators, the verdicts */
-	for (size_t k = 0; k < ns;) {
-		const Slot &s0 = b->slots[(size_t)e->scan_slot[k]];
-		size_t bytes = s0.coef_bytes, j = k + 1;
-		while (j < ns && b->slots[(size_t)e->scan_slot[j]].dev.comp[0].coef_off == s0.dev.comp[0].coef_off + bytes) {
-			bytes += b->slots[(size_t)e->scan_slot[j]].coef_bytes;
-			++j;
-		}
-		HIP_TRY(hipMemsetAsync(b->d_coef + s0.dev.comp[0].coef_off, 0, bytes, st));
-		k = j;
-	}
+	/* the write pass stores every block of the MCU grid whole, so the coefficient planes need no clearing;
+	 * the L1 accumulators and the verdicts do */
 	HIP_TRY(hipMemsetAsync(e->d_l1, 0, sizeof(uint32_t) * e->blk_used, st));
 	HIP_TRY(hipMemsetAsync(e->d_verdict, 0, sizeof(uint32_t) * 5 * (size_t)b->max_images, st));
 	HIP_TRY(hipMemsetAsync(e->d_rounds_changed, 0, sizeof(uint32_t) * ES_MAX_ROUNDS, st));
@@ -1219,6 +1210,9 @@ extern "C" int mij_batch_entropy_run(mij_batch *b, int *fallback, int cap, int *
 	HIP_TRY(hipGetLastError());
 	hipLaunchKernelGGL(k_es_write, gw, blk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, b->d_imgs, e->d_start, e->d_cnt,
 							 reinterpret_cast<int16_t *>(b->d_coef), e->d_dcdiff, e->d_l1, v_anom, v_pfinal);
+	HIP_TRY(hipGetLastError());
+	hipLaunchKernelGGL(k_es_tails, gw, blk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, b->d_imgs, e->d_start, e->d_cnt,
+							 reinterpret_cast<int16_t *>(b->d_coef), e->d_dcdiff, e->d_l1, e->d_rounds_changed);
 	HIP_TRY(hipGetLastError());
 	hipLaunchKernelGGL(k_es_dc, gs, blk, 0, st, e->d_scans, b->d_imgs, e->d_end[cur], v_total, v_changed, reinterpret_cast<int16_t *>(b->d_coef), e->d_dcdiff, e->d_l1,
 							 v_anom, v_l1, v_pfinal, e->d_stream);

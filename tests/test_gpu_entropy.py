@@ -30,7 +30,9 @@ def test_gpu_walk_equals_host_walk(ica, oracle, gpu_ctx, golden):
     for d, s in zip(datas, slots):
         desc, want = _host_planes(ica, d, 3)
         got = b.fetch_coef(s)
-        assert np.array_equal(got, want), (s, int((got != want).sum()))
+        # block by block over the MCU grid (tile slots past the last block are never read and never written)
+        for ci, (pg, pw) in enumerate(zip(ica.detile_coefficients(desc, got), ica.detile_coefficients(desc, want))):
+            assert np.array_equal(pg, pw), (s, ci, int((pg != pw).sum()))
     b.submit()
     b.wait()
     for d, s in zip(datas, slots):
