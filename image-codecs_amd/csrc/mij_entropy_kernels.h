@@ -12,14 +12,15 @@
  *                    started from last time; the true chain from subsequence 0 wins; stops changing after a
  *                    few rounds because wrong starts re-synchronise inside one subsequence
  *   3. k_es_offsets  prefix sum of the blocks completed per subsequence -> the block ordinal each one starts at
- *   4. k_es_write    decode once more, now knowing where every coefficient goes: quantised coefficients into
- *                    the tile-layout planes (mij.h) the IDCT kernels read, DC differences aside
+ *   4. k_es_write    decode once more, now knowing where every coefficient goes: each block is staged in LDS in
+ *                    tile order and stored whole into the tile-layout planes (mij.h) the IDCT kernels read,
+ *                    DC differences aside; k_es_tails adds the rest of blocks that began in the previous subsequence
  *   5. k_es_dc       per component running sum of the DC differences (codec/jpeg.c:323-325), per-block L1
- *                    bound (MIJ_FLAG_WIDE_IDCT), completion checks
+ *                    bound (MIJ_FLAG_WIDE_IDCT), completion checks, the left-over-0xff rule
  * Symbol decoding is the reference's (codec/jpeg.c:193-265: 9-bit fast table, maxcode/delta slow path,
  * extend_receive), so a well-formed stream yields exactly the host walk's coefficients.  Anything else --
- * an invalid code, a run past coefficient 63, a DC category above 11, a stream that ends early, no
- * convergence -- raises the image's anomaly flag and the caller re-does that image on the host, whose
+ * an invalid code, a run past coefficient 63, a DC category above 11, a stream that ends early, unread data
+ * that still holds a stuffed 0xff (the reference then fails with "unknown marker"), no convergence -- raises the image's anomaly flag and the caller re-does that image on the host, whose
  * behaviour on malformed input is the reference's.
  */
 #ifndef MIJ_ENTROPY_KERNELS_H
@@ -473,8 +474,7 @@ __global__ __launch_bounds__(256) void k_es_tails(const DevScan *__restrict__ sc
 }
 
 /* DC prediction (codec/jpeg.c:323-325), L1 bound and the completion checks; one workgroup per scan */
-__global__ __launch_bounds__(256) void k_es_dc(const DevScan *__restrict__ scans, const DevImage *__restrict__ imgs, const uint64_t *__restrict__ end,
-															  const uint32_t *__restrict__ total, const uint32_t *__restrict__ changed, int16_t *__restrict__ coef,
+__global__ __launch_bounds__(256) void k_es_dc(const DevScan *__restrict__ scans, const DevImage *__restrict__ imgs, const uint32_t *__restrict__ total, const uint32_t *__restrict__ changed, int16_t *__restrict__ coef,
 															  const int16_t *__restrict__ dcdiff, const uint32_t *__restrict__ l1, uint32_t *__restrict__ anom,
 															  uint32_t *__restrict__ l1max, const uint32_t *__restrict__ pfinal, const uint8_t *__restrict__ streams)
 {
@@ -488,8 +488,6 @@ __global__ __launch_bounds__(256) void k_es_dc(const DevScan *__restrict__ scans
 	const int16_t *dd = dcdiff + sc.blk_off;
 	const uint32_t *bl1 = l1 + sc.blk_off;
 	if (threadIdx.x == 0) {
-		const EsState last = es_unpack(end[sc.sub_off + sc.nsub - 1u]);
-		(void)last;
 		if (total[blockIdx.x] < sc.nblocks)
 			atomicOr(&anom[blockIdx.x], 4u); /* the stream ends before the last block */
 		if (changed[blockIdx.x])

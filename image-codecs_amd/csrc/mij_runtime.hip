@@ -1214,7 +1214,7 @@ extern "C" int mij_batch_entropy_run(mij_batch *b, int *fallback, int cap, int *
 	hipLaunchKernelGGL(k_es_tails, gw, blk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, b->d_imgs, e->d_start, e->d_cnt,
 							 reinterpret_cast<int16_t *>(b->d_coef), e->d_dcdiff, e->d_l1, e->d_rounds_changed);
 	HIP_TRY(hipGetLastError());
-	hipLaunchKernelGGL(k_es_dc, gs, blk, 0, st, e->d_scans, b->d_imgs, e->d_end[cur], v_total, v_changed, reinterpret_cast<int16_t *>(b->d_coef), e->d_dcdiff, e->d_l1,
+	hipLaunchKernelGGL(k_es_dc, gs, blk, 0, st, e->d_scans, b->d_imgs, v_total, v_changed, reinterpret_cast<int16_t *>(b->d_coef), e->d_dcdiff, e->d_l1,
 							 v_anom, v_l1, v_pfinal, e->d_stream);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipMemcpyAsync(e->h_verdict, e->d_verdict, sizeof(uint32_t) * 4 * (size_t)b->max_images, hipMemcpyDeviceToHost, st));
