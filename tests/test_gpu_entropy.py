@@ -151,3 +151,39 @@ def test_gpu_walk_fuzzed_streams_vs_oracle(golden, ica, oracle, gpu_ctx):
                 n_fail += 1
         b.close()
     assert n_gpu > 100
+
+
+def test_wide_streams_in_every_fused_family_and_through_the_gpu_walk(golden, ica, oracle, gpu_ctx):
+    """Quantisation tables blown up so that the first IDCT pass overflows int16: the exact (WIDE) instantiation of
+    each fused kernel -- 4:2:0, 4:2:2, 4:4:4, grey -- must equal the reference's wrapping arithmetic, whether the
+    flag was raised by the host walk or by the GPU walk's per-block bound."""
+    datas = []
+    for name in ("b420_64x64_q90", "big_b422_320x240", "b444_40x24_q95", "grey_33x20"):
+        data = bytearray(golden.jpg(name))
+        rng = np.random.default_rng(len(name))
+        pos = 0
+        while True:  # every DQT segment
+            pos = bytes(data).find(b"\xff\xdb", pos)
+            if pos < 0:
+                break
+            length = int.from_bytes(data[pos + 2:pos + 4], "big")
+            for t in range((length - 2) // 65):
+                for k in range(64):
+                    data[pos + 5 + 65 * t + k] = int(rng.integers(100, 256))
+            pos += 2 + length
+        datas.append(bytes(data))
+    wants = [oracle.load(d, 3)[1] for d in datas]
+    flags = [ica.HostDecoder.decode(d, 3)[0].flags & 1 for d in datas]
+    assert sum(flags) >= 3
+    expect_path = [1, 4, 3, 5]
+    for gpu_entropy in (False, True):
+        b = ica.Batch(gpu_ctx, len(datas), 16 << 20, 16 << 20, 16 << 20)
+        b.entropy_reserve(1 << 20)
+        ok, slots, reasons = b.decode_jpegs(datas, 3, threads=2, gpu_entropy=gpu_entropy)
+        assert ok == len(datas), reasons
+        b.submit()
+        b.wait()
+        for s, want, path in zip(slots, wants, expect_path):
+            assert b.slot_path(s) == path
+            assert np.array_equal(b.fetch(s), want), (gpu_entropy, path)
+        b.close()
