@@ -260,14 +260,24 @@ def main():
                 eb.wait()
             t0 = time.perf_counter()
             last = {}
+            pending = None  # (side, job, first image): its GPU walk runs while the next chunk's headers are parsed
             for k, lo in enumerate(range(0, n_e, gchunk)):
                 eb = ebs[k & 1]
                 eb.reset()
                 part = jl[lo:lo + gchunk]
-                ok, slots, reasons = eb.decode_jpegs(part, 3, threads, gpu_entropy=True)
-                assert ok == len(part), reasons
-                eb.submit()
-                last[k & 1] = (lo + len(part) - 1, slots[len(part) - 1])
+                job = eb.decode_jpegs_gpu_begin(part, 3, threads)
+                if pending is not None:
+                    side, pjob, plo, plen = pending
+                    ok, slots, reasons = ebs[side].decode_jpegs_gpu_end(pjob)
+                    assert ok == plen, reasons
+                    ebs[side].submit()
+                    last[side] = (plo + plen - 1, slots[plen - 1])
+                pending = (k & 1, job, lo, len(part))
+            side, pjob, plo, plen = pending
+            ok, slots, reasons = ebs[side].decode_jpegs_gpu_end(pjob)
+            assert ok == plen, reasons
+            ebs[side].submit()
+            last[side] = (plo + plen - 1, slots[plen - 1])
             for eb in ebs:
                 eb.wait()
             t_gpu = time.perf_counter() - t0

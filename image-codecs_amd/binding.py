@@ -411,6 +411,35 @@ class Batch:
                 self.descs.append(HostDecoder.probe(datas[i], req_comp))
         return rc, out_slots, [r.decode() if r else None for r in reasons]
 
+    def decode_jpegs_gpu_begin(self, datas, req_comp=0, threads=1):
+        """mjh_decode_batch_gpu_begin: headers + unstuffing on the host threads, GPU walk queued; returns a job
+        to pass to decode_jpegs_gpu_end (which waits for the walk and host-walks what it handed back)."""
+        L = lib()
+        n = len(datas)
+        job = {"datas": datas, "req": req_comp, "first": len(self.descs),
+               "bufs": (C.c_char_p * n)(*[bytes(d) for d in datas]), "lens": (C.c_int * n)(*[len(d) for d in datas]),
+               "slots": (C.c_int * n)(), "reasons": (C.c_char_p * n)(), "rc": C.c_int()}
+        L.mjh_decode_batch_gpu_begin.restype = C.c_void_p
+        L.mjh_decode_batch_gpu_begin.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
+                                                 C.POINTER(C.c_char_p), C.POINTER(C.c_int)]
+        job["h"] = L.mjh_decode_batch_gpu_begin(self._h, job["bufs"], job["lens"], n, int(req_comp), int(threads), job["slots"], job["reasons"], C.byref(job["rc"]))
+        if not job["h"]:
+            raise MijError("mjh_decode_batch_gpu_begin: %d %s" % (job["rc"].value, lib().mij_last_error().decode()))
+        return job
+
+    def decode_jpegs_gpu_end(self, job):
+        L = lib()
+        L.mjh_decode_batch_gpu_end.argtypes = [C.c_void_p]
+        rc = L.mjh_decode_batch_gpu_end(C.c_void_p(job["h"]))
+        if rc < 0:
+            raise MijError("mjh_decode_batch_gpu_end: %s" % lib().mij_last_error().decode())
+        out_slots = list(job["slots"])
+        for i, sl in enumerate(out_slots):
+            real = sl if sl >= 0 else (-1 - sl if sl < -1 else None)
+            if real is not None and real >= job["first"]:
+                self.descs.append(HostDecoder.probe(job["datas"][i], job["req"]))
+        return rc, out_slots, [r.decode() if r else None for r in job["reasons"]]
+
     def set_flags(self, slot, flags):
         _check(lib().mij_batch_set_flags(self._h, int(slot), int(flags)), "mij_batch_set_flags")
 

@@ -157,117 +157,171 @@ static void run_pool(pool_t *p, void *(*fn)(void *), int threads)
 		pthread_join(tid[i], NULL);
 }
 
-int mjh_decode_batch_gpu(mij_batch *b, const uint8_t *const *bufs, const int *lens, int n, int req_comp, int threads, int *slots, const char **reasons)
-{
+struct mjh_gpu_job {
 	pool_t p;
-	size_t cap = 0, used = 0;
+	int threads, max_slot, *fb;
+	char *todo;
+};
+
+static void job_free(mjh_gpu_job *j)
+{
+	if (!j)
+		return;
+	free(j->p.scans);
+	free(j->p.descs);
+	free(j->p.off);
+	free(j->p.status);
+	free(j->todo);
+	free(j->fb);
+	free(j);
+}
+
+mjh_gpu_job *mjh_decode_batch_gpu_begin(mij_batch *b, const uint8_t *const *bufs, const int *lens, int n, int req_comp, int threads, int *slots,
+													 const char **reasons, int *rc_out)
+{
+	mjh_gpu_job *j = NULL;
+	pool_t *p;
+	size_t cap = 0, used = 0, cnt = (size_t)(n > 0 ? n : 1);
 	uint8_t *stage;
-	int i, rc = MIJ_OK, n_fb = 0, *fb = NULL, *img_of_slot = NULL, gpu_ok = 0, max_slot = -1;
-	char *todo = NULL;
-	if (!b || !bufs || !lens || !slots || !reasons || n < 0)
-		return MIJ_E_ARG;
+	int i, rc = MIJ_OK;
+	if (rc_out)
+		*rc_out = MIJ_OK;
+	if (!b || !bufs || !lens || !slots || !reasons || n < 0) {
+		rc = MIJ_E_ARG;
+		goto fail;
+	}
 	stage = mij_batch_entropy_stage(b, &cap);
-	if (!stage)
-		return mjh_decode_batch(b, bufs, lens, n, req_comp, threads, slots, reasons); /* no entropy arena reserved */
+	if (!stage) {
+		rc = MIJ_E_STATE; /* no entropy arena reserved */
+		goto fail;
+	}
 	if (threads < 1)
 		threads = 1;
 	if (threads > 256)
 		threads = 256;
-	memset(&p, 0, sizeof p);
-	p.b = b;
-	p.bufs = bufs;
-	p.lens = lens;
-	p.n = n;
-	p.req_comp = req_comp;
-	p.slots = slots;
-	p.reasons = reasons;
-	p.stage = stage;
-	p.scans = (mjg_scan *)malloc(sizeof(mjg_scan) * (size_t)(n > 0 ? n : 1));
-	p.descs = (mij_image_desc *)malloc(sizeof(mij_image_desc) * (size_t)(n > 0 ? n : 1));
-	p.off = (size_t *)malloc(sizeof(size_t) * 3 * (size_t)(n > 0 ? n : 1));
-	p.status = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
-	todo = (char *)calloc((size_t)(n > 0 ? n : 1), 1);
-	fb = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
-	if (!p.scans || !p.descs || !p.off || !p.status || !todo || !fb) {
+	j = (mjh_gpu_job *)calloc(1, sizeof *j);
+	if (!j) {
 		rc = MIJ_E_NOMEM;
-		goto out;
+		goto fail;
 	}
-	p.cap = p.off + n;
-	p.slen = p.cap + n;
+	p = &j->p;
+	j->threads = threads;
+	j->max_slot = -1;
+	p->b = b;
+	p->bufs = bufs;
+	p->lens = lens;
+	p->n = n;
+	p->req_comp = req_comp;
+	p->slots = slots;
+	p->reasons = reasons;
+	p->stage = stage;
+	p->scans = (mjg_scan *)malloc(sizeof(mjg_scan) * cnt);
+	p->descs = (mij_image_desc *)malloc(sizeof(mij_image_desc) * cnt);
+	p->off = (size_t *)malloc(sizeof(size_t) * 3 * cnt);
+	p->status = (int *)malloc(sizeof(int) * cnt);
+	j->todo = (char *)calloc(cnt, 1);
+	j->fb = (int *)malloc(sizeof(int) * cnt);
+	if (!p->scans || !p->descs || !p->off || !p->status || !j->todo || !j->fb) {
+		rc = MIJ_E_NOMEM;
+		goto fail;
+	}
+	p->cap = p->off + n;
+	p->slen = p->cap + n;
 	/* every image gets a region as large as its file: the unstuffed segment cannot be longer */
 	for (i = 0; i < n; ++i) {
 		const size_t need = ((size_t)(lens[i] > 0 ? lens[i] : 0) + 64 + 255) / 256 * 256;
-		p.off[i] = used;
-		p.cap[i] = need;
+		p->off[i] = used;
+		p->cap[i] = need;
 		used += need;
 	}
 	if (used > cap) {
 		rc = MIJ_E_NOMEM;
-		goto out;
+		goto fail;
 	}
-	pthread_mutex_init(&p.lock, NULL);
-	run_pool(&p, extract_worker, threads);
+	pthread_mutex_init(&p->lock, NULL);
+	run_pool(p, extract_worker, threads);
+	pthread_mutex_destroy(&p->lock);
 	/* slots in input order */
 	for (i = 0; i < n; ++i) {
-		p.descs[i] = p.scans[i].desc;
-		if (p.status[i] == 0) {
+		p->descs[i] = p->scans[i].desc;
+		if (p->status[i] == 0) {
 			slots[i] = -1;
 			continue;
 		}
 		reasons[i] = NULL;
-		if (p.status[i] == 1)
-			slots[i] = mij_batch_add_stream(b, &p.scans[i], stage + p.off[i], p.slen[i]);
+		if (p->status[i] == 1)
+			slots[i] = mij_batch_add_stream(b, &p->scans[i], stage + p->off[i], p->slen[i]);
 		else {
-			slots[i] = mij_batch_add(b, &p.descs[i]);
-			todo[i] = 1;
+			slots[i] = mij_batch_add(b, &p->descs[i]);
+			j->todo[i] = 1;
 		}
 		if (slots[i] < 0) {
 			rc = slots[i];
-			pthread_mutex_destroy(&p.lock);
-			goto out;
+			goto fail;
 		}
-		if (slots[i] > max_slot)
-			max_slot = slots[i];
+		if (slots[i] > j->max_slot)
+			j->max_slot = slots[i];
 	}
-	rc = mij_batch_entropy_run(b, fb, n, &n_fb);
-	if (rc != MIJ_OK) {
-		pthread_mutex_destroy(&p.lock);
+	rc = mij_batch_entropy_launch(b);
+	if (rc != MIJ_OK)
+		goto fail;
+	return j;
+fail:
+	job_free(j);
+	if (rc_out)
+		*rc_out = rc;
+	return NULL;
+}
+
+int mjh_decode_batch_gpu_end(mjh_gpu_job *j)
+{
+	pool_t *p;
+	int i, rc, n_fb = 0, gpu_ok = 0, *img_of_slot = NULL;
+	if (!j)
+		return MIJ_E_ARG;
+	p = &j->p;
+	rc = mij_batch_entropy_finish(p->b, j->fb, p->n > 0 ? p->n : 1, &n_fb);
+	if (rc != MIJ_OK)
 		goto out;
-	}
 	if (n_fb > 0) {
-		img_of_slot = (int *)malloc(sizeof(int) * (size_t)(max_slot + 1));
+		img_of_slot = (int *)malloc(sizeof(int) * (size_t)(j->max_slot + 1));
 		if (!img_of_slot) {
 			rc = MIJ_E_NOMEM;
-			pthread_mutex_destroy(&p.lock);
 			goto out;
 		}
-		for (i = 0; i < n; ++i)
-			if (slots[i] >= 0)
-				img_of_slot[slots[i]] = i;
+		for (i = 0; i < p->n; ++i)
+			if (p->slots[i] >= 0)
+				img_of_slot[p->slots[i]] = i;
 		for (i = 0; i < n_fb; ++i) {
-			if ((rc = mij_batch_fallback_prepare(b, fb[i])) != MIJ_OK) { /* no staging planes left for the host walk */
-				pthread_mutex_destroy(&p.lock);
+			if ((rc = mij_batch_fallback_prepare(p->b, j->fb[i])) != MIJ_OK) /* no staging planes left for the host walk */
 				goto out;
-			}
-			todo[img_of_slot[fb[i]]] = 1;
+			j->todo[img_of_slot[j->fb[i]]] = 1;
 		}
 	}
-	for (i = 0; i < n; ++i)
-		if (p.status[i] == 1 && !todo[i])
+	for (i = 0; i < p->n; ++i)
+		if (p->status[i] == 1 && !j->todo[i])
 			++gpu_ok;
 	/* the host walk for what the GPU did not take */
-	p.todo = todo;
-	p.ok = 0;
-	run_pool(&p, worker, threads);
-	pthread_mutex_destroy(&p.lock);
-	rc = gpu_ok + p.ok;
+	p->todo = j->todo;
+	p->ok = 0;
+	pthread_mutex_init(&p->lock, NULL);
+	run_pool(p, worker, j->threads);
+	pthread_mutex_destroy(&p->lock);
+	rc = gpu_ok + p->ok;
 out:
-	free(p.scans);
-	free(p.descs);
-	free(p.off);
-	free(p.status);
-	free(todo);
-	free(fb);
 	free(img_of_slot);
+	job_free(j);
 	return rc;
+}
+
+int mjh_decode_batch_gpu(mij_batch *b, const uint8_t *const *bufs, const int *lens, int n, int req_comp, int threads, int *slots, const char **reasons)
+{
+	int rc = MIJ_OK;
+	mjh_gpu_job *j = mjh_decode_batch_gpu_begin(b, bufs, lens, n, req_comp, threads, slots, reasons, &rc);
+	if (!j) {
+		if (rc == MIJ_E_STATE) /* no entropy arena reserved: the host-only front end */
+			return mjh_decode_batch(b, bufs, lens, n, req_comp, threads, slots, reasons);
+		return rc;
+	}
+	return mjh_decode_batch_gpu_end(j);
 }

@@ -344,8 +344,9 @@ __global__ __launch_bounds__(256) void k_es_sync(const DevScan *__restrict__ sca
 	atomicAdd(&changed[wk.scan], 1u);
 }
 
-/* exclusive prefix sum of cnt over a scan's subsequences (one workgroup per scan), in place */
-__global__ __launch_bounds__(256) void k_es_offsets(const DevScan *__restrict__ scans, uint32_t *__restrict__ cnt, uint32_t *__restrict__ total)
+/* exclusive prefix sum of cnt over a scan's subsequences (one workgroup per scan) */
+__global__ __launch_bounds__(256) void k_es_offsets(const DevScan *__restrict__ scans, const uint32_t *__restrict__ cnt, uint32_t *__restrict__ base,
+																	 uint32_t *__restrict__ total)
 {
 	__shared__ uint32_t part[256];
 	const DevScan &sc = scans[blockIdx.x];
@@ -368,9 +369,8 @@ __global__ __launch_bounds__(256) void k_es_offsets(const DevScan *__restrict__ 
 	__syncthreads();
 	uint32_t run = part[threadIdx.x];
 	for (uint32_t i = lo; i < hi; ++i) {
-		const uint32_t v = cnt[sc.sub_off + i];
-		cnt[sc.sub_off + i] = run;
-		run += v;
+		base[sc.sub_off + i] = run;
+		run += cnt[sc.sub_off + i];
 	}
 }
 

@@ -999,7 +999,7 @@ struct EsArena {
 	EsWork *h_work, *d_work;
 	size_t work_cap;
 	uint64_t *d_start, *d_end[2];
-	uint32_t *d_cnt;
+	uint32_t *d_cnt, *d_base;
 	size_t sub_cap;
 	int16_t *d_dcdiff;
 	uint32_t *d_l1;
@@ -1008,7 +1008,8 @@ struct EsArena {
 	uint32_t *d_rounds_changed, *h_rounds_changed; /* [MAX_ROUNDS] sum over scans, for tuning */
 	std::vector<int> scan_slot; /* scan index -> batch slot */
 	size_t sub_used, blk_used, work_used;
-	int last_rounds;
+	int last_rounds, cur;
+	bool in_flight;
 };
 
 static const int ES_MAX_ROUNDS = 96;
@@ -1029,6 +1030,7 @@ static void es_free(EsArena *e)
 	if (e->d_end[0]) (void)hipFree(e->d_end[0]);
 	if (e->d_end[1]) (void)hipFree(e->d_end[1]);
 	if (e->d_cnt) (void)hipFree(e->d_cnt);
+	if (e->d_base) (void)hipFree(e->d_base);
 	if (e->d_dcdiff) (void)hipFree(e->d_dcdiff);
 	if (e->d_l1) (void)hipFree(e->d_l1);
 	if (e->d_verdict) (void)hipFree(e->d_verdict);
@@ -1075,6 +1077,7 @@ extern "C" int mij_batch_entropy_reserve(mij_batch *b, size_t stream_bytes)
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_end[0]), sizeof(uint64_t) * e->sub_cap);
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_end[1]), sizeof(uint64_t) * e->sub_cap);
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_cnt), sizeof(uint32_t) * e->sub_cap);
+	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_base), sizeof(uint32_t) * e->sub_cap);
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_dcdiff), sizeof(int16_t) * e->blk_cap);
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_l1), sizeof(uint32_t) * e->blk_cap);
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_verdict), sizeof(uint32_t) * 5 * n);
@@ -1148,13 +1151,54 @@ extern "C" int mij_batch_add_stream(mij_batch *b, const mjg_scan *scan, uint8_t 
 	return slot;
 }
 
-extern "C" int mij_batch_entropy_run(mij_batch *b, int *fallback, int cap, int *n_fallback)
+/* everything after the synchronisation rounds: offsets, write, tails, DC, verdict D2H (asynchronous) */
+static int es_enqueue_tail(mij_batch *b)
 {
-	if (!b || !b->es || !n_fallback)
-		return set_err(MIJ_E_ARG, "mij_batch_entropy_run: bad argument");
 	EsArena *e = b->es;
-	*n_fallback = 0;
+	hipStream_t st = b->stream;
 	const size_t ns = e->scan_slot.size();
+	uint32_t *v_anom = e->d_verdict, *v_changed = e->d_verdict + b->max_images, *v_total = e->d_verdict + 2 * (size_t)b->max_images,
+				*v_l1 = e->d_verdict + 3 * (size_t)b->max_images, *v_pfinal = e->d_verdict + 4 * (size_t)b->max_images;
+	const dim3 gw((unsigned)e->work_used), gs((unsigned)ns), blk(256);
+	hipLaunchKernelGGL(k_es_offsets, gs, blk, 0, st, e->d_scans, e->d_cnt, e->d_base, v_total);
+	HIP_TRY(hipGetLastError());
+	hipLaunchKernelGGL(k_es_write, gw, blk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, b->d_imgs, e->d_start, e->d_base,
+							 reinterpret_cast<int16_t *>(b->d_coef), e->d_dcdiff, e->d_l1, v_anom, v_pfinal);
+	HIP_TRY(hipGetLastError());
+	hipLaunchKernelGGL(k_es_tails, gw, blk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, b->d_imgs, e->d_start, e->d_base,
+							 reinterpret_cast<int16_t *>(b->d_coef), e->d_dcdiff, e->d_l1, e->d_rounds_changed);
+	HIP_TRY(hipGetLastError());
+	hipLaunchKernelGGL(k_es_dc, gs, blk, 0, st, e->d_scans, b->d_imgs, v_total, v_changed, reinterpret_cast<int16_t *>(b->d_coef), e->d_dcdiff, e->d_l1,
+							 v_anom, v_l1, v_pfinal, e->d_stream);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(e->h_verdict, e->d_verdict, sizeof(uint32_t) * 5 * (size_t)b->max_images, hipMemcpyDeviceToHost, st));
+	return MIJ_OK;
+}
+
+static int es_enqueue_round(mij_batch *b)
+{
+	EsArena *e = b->es;
+	hipStream_t st = b->stream;
+	const size_t ns = e->scan_slot.size();
+	uint32_t *v_changed = e->d_verdict + b->max_images;
+	const dim3 gw((unsigned)e->work_used), blk(256);
+	HIP_TRY(hipMemsetAsync(v_changed, 0, sizeof(uint32_t) * ns, st));
+	hipLaunchKernelGGL(k_es_sync, gw, blk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, e->d_start, e->d_end[e->cur], e->d_end[e->cur ^ 1], e->d_cnt, v_changed);
+	HIP_TRY(hipGetLastError());
+	e->cur ^= 1;
+	++e->last_rounds;
+	return MIJ_OK;
+}
+
+/* Asynchronous: uploads, cold pass, a fixed number of synchronisation rounds (enough for ordinary pictures),
+ * write / DC passes and the verdict copy are queued on the batch's stream; nothing waits. */
+extern "C" int mij_batch_entropy_launch(mij_batch *b)
+{
+	if (!b || !b->es)
+		return set_err(MIJ_E_ARG, "mij_batch_entropy_launch: bad argument");
+	EsArena *e = b->es;
+	const size_t ns = e->scan_slot.size();
+	e->in_flight = false;
 	if (!ns)
 		return MIJ_OK;
 	HIP_TRY(hipSetDevice(b->ctx->device));
@@ -1179,46 +1223,69 @@ extern "C" int mij_batch_entropy_run(mij_batch *b, int *fallback, int cap, int *
 	 * the L1 accumulators and the verdicts do */
 	HIP_TRY(hipMemsetAsync(e->d_l1, 0, sizeof(uint32_t) * e->blk_used, st));
 	HIP_TRY(hipMemsetAsync(e->d_verdict, 0, sizeof(uint32_t) * 5 * (size_t)b->max_images, st));
-	HIP_TRY(hipMemsetAsync(e->d_rounds_changed, 0, sizeof(uint32_t) * ES_MAX_ROUNDS, st));
-	uint32_t *v_anom = e->d_verdict, *v_changed = e->d_verdict + b->max_images, *v_total = e->d_verdict + 2 * (size_t)b->max_images,
-				*v_l1 = e->d_verdict + 3 * (size_t)b->max_images, *v_pfinal = e->d_verdict + 4 * (size_t)b->max_images;
-	const dim3 gw((unsigned)e->work_used), gs((unsigned)ns), blk(256);
+	const dim3 gw((unsigned)e->work_used), blk(256);
 	hipLaunchKernelGGL(k_es_cold, gw, blk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, e->d_start, e->d_end[0], e->d_cnt);
 	HIP_TRY(hipGetLastError());
-	int rounds = ES_MAX_ROUNDS;
+	e->cur = 0;
+	e->last_rounds = 0;
+	int rounds = 6;
 	if (const char *env = getenv("MIJ_ES_ROUNDS"))
 		rounds = atoi(env) > 0 && atoi(env) <= ES_MAX_ROUNDS ? atoi(env) : rounds;
-	int cur = 0;
 	for (int r = 0; r < rounds; ++r) {
-		HIP_TRY(hipMemsetAsync(v_changed, 0, sizeof(uint32_t) * ns, st));
-		hipLaunchKernelGGL(k_es_sync, gw, blk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, e->d_start, e->d_end[cur], e->d_end[cur ^ 1], e->d_cnt, v_changed);
-		HIP_TRY(hipGetLastError());
-		cur ^= 1;
-		/* every fourth round: stop as soon as a round moved nothing (one small D2H + wait) */
-		if ((r & 3) == 3 || r == rounds - 1) {
+		int rc = es_enqueue_round(b);
+		if (rc != MIJ_OK)
+			return rc;
+	}
+	int rc = es_enqueue_tail(b);
+	if (rc != MIJ_OK)
+		return rc;
+	e->in_flight = true;
+	return MIJ_OK;
+}
+
+/* Waits for mij_batch_entropy_launch.  Images whose chains had not settled get more rounds (stopping as soon as
+ * a round moves nothing, ES_MAX_ROUNDS at most) and the write / DC passes are repeated; then the verdicts. */
+extern "C" int mij_batch_entropy_finish(mij_batch *b, int *fallback, int cap, int *n_fallback)
+{
+	if (!b || !b->es || !n_fallback)
+		return set_err(MIJ_E_ARG, "mij_batch_entropy_finish: bad argument");
+	EsArena *e = b->es;
+	*n_fallback = 0;
+	const size_t ns = e->scan_slot.size();
+	if (!ns || !e->in_flight)
+		return MIJ_OK;
+	e->in_flight = false;
+	HIP_TRY(hipSetDevice(b->ctx->device));
+	hipStream_t st = b->stream;
+	HIP_TRY(hipStreamSynchronize(st));
+	bool unsettled = false;
+	for (size_t k = 0; k < ns; ++k)
+		unsettled |= (e->h_verdict[k] & 8u) != 0;
+	if (unsettled) {
+		uint32_t *v_changed = e->d_verdict + b->max_images;
+		while (e->last_rounds < ES_MAX_ROUNDS) {
+			int rc = MIJ_OK;
+			for (int r = 0; r < 4 && e->last_rounds < ES_MAX_ROUNDS && rc == MIJ_OK; ++r)
+				rc = es_enqueue_round(b);
+			if (rc != MIJ_OK)
+				return rc;
 			HIP_TRY(hipMemcpyAsync(e->h_verdict + b->max_images, v_changed, sizeof(uint32_t) * ns, hipMemcpyDeviceToHost, st));
 			HIP_TRY(hipStreamSynchronize(st));
 			uint32_t any = 0;
 			for (size_t k = 0; k < ns; ++k)
 				any |= e->h_verdict[(size_t)b->max_images + k];
-			e->last_rounds = r + 1;
 			if (!any)
 				break;
 		}
+		/* the passes behind the rounds again, on clean accumulators and verdicts (the last round's counters stay) */
+		HIP_TRY(hipMemsetAsync(e->d_l1, 0, sizeof(uint32_t) * e->blk_used, st));
+		HIP_TRY(hipMemsetAsync(e->d_verdict, 0, sizeof(uint32_t) * (size_t)b->max_images, st));
+		HIP_TRY(hipMemsetAsync(e->d_verdict + 2 * (size_t)b->max_images, 0, sizeof(uint32_t) * 3 * (size_t)b->max_images, st));
+		int rc = es_enqueue_tail(b);
+		if (rc != MIJ_OK)
+			return rc;
+		HIP_TRY(hipStreamSynchronize(st));
 	}
-	hipLaunchKernelGGL(k_es_offsets, gs, blk, 0, st, e->d_scans, e->d_cnt, v_total);
-	HIP_TRY(hipGetLastError());
-	hipLaunchKernelGGL(k_es_write, gw, blk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, b->d_imgs, e->d_start, e->d_cnt,
-							 reinterpret_cast<int16_t *>(b->d_coef), e->d_dcdiff, e->d_l1, v_anom, v_pfinal);
-	HIP_TRY(hipGetLastError());
-	hipLaunchKernelGGL(k_es_tails, gw, blk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, b->d_imgs, e->d_start, e->d_cnt,
-							 reinterpret_cast<int16_t *>(b->d_coef), e->d_dcdiff, e->d_l1, e->d_rounds_changed);
-	HIP_TRY(hipGetLastError());
-	hipLaunchKernelGGL(k_es_dc, gs, blk, 0, st, e->d_scans, b->d_imgs, v_total, v_changed, reinterpret_cast<int16_t *>(b->d_coef), e->d_dcdiff, e->d_l1,
-							 v_anom, v_l1, v_pfinal, e->d_stream);
-	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipMemcpyAsync(e->h_verdict, e->d_verdict, sizeof(uint32_t) * 4 * (size_t)b->max_images, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipStreamSynchronize(st));
 	if (getenv("MIJ_ES_DEBUG"))
 		for (size_t k = 0; k < ns; ++k)
 			fprintf(stderr, "es scan %zu slot %d: anomaly %u changed %u blocks %u/%u l1max %u nsub %u rounds %d\n", k, e->scan_slot[k], e->h_verdict[k],
@@ -1239,6 +1306,14 @@ extern "C" int mij_batch_entropy_run(mij_batch *b, int *fallback, int cap, int *
 	if (*n_fallback > cap)
 		return set_err(MIJ_E_ARG, "fallback list too small (%d > %d)", *n_fallback, cap);
 	return MIJ_OK;
+}
+
+extern "C" int mij_batch_entropy_run(mij_batch *b, int *fallback, int cap, int *n_fallback)
+{
+	int rc = mij_batch_entropy_launch(b);
+	if (rc != MIJ_OK)
+		return rc;
+	return mij_batch_entropy_finish(b, fallback, cap, n_fallback);
 }
 
 extern "C" int mij_batch_fallback_prepare(mij_batch *b, int slot)

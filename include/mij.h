@@ -225,6 +225,10 @@ int mij_batch_add_stream(mij_batch *b, const mjg_scan *scan, uint8_t *stream, si
 /* H2D of the streams, the five kernels, D2H of the verdicts; waits.  fallback[0..*n_fallback) = slots the host
  * walk must redo (mij_batch_fallback_prepare, then decode into mij_batch_coef as usual). */
 int mij_batch_entropy_run(mij_batch *b, int *fallback, int cap, int *n_fallback);
+/* The same in two halves: launch queues everything on the batch's stream and returns at once (the host can
+ * parse the next batch's headers meanwhile), finish waits and reports. */
+int mij_batch_entropy_launch(mij_batch *b);
+int mij_batch_entropy_finish(mij_batch *b, int *fallback, int cap, int *n_fallback);
 int mij_batch_fallback_prepare(mij_batch *b, int slot);
 /* tests: the coefficient planes of a slot as they sit in HBM (tile layout), after entropy_run or upload */
 int mij_batch_fetch_coef(mij_batch *b, int slot, int16_t *dst, size_t dst_elems);

@@ -58,6 +58,15 @@ int mjh_decode_batch(mij_batch *b, const uint8_t *const *bufs, const int *lens, 
  * the host as above.  Waits for the GPU walk; follow with mij_batch_submit(). */
 int mjh_decode_batch_gpu(mij_batch *b, const uint8_t *const *bufs, const int *lens, int n, int req_comp, int threads, int *slots, const char **reasons);
 
+/* The same in two halves, so that the host can prepare the next batch while the GPU walks this one: begin parses,
+ * unstuffs, adds the slots and queues the GPU walk (returns NULL with *rc set on failure; MIJ_E_STATE = no entropy
+ * arena reserved); end waits for the walk, host-walks what it handed back and returns the count like above.
+ * bufs, lens, slots and reasons must stay valid until end. */
+typedef struct mjh_gpu_job mjh_gpu_job;
+mjh_gpu_job *mjh_decode_batch_gpu_begin(mij_batch *b, const uint8_t *const *bufs, const int *lens, int n, int req_comp, int threads, int *slots,
+													 const char **reasons, int *rc);
+int mjh_decode_batch_gpu_end(mjh_gpu_job *job);
+
 /*
  * JPEG writer in three steps (stbi_write_jpg_to_func = plan + transform + emit); step 2 also exists
  * on the GPU (mij_enc_* in mij.h) and must produce the same data units bit for bit.
