@@ -66,7 +66,7 @@ if "SQ_INSTS_VALU" in counters:
 
 # ---- secondary kernels
 lines.append("## 5. secondary kernels (tools/profile_extra.sh: kernel-trace --stats)")
-for sub in ("k444", "kenc"):
+for sub in ("k444", "kenc", "k422", "kes"):
     f = one(sub + "/**/*kernel_stats.csv")
     if f:
         lines += ["### " + sub, "```"] + [l.rstrip() for l in open(f)] + ["```"]
