@@ -1,0 +1,88 @@
+"""Randomised parity stress (not part of the pytest suites): many small random pictures of random sizes,
+qualities, layouts (4:2:0 / 4:4:4 baseline from the writer, 4:2:2 / grey / progressive from the test-side
+writer) and req_comp through every decode route -- fused kernels, the two-pass family, the GPU Huffman walk --
+against the oracle.  python tools/stress.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import image_codecs_amd as ica  # noqa: E402
+import helpers  # noqa: E402
+
+
+def picture(rng, w, h):
+    kind = int(rng.integers(0, 4))
+    if kind == 0:
+        return rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+    if kind == 1:
+        return ica.synth_rgb(w, h, int(rng.integers(0, 1000)))
+    if kind == 2:  # flat areas with hard edges (big AC, saturation)
+        a = np.zeros((h, w, 3), np.uint8)
+        for _ in range(6):
+            x0, y0 = int(rng.integers(0, w)), int(rng.integers(0, h))
+            a[y0:y0 + int(rng.integers(1, h + 1)), x0:x0 + int(rng.integers(1, w + 1))] = rng.integers(0, 256, 3)
+        return a
+    g = np.linspace(0, 255, w)[None, :, None] * np.ones((h, 1, 3))
+    return np.clip(g + rng.normal(0, 20, (h, w, 3)), 0, 255).astype(np.uint8)
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    oracle = helpers.Oracle()
+    ctx = ica.Context()
+    t_end = time.time() + budget
+    n_img = n_cmp = rounds = 0
+    while time.time() < t_end:
+        rounds += 1
+        datas = []
+        for _ in range(24):
+            w = int(rng.integers(1, 96)) if rng.random() < 0.3 else int(rng.integers(1, 700))
+            h = int(rng.integers(1, 96)) if rng.random() < 0.3 else int(rng.integers(1, 500))
+            q = int(rng.choice([1, 10, 35, 50, 75, 85, 90, 91, 95, 100]))
+            img = picture(rng, w, h)
+            layout = int(rng.integers(0, 6))
+            if layout <= 1:
+                datas.append(ica.stbi_write_jpg_to_memory(img, q))
+            else:
+                plan, du = ica.host_transform(img, q if layout == 2 else max(q, 91))
+                script = int(rng.integers(0, 2))
+                if layout == 2:
+                    datas.append(helpers.progressive_from_du(plan, du, script))
+                elif layout == 3:
+                    datas.append(helpers.progressive_422_from_444(plan, du, script))
+                elif layout == 4:
+                    datas.append(helpers.progressive_grey_from_444(plan, du, script))
+                else:
+                    datas.append(helpers.progressive_from_du(plan, du, script))
+        req = int(rng.integers(0, 5))
+        wants = [oracle.load(d, req) for d in datas]
+        for mode in ("fused", "generic", "gpu_walk"):
+            b = ica.Batch(ctx, len(datas), 96 << 20, 96 << 20, 96 << 20)
+            if mode == "gpu_walk":
+                b.entropy_reserve(8 << 20)
+            b.force_generic(mode == "generic")
+            ok, slots, reasons = b.decode_jpegs(datas, req, threads=4, gpu_entropy=(mode == "gpu_walk"))
+            b.submit()
+            b.wait()
+            for i, (kind, want, _) in enumerate(wants):
+                if kind != "ok":
+                    assert slots[i] < 0, (mode, i)
+                    continue
+                assert slots[i] >= 0, (mode, i, reasons[i])
+                got = b.fetch(slots[i])
+                if not np.array_equal(got.reshape(-1), want.reshape(-1)):
+                    open(os.path.join(ROOT, "gpurun_out", "stress_fail_%d_%d.jpg" % (rounds, i)), "wb").write(datas[i])
+                    raise SystemExit("MISMATCH mode=%s round=%d image=%d shape=%s req=%d path=%d" % (mode, rounds, i, want.shape, req, b.slot_path(slots[i])))
+                n_cmp += 1
+            b.close()
+        n_img += len(datas)
+    print("stress ok: %d rounds, %d pictures, %d comparisons in %.0f s" % (rounds, n_img, n_cmp, budget))
+
+
+if __name__ == "__main__":
+    main()
