@@ -30,7 +30,41 @@ def picture(rng, w, h):
     return np.clip(g + rng.normal(0, 20, (h, w, 3)), 0, 255).astype(np.uint8)
 
 
+def encoder_stress(budget, rng):
+    """GPU data units (strip kernel where it applies, per-unit kernels, both forced) against the host transform."""
+    ctx = ica.Context()
+    t_end = time.time() + budget
+    n = 0
+    while time.time() < t_end:
+        imgs, qs, flips = [], [], []
+        for _ in range(16):
+            w = int(rng.integers(1, 40)) * 16 if rng.random() < 0.5 else int(rng.integers(1, 500))
+            h = int(rng.integers(1, 400))
+            c = int(rng.choice([1, 3, 3, 3, 4]))
+            img = picture(rng, w, h)
+            img = img[:, :, :c] if c <= 3 else np.concatenate([img, img[:, :, :1]], -1)
+            imgs.append(np.ascontiguousarray(img))
+            qs.append(int(rng.choice([1, 20, 50, 75, 90, 91, 100])))
+            flips.append(bool(rng.integers(0, 2)))
+        want = [ica.host_transform(im[::-1] if f else im, q)[1] for im, q, f in zip(imgs, qs, flips)]
+        for generic in (False, True):
+            enc = ica.Encoder(ctx, len(imgs), 64 << 20, 64 << 20)
+            enc.force_generic(generic)
+            slots = [enc.add(im, q, flip=f) for im, q, f in zip(imgs, qs, flips)]
+            enc.upload()
+            enc.launch()
+            enc.wait()
+            for s_, w_, im in zip(slots, want, imgs):
+                if not np.array_equal(enc.fetch(s_), w_):
+                    raise SystemExit("ENCODER MISMATCH generic=%s shape=%s" % (generic, im.shape))
+                n += 1
+            enc.close()
+    print("encoder stress ok: %d comparisons in %.0f s" % (n, budget))
+
+
 def main():
+    if len(sys.argv) > 3 and sys.argv[3] == "enc":
+        return encoder_stress(float(sys.argv[1]), np.random.default_rng(int(sys.argv[2])))
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     oracle = helpers.Oracle()
