@@ -100,6 +100,122 @@ def cpu_baseline(datas, want_seconds=12.0):
     }
 
 
+def end_to_end(ica, ctx, datas, distinct, n_img, src_hash, cbytes, obytes, args):
+    """Outside the timed region (rank 0, one GPU): bitstream in host RAM -> RGB in HBM, three ways."""
+    e2e = None
+    n_e = min(args.e2e_images, n_img)
+    threads = usable_cores()
+    chunk = max(1, min(64, n_e // 2))
+    # two batches ping-pong: while the GPU uploads and transforms chunk k (async on its own stream)
+    # the host threads already walk chunk k+1 -- the "H2D / kernel overlap" of SURVEY 8(e)
+    ebs = [ica.Batch(ctx, chunk, cbytes * chunk, cbytes * chunk, obytes * chunk) for _ in range(2)]
+    jl = [datas[i % distinct] for i in range(n_e)]
+    for eb in ebs:  # warm the pool / page in staging
+        eb.decode_jpegs(jl[:chunk], 3, threads)
+        eb.submit()
+        eb.wait()
+    t_host = 0.0
+    t0 = time.perf_counter()
+    last = {}
+    for k, lo in enumerate(range(0, n_e, chunk)):
+        eb = ebs[k & 1]
+        eb.reset()  # waits for this batch's previous chunk
+        part = jl[lo:lo + chunk]
+        th = time.perf_counter()
+        ok, slots, reasons = eb.decode_jpegs(part, 3, threads)
+        t_host += time.perf_counter() - th
+        assert ok == len(part), reasons
+        eb.submit()
+        last[k & 1] = (lo + len(part) - 1, slots[len(part) - 1])
+    for eb in ebs:
+        eb.wait()
+    t_all = time.perf_counter() - t0
+    for side, (img, slot) in last.items():
+        assert ebs[side].hash_out(slot) == src_hash[img % distinct]
+    e2e = {
+        "value": round(n_e * W * H / t_all / 1e6, 1),
+        "unit": "Mpix/s",
+        "images": n_e,
+        "host_threads": threads,
+        "chunk_images": chunk,
+        "host_stage_only_mpix_s": round(n_e * W * H / t_host / 1e6, 1),
+        "includes": "Huffman walk on the host threads -> pinned staging -> H2D -> fused kernel, two batches ping-pong; pixels left in HBM",
+    }
+    # the same pipeline with the pixels brought back to (pinned) host memory: one asynchronous D2H of the
+    # chunk's output arena queued behind its kernels, completed when the batch is reused
+    pins = [ica.PinnedBuffer(obytes * chunk) for _ in range(2)]
+    t0 = time.perf_counter()
+    for k, lo in enumerate(range(0, n_e, chunk)):
+        eb = ebs[k & 1]
+        eb.reset()
+        part = jl[lo:lo + chunk]
+        ok, slots, reasons = eb.decode_jpegs(part, 3, threads)
+        eb.submit()
+        eb.fetch_all_async(pins[k & 1].ptr, pins[k & 1].nbytes)
+        last[k & 1] = (lo + len(part) - 1, slots[len(part) - 1])
+    for eb in ebs:
+        eb.wait()
+    t_d2h = time.perf_counter() - t0
+    for side, (img, slot) in last.items():
+        off = ebs[side].out_offset(slot)
+        got = pins[side].array[off:off + W * H * 3]
+        assert np.array_equal(got, ebs[side].fetch(slot).reshape(-1)), "D2H copy differs from the device image"
+    e2e["value_with_d2h"] = round(n_e * W * H / t_d2h / 1e6, 1)
+    # experimental: the Huffman walk itself on the GPU (mjh_decode_batch_gpu): the host threads only parse
+    # headers and remove byte stuffing, 0.45 MB of bitstream per image crosses PCIe instead of 6.3 MB of
+    # coefficients; images the GPU walk refuses are walked on the host
+    try:
+        for eb in ebs:
+            eb.close()
+        gchunk = max(1, min(int(os.environ.get("MIJ_BENCH_GPU_CHUNK", "128")), n_e // 2))
+        # no coefficient staging to speak of: it is only needed for images the GPU walk hands back
+        ebs = [ica.Batch(ctx, gchunk, cbytes * 4, cbytes * gchunk, obytes * gchunk) for _ in range(2)]
+        for eb in ebs:
+            eb.entropy_reserve(sum(len(x) + 512 for x in jl[:gchunk]) * 2)
+        for eb in ebs:  # warm-up
+            eb.reset()
+            eb.decode_jpegs(jl[:gchunk], 3, threads, gpu_entropy=True)
+            eb.submit()
+            eb.wait()
+        t0 = time.perf_counter()
+        last = {}
+        pending = None  # (side, job, first image): its GPU walk runs while the next chunk's headers are parsed
+        for k, lo in enumerate(range(0, n_e, gchunk)):
+            eb = ebs[k & 1]
+            eb.reset()
+            part = jl[lo:lo + gchunk]
+            job = eb.decode_jpegs_gpu_begin(part, 3, threads)
+            if pending is not None:
+                side, pjob, plo, plen = pending
+                ok, slots, reasons = ebs[side].decode_jpegs_gpu_end(pjob)
+                assert ok == plen, reasons
+                ebs[side].submit()
+                last[side] = (plo + plen - 1, slots[plen - 1])
+            pending = (k & 1, job, lo, len(part))
+        side, pjob, plo, plen = pending
+        ok, slots, reasons = ebs[side].decode_jpegs_gpu_end(pjob)
+        assert ok == plen, reasons
+        ebs[side].submit()
+        last[side] = (plo + plen - 1, slots[plen - 1])
+        for eb in ebs:
+            eb.wait()
+        t_gpu = time.perf_counter() - t0
+        for side, (img, slot) in last.items():
+            assert ebs[side].hash_out(slot) == src_hash[img % distinct], "GPU-walked image differs"
+        e2e["value_gpu_entropy"] = round(n_e * W * H / t_gpu / 1e6, 1)
+        e2e["gpu_entropy_sync_rounds"] = ebs[0].entropy_rounds()
+        e2e["gpu_entropy_chunk_images"] = gchunk
+    except ica.MijError as exc:
+        e2e["value_gpu_entropy"] = None
+        e2e["gpu_entropy_error"] = str(exc)
+    for pb in pins:
+        pb.close()
+    for eb in ebs:
+        eb.close()
+
+    return e2e
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -182,117 +298,14 @@ def main():
     kernel_ms_max = cp.max(kernel_ms)
 
     # ---- outside the timed region: the end-to-end path (bitstream in host RAM -> RGB in HBM), rank 0
+    # ---- outside the timed region: the end-to-end path (bitstream in host RAM -> RGB in HBM), rank 0.  It must never
+    # cost the benchmark its JSON line: any failure is reported inside the line instead
     e2e = None
     if cp.rank == 0 and cp.world == 1 and not args.no_e2e:
-        n_e = min(args.e2e_images, n_img)
-        threads = usable_cores()
-        chunk = max(1, min(64, n_e // 2))
-        # two batches ping-pong: while the GPU uploads and transforms chunk k (async on its own stream)
-        # the host threads already walk chunk k+1 -- the "H2D / kernel overlap" of SURVEY 8(e)
-        ebs = [ica.Batch(ctx, chunk, cbytes * chunk, cbytes * chunk, obytes * chunk) for _ in range(2)]
-        jl = [datas[i % distinct] for i in range(n_e)]
-        for eb in ebs:  # warm the pool / page in staging
-            eb.decode_jpegs(jl[:chunk], 3, threads)
-            eb.submit()
-            eb.wait()
-        t_host = 0.0
-        t0 = time.perf_counter()
-        last = {}
-        for k, lo in enumerate(range(0, n_e, chunk)):
-            eb = ebs[k & 1]
-            eb.reset()  # waits for this batch's previous chunk
-            part = jl[lo:lo + chunk]
-            th = time.perf_counter()
-            ok, slots, reasons = eb.decode_jpegs(part, 3, threads)
-            t_host += time.perf_counter() - th
-            assert ok == len(part), reasons
-            eb.submit()
-            last[k & 1] = (lo + len(part) - 1, slots[len(part) - 1])
-        for eb in ebs:
-            eb.wait()
-        t_all = time.perf_counter() - t0
-        for side, (img, slot) in last.items():
-            assert ebs[side].hash_out(slot) == src_hash[img % distinct]
-        e2e = {
-            "value": round(n_e * W * H / t_all / 1e6, 1),
-            "unit": "Mpix/s",
-            "images": n_e,
-            "host_threads": threads,
-            "chunk_images": chunk,
-            "host_stage_only_mpix_s": round(n_e * W * H / t_host / 1e6, 1),
-            "includes": "Huffman walk on the host threads -> pinned staging -> H2D -> fused kernel, two batches ping-pong; pixels left in HBM",
-        }
-        # the same pipeline with the pixels brought back to (pinned) host memory: one asynchronous D2H of the
-        # chunk's output arena queued behind its kernels, completed when the batch is reused
-        pins = [ica.PinnedBuffer(obytes * chunk) for _ in range(2)]
-        t0 = time.perf_counter()
-        for k, lo in enumerate(range(0, n_e, chunk)):
-            eb = ebs[k & 1]
-            eb.reset()
-            part = jl[lo:lo + chunk]
-            ok, slots, reasons = eb.decode_jpegs(part, 3, threads)
-            eb.submit()
-            eb.fetch_all_async(pins[k & 1].ptr, pins[k & 1].nbytes)
-            last[k & 1] = (lo + len(part) - 1, slots[len(part) - 1])
-        for eb in ebs:
-            eb.wait()
-        t_d2h = time.perf_counter() - t0
-        for side, (img, slot) in last.items():
-            off = ebs[side].out_offset(slot)
-            got = pins[side].array[off:off + W * H * 3]
-            assert np.array_equal(got, ebs[side].fetch(slot).reshape(-1)), "D2H copy differs from the device image"
-        e2e["value_with_d2h"] = round(n_e * W * H / t_d2h / 1e6, 1)
-        # experimental: the Huffman walk itself on the GPU (mjh_decode_batch_gpu): the host threads only parse
-        # headers and remove byte stuffing, 0.45 MB of bitstream per image crosses PCIe instead of 6.3 MB of
-        # coefficients; images the GPU walk refuses are walked on the host
         try:
-            for eb in ebs:
-                eb.close()
-            gchunk = max(1, min(int(os.environ.get("MIJ_BENCH_GPU_CHUNK", "128")), n_e // 2))
-            # no coefficient staging to speak of: it is only needed for images the GPU walk hands back
-            ebs = [ica.Batch(ctx, gchunk, cbytes * 4, cbytes * gchunk, obytes * gchunk) for _ in range(2)]
-            for eb in ebs:
-                eb.entropy_reserve(sum(len(x) + 512 for x in jl[:gchunk]) * 2)
-            for eb in ebs:  # warm-up
-                eb.reset()
-                eb.decode_jpegs(jl[:gchunk], 3, threads, gpu_entropy=True)
-                eb.submit()
-                eb.wait()
-            t0 = time.perf_counter()
-            last = {}
-            pending = None  # (side, job, first image): its GPU walk runs while the next chunk's headers are parsed
-            for k, lo in enumerate(range(0, n_e, gchunk)):
-                eb = ebs[k & 1]
-                eb.reset()
-                part = jl[lo:lo + gchunk]
-                job = eb.decode_jpegs_gpu_begin(part, 3, threads)
-                if pending is not None:
-                    side, pjob, plo, plen = pending
-                    ok, slots, reasons = ebs[side].decode_jpegs_gpu_end(pjob)
-                    assert ok == plen, reasons
-                    ebs[side].submit()
-                    last[side] = (plo + plen - 1, slots[plen - 1])
-                pending = (k & 1, job, lo, len(part))
-            side, pjob, plo, plen = pending
-            ok, slots, reasons = ebs[side].decode_jpegs_gpu_end(pjob)
-            assert ok == plen, reasons
-            ebs[side].submit()
-            last[side] = (plo + plen - 1, slots[plen - 1])
-            for eb in ebs:
-                eb.wait()
-            t_gpu = time.perf_counter() - t0
-            for side, (img, slot) in last.items():
-                assert ebs[side].hash_out(slot) == src_hash[img % distinct], "GPU-walked image differs"
-            e2e["value_gpu_entropy"] = round(n_e * W * H / t_gpu / 1e6, 1)
-            e2e["gpu_entropy_sync_rounds"] = ebs[0].entropy_rounds()
-            e2e["gpu_entropy_chunk_images"] = gchunk
-        except ica.MijError as exc:
-            e2e["value_gpu_entropy"] = None
-            e2e["gpu_entropy_error"] = str(exc)
-        for pb in pins:
-            pb.close()
-        for eb in ebs:
-            eb.close()
+            e2e = end_to_end(ica, ctx, datas, distinct, n_img, src_hash, cbytes, obytes, args)
+        except Exception as exc:  # noqa: BLE001
+            e2e = {"value": None, "error": "%s: %s" % (type(exc).__name__, exc)}
 
     out = None
     if cp.rank == 0:
@@ -347,7 +360,10 @@ def main():
         if e2e is not None:
             out["end_to_end"] = e2e
         if cp.world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(datas)
+            try:
+                out["cpu_baseline"] = cpu_baseline(datas)
+            except Exception as exc:  # noqa: BLE001
+                out["cpu_baseline"] = {"value": None, "error": "%s: %s" % (type(exc).__name__, exc)}
     batch.close()
     ctx.close()
     cp.close()
