@@ -1047,6 +1047,7 @@ static void es_reset_fwd(EsArena *e)
 		return;
 	e->scan_slot.clear();
 	e->sub_used = e->blk_used = e->work_used = 0;
+	e->in_flight = false;
 }
 
 extern "C" int mij_batch_entropy_reserve(mij_batch *b, size_t stream_bytes)
