@@ -241,10 +241,15 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const DevHuff *
 			if (WRITE) {
 				if (s.p > sc.nbits)
 					atomicOr(anom, 16u); /* the data ran out inside this block: the reference decodes on with zero bits */
-				if (!wr->skip && wr->buf)
-					wr->flush();
-				if (wr->acc)
-					atomicAdd(&wr->l1[wr->ord], wr->acc);
+				/* per-block L1 of the AC coefficients without atomics: whoever holds the block's start stores, the
+				 * thread that finishes a block begun elsewhere (k_es_tails, a later launch) adds */
+				if (wr->buf) {
+					if (!wr->skip) {
+						wr->flush();
+						wr->l1[wr->ord] = wr->acc;
+					}
+				} else
+					wr->l1[wr->ord] += wr->acc;
 				wr->acc = 0;
 				if (wr->stop_after_block) { /* k_es_tails: only the rest of the block the subsequence started in */
 					s.z = 0;
@@ -271,11 +276,10 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const DevHuff *
 			break;
 		}
 	}
-	if (WRITE && wr->ord < sc.nblocks && !wr->skip) { /* a block that continues in the next subsequence: its head goes out now */
-		if (wr->buf && s.z != 0 && s.z != MIJ_ES_DEAD)
-			wr->flush();
-		if (wr->acc)
-			atomicAdd(&wr->l1[wr->ord], wr->acc);
+	if (WRITE && wr->buf && wr->ord < sc.nblocks && !wr->skip && s.z != 0 && s.z != MIJ_ES_DEAD) {
+		/* a block that continues in the next subsequence: its head goes out now */
+		wr->flush();
+		wr->l1[wr->ord] = wr->acc;
 	}
 	return done;
 }

@@ -1220,9 +1220,8 @@ extern "C" int mij_batch_entropy_launch(mij_batch *b)
 		hi = end > hi ? end : hi;
 	}
 	HIP_TRY(hipMemcpyAsync(e->d_stream + lo, e->stage + lo, hi - lo, hipMemcpyHostToDevice, st));
-	/* the write pass stores every block of the MCU grid whole, so the coefficient planes need no clearing;
-	 * the L1 accumulators and the verdicts do */
-	HIP_TRY(hipMemsetAsync(e->d_l1, 0, sizeof(uint32_t) * e->blk_used, st));
+	/* the write pass stores every block of the MCU grid whole and its L1 word with it, so neither the
+	 * coefficient planes nor the accumulators need clearing; the verdicts do */
 	HIP_TRY(hipMemsetAsync(e->d_verdict, 0, sizeof(uint32_t) * 5 * (size_t)b->max_images, st));
 	const dim3 gw((unsigned)e->work_used), blk(256);
 	hipLaunchKernelGGL(k_es_cold, gw, blk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, e->d_start, e->d_end[0], e->d_cnt);
@@ -1278,8 +1277,7 @@ extern "C" int mij_batch_entropy_finish(mij_batch *b, int *fallback, int cap, in
 			if (!any)
 				break;
 		}
-		/* the passes behind the rounds again, on clean accumulators and verdicts (the last round's counters stay) */
-		HIP_TRY(hipMemsetAsync(e->d_l1, 0, sizeof(uint32_t) * e->blk_used, st));
+		/* the passes behind the rounds again, on clean verdicts (the last round's counters stay) */
 		HIP_TRY(hipMemsetAsync(e->d_verdict, 0, sizeof(uint32_t) * (size_t)b->max_images, st));
 		HIP_TRY(hipMemsetAsync(e->d_verdict + 2 * (size_t)b->max_images, 0, sizeof(uint32_t) * 3 * (size_t)b->max_images, st));
 		int rc = es_enqueue_tail(b);
