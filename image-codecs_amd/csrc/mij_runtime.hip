@@ -1228,7 +1228,7 @@ extern "C" int mij_batch_entropy_launch(mij_batch *b)
 	HIP_TRY(hipGetLastError());
 	e->cur = 0;
 	e->last_rounds = 0;
-	int rounds = 6;
+	int rounds = 4; /* ordinary pictures settle in two or three; finish() adds rounds for those that have not */
 	if (const char *env = getenv("MIJ_ES_ROUNDS"))
 		rounds = atoi(env) > 0 && atoi(env) <= ES_MAX_ROUNDS ? atoi(env) : rounds;
 	for (int r = 0; r < rounds; ++r) {
