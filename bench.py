@@ -240,7 +240,9 @@ def main():
     if cp.world != args.gpus:
         if cp.rank == 0:
             print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, cp.world), file=sys.stderr)
-    ica.build_library()
+    if cp.local_rank == 0:
+        ica.build_library()  # a no-op when the in-tree .so exists; never from several ranks at once
+    cp.barrier()
     if not ica.gpu_available():
         raise SystemExit("bench.py needs a gfx950 GPU: the decode path has no CPU fallback")
     ctx = ica.Context(cp.local_rank)
