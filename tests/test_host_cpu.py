@@ -214,3 +214,91 @@ def test_decode_fails_loudly_without_gpu(golden, ica):
     assert ica.stbi_failure_reason() == "no gpu device"
     with pytest.raises(ica.MijError):
         ica.Context()
+
+
+def _walk_extracted_scan(scan, stream):
+    """Plain sequential Huffman walk over what mjh_extract_scan hands to the GPU stage (tables as copied,
+    unstuffed bytes): -> int16 [nblocks, 64] in zigzag order, DC predicted per component."""
+    bits = int.from_bytes(stream + b"\0" * 16, "big")
+    total = (len(stream) + 16) * 8
+
+    def window(p):
+        return (bits >> (total - p - 64)) & ((1 << 64) - 1)
+
+    tabs = [(bytes(h.fast), bytes(h.size), bytes(h.values), list(h.maxcode), list(h.delta)) for h in scan.huff]
+
+    def symbol(t, win):
+        fast, size, values, maxcode, delta = t
+        top16 = win >> 48
+        k = fast[top16 >> 7]
+        if k < 255:
+            return values[k], size[k]
+        n = 10
+        while top16 >= maxcode[n]:
+            n += 1
+        return values[((top16 >> (16 - n)) & ((1 << n) - 1)) + delta[n]], n
+
+    def extend(win, ln, n):
+        v = (win >> (64 - ln - n)) & ((1 << n) - 1)
+        return v if v >> (n - 1) else v - (1 << n) + 1
+
+    bpm = scan.blocks_per_mcu
+    out = np.zeros((scan.nblocks, 64), np.int64)
+    pred = [0, 0, 0, 0]
+    p = 0
+    for b in range(scan.nblocks):
+        ci = scan.blk_comp[b % bpm]
+        t, ln = symbol(tabs[scan.dc_tab[ci]], window(p))
+        diff = extend(window(p), ln, t) if t else 0
+        p += ln + t
+        pred[ci] += diff
+        out[b, 0] = pred[ci]
+        k = 1
+        while k < 64:
+            rs, ln = symbol(tabs[scan.ac_tab[ci]], window(p))
+            r, n = rs >> 4, rs & 15
+            if n == 0:
+                p += ln
+                if rs != 0xF0:
+                    break
+                k += 16
+                continue
+            k += r
+            out[b, k] = extend(window(p), ln, n)
+            p += ln + n
+            k += 1
+    return out.astype(np.int16), p
+
+
+def test_extracted_scan_walks_to_the_host_walk_coefficients(golden, ica):
+    """What the GPU entropy stage is given (mjh_extract_scan: copied tables, unstuffed segment, block order)
+    decodes, with a plain sequential walk, to exactly the host walk's coefficients; layouts outside its scope
+    are declined, not guessed at."""
+    import ctypes as C
+    from image_codecs_amd.binding import GpuScan, lib
+    L = lib()
+    L.mjh_extract_scan.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(GpuScan), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_char_p)]
+    zig = np.array([0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50,
+                    43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63])
+    cases = [golden.jpg("b420_64x64_q90"), golden.jpg("b444_40x24_q95"), golden.jpg("grey_33x20"), ica.synth_jpeg(97, 51, 3, 75), ica.synth_jpeg(16, 16, 4, 100)]
+    for data in cases:
+        scan, n, why = GpuScan(), C.c_size_t(), C.c_char_p()
+        buf = np.zeros(len(data) + 64, np.uint8)
+        assert L.mjh_extract_scan(data, len(data), 3, C.byref(scan), buf.ctypes.data_as(C.c_void_p), buf.size, C.byref(n), C.byref(why)) == 1
+        got, p_end = _walk_extracted_scan(scan, bytes(buf[:n.value]))
+        assert n.value * 8 - p_end < 8  # only the byte-alignment padding is left
+        desc, arena = ica.HostDecoder.decode(data, 3)
+        planes = ica.detile_coefficients(desc, arena)  # [bh, bw, 8, 8] natural order
+        bpm, mcu_x = scan.blocks_per_mcu, desc.mcu_x
+        for b in range(scan.nblocks):
+            m, c = divmod(b, bpm)
+            ci = scan.blk_comp[c]
+            bx = (m % mcu_x) * desc.comp[ci].h + scan.blk_dx[c]
+            by = (m // mcu_x) * desc.comp[ci].v + scan.blk_dy[c]
+            want = planes[ci][by, bx].reshape(64)[zig]
+            assert np.array_equal(got[b], want), (b, ci, bx, by)
+    for name in ("prog_420_64x64", "big_b444_rst_250x130", "trunc_noeoi"):
+        d = golden.jpg(name)
+        scan, n, why = GpuScan(), C.c_size_t(), C.c_char_p()
+        buf = np.zeros(len(d) + 64, np.uint8)
+        assert L.mjh_extract_scan(d, len(d), 3, C.byref(scan), buf.ctypes.data_as(C.c_void_p), buf.size, C.byref(n), C.byref(why)) == 2, name
