@@ -171,7 +171,7 @@ def end_to_end(ica, ctx, datas, distinct, n_img, src_hash, cbytes, obytes, args)
         # no coefficient staging to speak of: it is only needed for images the GPU walk hands back
         ebs = [ica.Batch(ctx, gchunk, cbytes * 4, cbytes * gchunk, obytes * gchunk) for _ in range(2)]
         for eb in ebs:
-            eb.entropy_reserve(sum(len(x) + 512 for x in jl[:gchunk]) * 2)
+            eb.entropy_reserve(sum(len(x) * 9 // 8 + 4352 for x in jl[:gchunk]))
         for eb in ebs:  # warm-up
             eb.reset()
             eb.decode_jpegs(jl[:gchunk], 3, threads, gpu_entropy=True)

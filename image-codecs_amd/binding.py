@@ -53,7 +53,8 @@ class GpuScan(C.Structure):
     """mjg_scan (include/mij.h): what the GPU entropy stage needs to walk one baseline scan."""
     _fields_ = [("desc", ImageDesc), ("nblocks", C.c_uint32), ("blocks_per_mcu", C.c_uint32), ("blk_comp", C.c_uint8 * 12),
                 ("blk_dx", C.c_uint8 * 12), ("blk_dy", C.c_uint8 * 12), ("dc_tab", C.c_uint8 * 4), ("ac_tab", C.c_uint8 * 4),
-                ("huff", GpuHuff * 8), ("qz", (C.c_uint16 * 64) * 4)]
+                ("huff", GpuHuff * 8), ("qz", (C.c_uint16 * 64) * 4), ("n_seg", C.c_uint32), ("restart_mcus", C.c_uint32),
+                ("seg_table_off", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 _lib = None

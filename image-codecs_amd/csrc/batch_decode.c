@@ -227,9 +227,12 @@ mjh_gpu_job *mjh_decode_batch_gpu_begin(mij_batch *b, const uint8_t *const *bufs
 	}
 	p->cap = p->off + n;
 	p->slen = p->cap + n;
-	/* every image gets a region as large as its file: the unstuffed segment cannot be longer */
+	/* every image gets a region a little larger than its file: the unstuffed data cannot be longer, and each
+	 * restart interval adds about 40 bytes of padding and table (files with intervals shorter than ~350 bytes
+	 * do not fit and take the host walk) */
 	for (i = 0; i < n; ++i) {
-		const size_t need = ((size_t)(lens[i] > 0 ? lens[i] : 0) + 64 + 255) / 256 * 256;
+		const size_t len = (size_t)(lens[i] > 0 ? lens[i] : 0);
+		const size_t need = (len + len / 8 + 4096 + 255) / 256 * 256;
 		p->off[i] = used;
 		p->cap[i] = need;
 		used += need;
@@ -249,9 +252,12 @@ mjh_gpu_job *mjh_decode_batch_gpu_begin(mij_batch *b, const uint8_t *const *bufs
 			continue;
 		}
 		reasons[i] = NULL;
-		if (p->status[i] == 1)
+		if (p->status[i] == 1) {
 			slots[i] = mij_batch_add_stream(b, &p->scans[i], stage + p->off[i], p->slen[i]);
-		else {
+			if (slots[i] == MIJ_E_NOMEM) /* e.g. more restart intervals than the entropy arena has scans for: host walk */
+				p->status[i] = 2;
+		}
+		if (p->status[i] != 1) {
 			slots[i] = mij_batch_add(b, &p->descs[i]);
 			j->todo[i] = 1;
 		}

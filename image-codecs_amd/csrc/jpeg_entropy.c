@@ -1310,7 +1310,7 @@ int mjh_extract_scan(const uint8_t *buf, int len, int req_comp, mjg_scan *scan, 
 	}
 	if (!process_scan_header(d))
 		goto done;
-	if (d->progressive || d->restart_interval != 0 || d->scan_n != d->img_n || (d->img_n != 1 && d->img_n != 3))
+	if (d->progressive || d->scan_n != d->img_n || (d->img_n != 1 && d->img_n != 3))
 		goto done;
 	for (ci = 0; ci < d->scan_n; ++ci)
 		if (d->order[ci] != ci)
@@ -1318,34 +1318,75 @@ int mjh_extract_scan(const uint8_t *buf, int len, int req_comp, mjg_scan *scan, 
 	if (d->img_n == 1 && (d->comp[0].h != 1 || d->comp[0].v != 1))
 		goto done; /* a lone component is walked over its own block grid (codec/jpeg.c:1160-1190), not over MCUs */
 	{
-		/* the entropy segment: up to the first 0xff that is not followed by 0x00 */
-		const uint8_t *p = r.p, *end = r.end, *q;
-		size_t n = 0;
-		int bpm = 0;
-		for (q = p;;) {
+		/* The entropy data: runs of bytes up to a 0xff that is not followed by 0x00.  Without a restart interval
+		 * that marker must be EOI; with one, the data is cut at every RSTn (the reference accepts any RST number,
+		 * :1183) into exactly ceil(MCUs / interval) pieces, the last one ending at EOI. */
+		const uint8_t *q = r.p, *end = r.end;
+		const uint32_t nmcu = (uint32_t)d->mcu_x * (uint32_t)d->mcu_y;
+		const uint32_t dri = (uint32_t)d->restart_interval;
+		const uint32_t want_seg = dri ? (nmcu + dri - 1) / dri : 1;
+		uint32_t seg_off[2], nseg = 0; /* the table itself is appended behind the data */
+		size_t n = 0, seg_start = 0;
+		uint32_t *table = NULL;
+		int bpm = 0, at_eoi = 0;
+		if (want_seg > 65536u)
+			goto done;
+		table = (uint32_t *)malloc(sizeof(uint32_t) * 2 * want_seg);
+		if (!table)
+			goto done;
+		(void)seg_off;
+		while (!at_eoi) {
 			const uint8_t *f = (const uint8_t *)memchr(q, 0xff, (size_t)(end - q));
-			if (!f || f + 1 >= end)
+			size_t run;
+			if (!f || f + 1 >= end) {
+				free(table);
 				goto done; /* no marker behind the data: truncated file, the host walk knows what the reference does */
+			}
+			run = (size_t)(f - q) + (f[1] == 0x00 ? 1u : 0u); /* a stuffed 0xff is data */
+			if (n + run + 64 > stream_cap) {
+				free(table);
+				goto done;
+			}
+			memcpy(stream + n, q, run);
+			n += run;
 			if (f[1] == 0x00) {
 				q = f + 2;
 				continue;
 			}
-			if (f[1] != 0xd9)
-				goto done; /* fill bytes, a restart marker, another scan, ...: host walk */
-			end = f;
-			break;
+			if (f[1] == 0xd9)
+				at_eoi = 1;
+			else if (!(dri && f[1] >= 0xd0 && f[1] <= 0xd7)) {
+				free(table);
+				goto done; /* fill bytes, a stray restart marker, another scan, ...: host walk */
+			}
+			if (nseg >= want_seg) {
+				free(table);
+				goto done; /* more restart markers than intervals */
+			}
+			table[2 * nseg] = (uint32_t)seg_start;
+			table[2 * nseg + 1] = (uint32_t)(n - seg_start);
+			++nseg;
+			memset(stream + n, 0, 32);
+			n = (n + 32 + 3) & ~(size_t)3;
+			seg_start = n;
+			q = f + 2;
 		}
-		if ((size_t)(end - p) + 32 > stream_cap)
+		if (nseg != want_seg) {
+			free(table);
+			goto done; /* EOI before the last interval */
+		}
+		scan->n_seg = dri ? nseg : 0;
+		scan->restart_mcus = dri;
+		scan->reserved = 0;
+		n = (n + 7) & ~(size_t)7;
+		if (n + sizeof(uint32_t) * 2 * nseg + 32 > stream_cap) {
+			free(table);
 			goto done;
-		for (q = p; q < end;) {
-			const uint8_t *f = (const uint8_t *)memchr(q, 0xff, (size_t)(end - q));
-			const size_t run = (size_t)((f ? f + 1 : end) - q);
-			memcpy(stream + n, q, run);
-			n += run;
-			q += run;
-			if (f)
-				++q; /* the stuffed zero */
 		}
+		scan->seg_table_off = (uint32_t)n;
+		memcpy(stream + n, table, sizeof(uint32_t) * 2 * nseg);
+		n += sizeof(uint32_t) * 2 * nseg;
+		free(table);
 		*stream_len = n;
 		for (ci = 0; ci < d->img_n; ++ci) {
 			int x, y;

@@ -54,6 +54,8 @@ struct DevScan {
 	uint32_t nblocks;    /* blocks the scan must produce: mcu_x * mcu_y * bpm */
 	uint32_t blk_off;    /* where this image's per-block arrays (DC differences, L1) start */
 	uint32_t bpm, mcu_x;
+	uint32_t first_mcu;  /* restart intervals: the MCU this segment starts at (0 without restart markers) */
+	uint32_t last_seg;   /* the segment that ends at EOI */
 	uint8_t blk_comp[12], blk_dx[12], blk_dy[12]; /* block-in-MCU -> component and position inside the MCU */
 	uint8_t dc_tab[4], ac_tab[4];                 /* component -> table index (0..3 DC, 4..7 AC) of this scan's eight tables */
 	uint32_t tab_off;    /* first of the eight DevHuff of this scan */
@@ -416,8 +418,8 @@ __global__ __launch_bounds__(256) void k_es_write(const DevScan *__restrict__ sc
 	wr.pfinal = &pfinal[wk.scan];
 	if (wr.ord >= sc.nblocks)
 		return;
-	const uint32_t m = wr.ord / sc.bpm;
-	if (wr.ord - m * sc.bpm != s.c) { /* the chain is inconsistent: cannot happen after convergence */
+	const uint32_t ml = wr.ord / sc.bpm, m = sc.first_mcu + ml;
+	if (wr.ord - ml * sc.bpm != s.c) { /* the chain is inconsistent: cannot happen after convergence */
 		atomicOr(&anom[wk.scan], 2u);
 		return;
 	}
@@ -467,8 +469,8 @@ __global__ __launch_bounds__(256) void k_es_tails(const DevScan *__restrict__ sc
 	wr.pfinal = scratch; /* never reached: the walk stops at the end of this block */
 	if (wr.ord >= sc.nblocks)
 		return;
-	const uint32_t m = wr.ord / sc.bpm;
-	if (wr.ord - m * sc.bpm != s.c)
+	const uint32_t ml = wr.ord / sc.bpm, m = sc.first_mcu + ml;
+	if (wr.ord - ml * sc.bpm != s.c)
 		return;
 	wr.my = m / sc.mcu_x;
 	wr.mx = m - wr.my * sc.mcu_x;
@@ -500,8 +502,11 @@ __global__ __launch_bounds__(256) void k_es_dc(const DevScan *__restrict__ scans
 	/* After its last block the reference skips ahead to the next 0xff and takes the byte behind it for a marker
 	 * (codec/jpeg.c:1727-1737): a stuffed 0xff00 left over in unread data makes it fail with "unknown marker".
 	 * How many bytes its 32-bit look-ahead had already taken is not tracked here, so any 0xff data byte behind
-	 * the byte of the final bit position sends the image to the host walk. */
-	{
+	 * the byte of the final bit position sends the image to the host walk.
+	 * Before a restart marker the rule is different: the reference only sees the marker if its refill (to 24 bits,
+	 * :1181) reaches it, otherwise it quietly stops decoding (:1183); with less than a byte of padding behind the
+	 * final bit position it certainly does, anything more goes to the host walk. */
+	if (sc.last_seg) {
 		const uint8_t *st = streams + sc.stream_off;
 		const uint32_t nbytes = sc.nbits >> 3;
 		uint32_t found = 0;
@@ -509,7 +514,8 @@ __global__ __launch_bounds__(256) void k_es_dc(const DevScan *__restrict__ scans
 			found |= st[q] == 0xffu;
 		if (found)
 			atomicOr(&anom[blockIdx.x], 32u);
-	}
+	} else if (threadIdx.x == 0 && (pfinal[blockIdx.x] > sc.nbits || sc.nbits - pfinal[blockIdx.x] >= 8u))
+		atomicOr(&anom[blockIdx.x], 64u);
 	int sum[4] = {0, 0, 0, 0};
 	for (uint32_t m = lo; m < hi; ++m)
 		for (uint32_t c = 0; c < sc.bpm; ++c)
@@ -530,7 +536,7 @@ __global__ __launch_bounds__(256) void k_es_dc(const DevScan *__restrict__ scans
 	for (int k = 0; k < 4; ++k)
 		pred[k] = part[threadIdx.x][k];
 	uint32_t mymax = 0;
-	uint32_t my = lo / sc.mcu_x, mx = lo - my * sc.mcu_x;
+	uint32_t my = (sc.first_mcu + lo) / sc.mcu_x, mx = (sc.first_mcu + lo) - my * sc.mcu_x;
 	for (uint32_t m = lo; m < hi; ++m) {
 		for (uint32_t c = 0; c < sc.bpm; ++c) {
 			const uint32_t ci = sc.blk_comp[c];

@@ -1004,10 +1004,10 @@ struct EsArena {
 	int16_t *d_dcdiff;
 	uint32_t *d_l1;
 	size_t blk_cap;
-	uint32_t *d_verdict, *h_verdict; /* [5][max_images]: anomaly, changed, total, l1max, final bit position */
+	uint32_t *d_verdict, *h_verdict; /* [5][scan_cap]: anomaly, changed, total, l1max, final bit position */
 	uint32_t *d_rounds_changed, *h_rounds_changed; /* [MAX_ROUNDS] sum over scans, for tuning */
 	std::vector<int> scan_slot; /* scan index -> batch slot */
-	size_t sub_used, blk_used, work_used;
+	size_t sub_used, blk_used, work_used, scan_cap, n_tabs;
 	int last_rounds, cur;
 	bool in_flight;
 };
@@ -1046,7 +1046,7 @@ static void es_reset_fwd(EsArena *e)
 	if (!e)
 		return;
 	e->scan_slot.clear();
-	e->sub_used = e->blk_used = e->work_used = 0;
+	e->sub_used = e->blk_used = e->work_used = e->n_tabs = 0;
 	e->in_flight = false;
 }
 
@@ -1063,13 +1063,14 @@ extern "C" int mij_batch_entropy_reserve(mij_batch *b, size_t stream_bytes)
 	memset(static_cast<void *>(e), 0, offsetof(EsArena, scan_slot));
 	const size_t n = (size_t)b->max_images;
 	e->stream_cap = align_up(stream_bytes + 64 * n, 256);
-	e->sub_cap = e->stream_cap * 8 / MIJ_ES_BITS + 2 * n;
+	e->scan_cap = 16 * n + 1024; /* restart intervals are walked one DevScan each */
+	e->sub_cap = e->stream_cap * 8 / MIJ_ES_BITS + 2 * e->scan_cap;
 	e->blk_cap = b->coef_cap / 128 + n;
-	e->work_cap = e->sub_cap / 256 + 2 * n;
+	e->work_cap = e->sub_cap / 256 + 2 * e->scan_cap;
 	hipError_t r = hipHostMalloc(reinterpret_cast<void **>(&e->stage), e->stream_cap, hipHostMallocDefault);
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_stream), e->stream_cap);
-	if (r == hipSuccess) r = hipHostMalloc(reinterpret_cast<void **>(&e->h_scans), sizeof(DevScan) * n, hipHostMallocDefault);
-	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_scans), sizeof(DevScan) * n);
+	if (r == hipSuccess) r = hipHostMalloc(reinterpret_cast<void **>(&e->h_scans), sizeof(DevScan) * e->scan_cap, hipHostMallocDefault);
+	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_scans), sizeof(DevScan) * e->scan_cap);
 	if (r == hipSuccess) r = hipHostMalloc(reinterpret_cast<void **>(&e->h_huff), sizeof(DevHuff) * 8 * n, hipHostMallocDefault);
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_huff), sizeof(DevHuff) * 8 * n);
 	if (r == hipSuccess) r = hipHostMalloc(reinterpret_cast<void **>(&e->h_work), sizeof(EsWork) * e->work_cap, hipHostMallocDefault);
@@ -1081,8 +1082,8 @@ extern "C" int mij_batch_entropy_reserve(mij_batch *b, size_t stream_bytes)
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_base), sizeof(uint32_t) * e->sub_cap);
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_dcdiff), sizeof(int16_t) * e->blk_cap);
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_l1), sizeof(uint32_t) * e->blk_cap);
-	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_verdict), sizeof(uint32_t) * 5 * n);
-	if (r == hipSuccess) r = hipHostMalloc(reinterpret_cast<void **>(&e->h_verdict), sizeof(uint32_t) * 5 * n, hipHostMallocDefault);
+	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_verdict), sizeof(uint32_t) * 5 * e->scan_cap);
+	if (r == hipSuccess) r = hipHostMalloc(reinterpret_cast<void **>(&e->h_verdict), sizeof(uint32_t) * 5 * e->scan_cap, hipHostMallocDefault);
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_rounds_changed), sizeof(uint32_t) * ES_MAX_ROUNDS);
 	if (r == hipSuccess) r = hipHostMalloc(reinterpret_cast<void **>(&e->h_rounds_changed), sizeof(uint32_t) * ES_MAX_ROUNDS, hipHostMallocDefault);
 	if (r != hipSuccess) {
@@ -1111,44 +1112,70 @@ extern "C" int mij_batch_add_stream(mij_batch *b, const mjg_scan *scan, uint8_t 
 		return set_err(MIJ_E_ARG, "the stream must lie 4-byte aligned inside the pinned entropy region with 32 spare bytes behind it");
 	if (scan->blocks_per_mcu < 1 || scan->blocks_per_mcu > 10 || scan->nblocks == 0 || stream_len >= (1u << 28))
 		return set_err(MIJ_E_ARG, "bad scan description");
-	const size_t nsub = (stream_len * 8 + MIJ_ES_BITS - 1) / MIJ_ES_BITS;
-	if (e->sub_used + nsub + 1 > e->sub_cap || e->blk_used + scan->nblocks > e->blk_cap || e->work_used + nsub / 256 + 1 > e->work_cap)
+	/* one DevScan per restart interval (one for the whole stream without restart markers) */
+	const uint32_t nseg = scan->n_seg ? scan->n_seg : 1u;
+	if ((size_t)scan->seg_table_off + 8u * (size_t)nseg > stream_len || (scan->seg_table_off & 3u))
+		return set_err(MIJ_E_ARG, "bad segment table");
+	const uint32_t *table = reinterpret_cast<const uint32_t *>(stream + scan->seg_table_off);
+	const uint32_t nmcu = scan->nblocks / scan->blocks_per_mcu;
+	size_t need_sub = 0, need_work = 0;
+	for (uint32_t g = 0; g < nseg; ++g) {
+		const size_t off = table[2 * g], len = table[2 * g + 1];
+		if ((off & 3u) || off + len + 32 > stream_len + 32 || off + len > scan->seg_table_off)
+			return set_err(MIJ_E_ARG, "bad segment %u", g);
+		const size_t ns = (len * 8 + MIJ_ES_BITS - 1) / MIJ_ES_BITS;
+		need_sub += ns ? ns : 1;
+		need_work += (ns ? ns : 1) / 256 + 1;
+	}
+	if (scan->n_seg && ((uint64_t)scan->restart_mcus * (nseg - 1) >= nmcu || (uint64_t)scan->restart_mcus * nseg < nmcu))
+		return set_err(MIJ_E_ARG, "segment count does not match the restart interval");
+	if (e->sub_used + need_sub > e->sub_cap || e->blk_used + scan->nblocks > e->blk_cap || e->work_used + need_work > e->work_cap ||
+		 e->scan_slot.size() + nseg > e->scan_cap || e->n_tabs + 1 > (size_t)b->max_images)
 		return set_err(MIJ_E_NOMEM, "entropy arena exhausted");
 	const int slot = add_common(b, &scan->desc, -1, true);
 	if (slot < 0)
 		return slot;
 	Slot &s = b->slots[(size_t)slot];
-	const size_t k = e->scan_slot.size();
 	s.dev_coef = 1;
-	s.es_index = (int)k;
-	memset(stream + stream_len, 0, 32);
-	DevScan &d = e->h_scans[k];
-	memset(&d, 0, sizeof(d));
-	d.stream_off = (uint64_t)(stream - e->stage);
-	d.nbits = (uint32_t)(stream_len * 8);
-	d.nsub = (uint32_t)(nsub ? nsub : 1);
-	d.sub_off = (uint32_t)e->sub_used;
-	d.img = (uint32_t)slot;
-	d.nblocks = scan->nblocks;
-	d.blk_off = (uint32_t)e->blk_used;
-	d.bpm = scan->blocks_per_mcu;
-	d.mcu_x = (uint32_t)scan->desc.mcu_x;
-	memcpy(d.blk_comp, scan->blk_comp, 12);
-	memcpy(d.blk_dx, scan->blk_dx, 12);
-	memcpy(d.blk_dy, scan->blk_dy, 12);
-	memcpy(d.dc_tab, scan->dc_tab, 4);
-	memcpy(d.ac_tab, scan->ac_tab, 4);
-	d.tab_off = (uint32_t)(8 * k);
-	memcpy(d.qz, scan->qz, sizeof(d.qz));
+	s.es_index = (int)e->scan_slot.size();
 	static_assert(sizeof(DevHuff) == sizeof(mjg_huff), "mjg_huff and DevHuff must match");
-	memcpy(&e->h_huff[8 * k], scan->huff, sizeof(mjg_huff) * 8);
-	for (uint32_t f = 0; f < d.nsub; f += 256) {
-		EsWork w = {(uint32_t)k, f};
-		e->h_work[e->work_used++] = w;
+	const size_t tab = e->n_tabs++;
+	memcpy(&e->h_huff[8 * tab], scan->huff, sizeof(mjg_huff) * 8);
+	uint32_t first_mcu = 0;
+	for (uint32_t g = 0; g < nseg; ++g) {
+		const size_t k = e->scan_slot.size();
+		const size_t off = table[2 * g], len = table[2 * g + 1];
+		const uint32_t seg_mcus = scan->n_seg ? (g + 1 < nseg ? scan->restart_mcus : nmcu - first_mcu) : nmcu;
+		const size_t ns = (len * 8 + MIJ_ES_BITS - 1) / MIJ_ES_BITS;
+		DevScan &d = e->h_scans[k];
+		memset(&d, 0, sizeof(d));
+		d.stream_off = (uint64_t)(stream - e->stage) + off;
+		d.nbits = (uint32_t)(len * 8);
+		d.nsub = (uint32_t)(ns ? ns : 1);
+		d.sub_off = (uint32_t)e->sub_used;
+		d.img = (uint32_t)slot;
+		d.nblocks = seg_mcus * scan->blocks_per_mcu;
+		d.blk_off = (uint32_t)e->blk_used;
+		d.bpm = scan->blocks_per_mcu;
+		d.mcu_x = (uint32_t)scan->desc.mcu_x;
+		d.first_mcu = first_mcu;
+		d.last_seg = g + 1 == nseg;
+		memcpy(d.blk_comp, scan->blk_comp, 12);
+		memcpy(d.blk_dx, scan->blk_dx, 12);
+		memcpy(d.blk_dy, scan->blk_dy, 12);
+		memcpy(d.dc_tab, scan->dc_tab, 4);
+		memcpy(d.ac_tab, scan->ac_tab, 4);
+		d.tab_off = (uint32_t)(8 * tab);
+		memcpy(d.qz, scan->qz, sizeof(d.qz));
+		for (uint32_t f = 0; f < d.nsub; f += 256) {
+			EsWork w = {(uint32_t)k, f};
+			e->h_work[e->work_used++] = w;
+		}
+		e->sub_used += d.nsub;
+		e->blk_used += d.nblocks;
+		e->scan_slot.push_back(slot);
+		first_mcu += seg_mcus;
 	}
-	e->sub_used += d.nsub;
-	e->blk_used += d.nblocks;
-	e->scan_slot.push_back(slot);
 	return slot;
 }
 
@@ -1158,8 +1185,8 @@ static int es_enqueue_tail(mij_batch *b)
 	EsArena *e = b->es;
 	hipStream_t st = b->stream;
 	const size_t ns = e->scan_slot.size();
-	uint32_t *v_anom = e->d_verdict, *v_changed = e->d_verdict + b->max_images, *v_total = e->d_verdict + 2 * (size_t)b->max_images,
-				*v_l1 = e->d_verdict + 3 * (size_t)b->max_images, *v_pfinal = e->d_verdict + 4 * (size_t)b->max_images;
+	uint32_t *v_anom = e->d_verdict, *v_changed = e->d_verdict + e->scan_cap, *v_total = e->d_verdict + 2 * e->scan_cap,
+				*v_l1 = e->d_verdict + 3 * e->scan_cap, *v_pfinal = e->d_verdict + 4 * e->scan_cap;
 	const dim3 gw((unsigned)e->work_used), gs((unsigned)ns), blk(256);
 	hipLaunchKernelGGL(k_es_offsets, gs, blk, 0, st, e->d_scans, e->d_cnt, e->d_base, v_total);
 	HIP_TRY(hipGetLastError());
@@ -1172,7 +1199,7 @@ static int es_enqueue_tail(mij_batch *b)
 	hipLaunchKernelGGL(k_es_dc, gs, blk, 0, st, e->d_scans, b->d_imgs, v_total, v_changed, reinterpret_cast<int16_t *>(b->d_coef), e->d_dcdiff, e->d_l1,
 							 v_anom, v_l1, v_pfinal, e->d_stream);
 	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipMemcpyAsync(e->h_verdict, e->d_verdict, sizeof(uint32_t) * 5 * (size_t)b->max_images, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(e->h_verdict, e->d_verdict, sizeof(uint32_t) * 5 * e->scan_cap, hipMemcpyDeviceToHost, st));
 	return MIJ_OK;
 }
 
@@ -1181,7 +1208,7 @@ static int es_enqueue_round(mij_batch *b)
 	EsArena *e = b->es;
 	hipStream_t st = b->stream;
 	const size_t ns = e->scan_slot.size();
-	uint32_t *v_changed = e->d_verdict + b->max_images;
+	uint32_t *v_changed = e->d_verdict + e->scan_cap;
 	const dim3 gw((unsigned)e->work_used), blk(256);
 	HIP_TRY(hipMemsetAsync(v_changed, 0, sizeof(uint32_t) * ns, st));
 	hipLaunchKernelGGL(k_es_sync, gw, blk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, e->d_start, e->d_end[e->cur], e->d_end[e->cur ^ 1], e->d_cnt, v_changed);
@@ -1209,7 +1236,7 @@ extern "C" int mij_batch_entropy_launch(mij_batch *b)
 		b->h_imgs[i] = b->slots[i].dev;
 	HIP_TRY(hipMemcpyAsync(b->d_imgs, b->h_imgs, sizeof(DevImage) * n, hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(e->d_scans, e->h_scans, sizeof(DevScan) * ns, hipMemcpyHostToDevice, st));
-	HIP_TRY(hipMemcpyAsync(e->d_huff, e->h_huff, sizeof(DevHuff) * 8 * ns, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(e->d_huff, e->h_huff, sizeof(DevHuff) * 8 * e->n_tabs, hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(e->d_work, e->h_work, sizeof(EsWork) * e->work_used, hipMemcpyHostToDevice, st));
 	/* streams: one copy from the first to the last byte in use */
 	size_t lo = (size_t)-1, hi = 0;
@@ -1222,7 +1249,7 @@ extern "C" int mij_batch_entropy_launch(mij_batch *b)
 	HIP_TRY(hipMemcpyAsync(e->d_stream + lo, e->stage + lo, hi - lo, hipMemcpyHostToDevice, st));
 	/* the write pass stores every block of the MCU grid whole and its L1 word with it, so neither the
 	 * coefficient planes nor the accumulators need clearing; the verdicts do */
-	HIP_TRY(hipMemsetAsync(e->d_verdict, 0, sizeof(uint32_t) * 5 * (size_t)b->max_images, st));
+	HIP_TRY(hipMemsetAsync(e->d_verdict, 0, sizeof(uint32_t) * 5 * e->scan_cap, st));
 	const dim3 gw((unsigned)e->work_used), blk(256);
 	hipLaunchKernelGGL(k_es_cold, gw, blk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, e->d_start, e->d_end[0], e->d_cnt);
 	HIP_TRY(hipGetLastError());
@@ -1262,24 +1289,24 @@ extern "C" int mij_batch_entropy_finish(mij_batch *b, int *fallback, int cap, in
 	for (size_t k = 0; k < ns; ++k)
 		unsettled |= (e->h_verdict[k] & 8u) != 0;
 	if (unsettled) {
-		uint32_t *v_changed = e->d_verdict + b->max_images;
+		uint32_t *v_changed = e->d_verdict + e->scan_cap;
 		while (e->last_rounds < ES_MAX_ROUNDS) {
 			int rc = MIJ_OK;
 			for (int r = 0; r < 4 && e->last_rounds < ES_MAX_ROUNDS && rc == MIJ_OK; ++r)
 				rc = es_enqueue_round(b);
 			if (rc != MIJ_OK)
 				return rc;
-			HIP_TRY(hipMemcpyAsync(e->h_verdict + b->max_images, v_changed, sizeof(uint32_t) * ns, hipMemcpyDeviceToHost, st));
+			HIP_TRY(hipMemcpyAsync(e->h_verdict + e->scan_cap, v_changed, sizeof(uint32_t) * ns, hipMemcpyDeviceToHost, st));
 			HIP_TRY(hipStreamSynchronize(st));
 			uint32_t any = 0;
 			for (size_t k = 0; k < ns; ++k)
-				any |= e->h_verdict[(size_t)b->max_images + k];
+				any |= e->h_verdict[e->scan_cap + k];
 			if (!any)
 				break;
 		}
 		/* the passes behind the rounds again, on clean verdicts (the last round's counters stay) */
-		HIP_TRY(hipMemsetAsync(e->d_verdict, 0, sizeof(uint32_t) * (size_t)b->max_images, st));
-		HIP_TRY(hipMemsetAsync(e->d_verdict + 2 * (size_t)b->max_images, 0, sizeof(uint32_t) * 3 * (size_t)b->max_images, st));
+		HIP_TRY(hipMemsetAsync(e->d_verdict, 0, sizeof(uint32_t) * e->scan_cap, st));
+		HIP_TRY(hipMemsetAsync(e->d_verdict + 2 * e->scan_cap, 0, sizeof(uint32_t) * 3 * e->scan_cap, st));
 		int rc = es_enqueue_tail(b);
 		if (rc != MIJ_OK)
 			return rc;
@@ -1288,17 +1315,25 @@ extern "C" int mij_batch_entropy_finish(mij_batch *b, int *fallback, int cap, in
 	if (getenv("MIJ_ES_DEBUG"))
 		for (size_t k = 0; k < ns; ++k)
 			fprintf(stderr, "es scan %zu slot %d: anomaly %u changed %u blocks %u/%u l1max %u nsub %u rounds %d\n", k, e->scan_slot[k], e->h_verdict[k],
-					  e->h_verdict[(size_t)b->max_images + k], e->h_verdict[2 * (size_t)b->max_images + k], e->h_scans[k].nblocks,
-					  e->h_verdict[3 * (size_t)b->max_images + k], e->h_scans[k].nsub, e->last_rounds);
-	for (size_t k = 0; k < ns; ++k) {
-		Slot &s = b->slots[(size_t)e->scan_slot[k]];
-		if (e->h_verdict[k]) {
+					  e->h_verdict[e->scan_cap + k], e->h_verdict[2 * e->scan_cap + k], e->h_scans[k].nblocks,
+					  e->h_verdict[3 * e->scan_cap + k], e->h_scans[k].nsub, e->last_rounds);
+	/* a slot's restart intervals are consecutive scans: any verdict bit in one of them hands the image back */
+	for (size_t k = 0; k < ns;) {
+		const int slot = e->scan_slot[k];
+		uint32_t bad = 0, l1max = 0;
+		for (; k < ns && e->scan_slot[k] == slot; ++k) {
+			bad |= e->h_verdict[k];
+			const uint32_t v = e->h_verdict[3 * e->scan_cap + k];
+			l1max = v > l1max ? v : l1max;
+		}
+		Slot &s = b->slots[(size_t)slot];
+		if (bad) {
 			if (*n_fallback < cap && fallback)
-				fallback[*n_fallback] = e->scan_slot[k];
+				fallback[*n_fallback] = slot;
 			++*n_fallback;
 			continue;
 		}
-		if (e->h_verdict[3 * (size_t)b->max_images + k] > MIJ_BLOCK_L1_LIMIT)
+		if (l1max > MIJ_BLOCK_L1_LIMIT)
 			s.desc.flags |= MIJ_FLAG_WIDE_IDCT;
 	}
 	b->uploaded = b->launched = false;

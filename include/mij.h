@@ -213,6 +213,12 @@ typedef struct {
 	uint8_t dc_tab[4], ac_tab[4];                 /* component -> index into huff[] (0..3 DC tables, 4..7 AC tables) */
 	mjg_huff huff[8];
 	uint16_t qz[4][64];                           /* per component, zigzag order */
+	/* Restart intervals (DRI): every interval is walked on its own (DC prediction starts at 0 in each, codec/jpeg.c
+	 * :1142-1153).  n_seg intervals of restart_mcus MCUs (the last one shorter); their unstuffed bytes lie at
+	 * seg[k].off .. + seg[k].len of the stream buffer, 4-byte aligned and 32 zero bytes apart, where seg = the
+	 * table of n_seg {uint32 off, uint32 len} pairs at byte seg_table_off of the same buffer.  n_seg == 0: no
+	 * restart interval, the whole stream is one segment at offset 0. */
+	uint32_t n_seg, restart_mcus, seg_table_off, reserved;
 } mjg_scan;
 
 /* pinned + device arenas for stream_bytes of unstuffed entropy data; once per batch */
@@ -221,7 +227,7 @@ int mij_batch_entropy_reserve(mij_batch *b, size_t stream_bytes);
 uint8_t *mij_batch_entropy_stage(mij_batch *b, size_t *capacity);
 /* new slot whose coefficients the GPU walk will produce; stream = pointer into the pinned region, followed by
  * at least 32 writable bytes (zeroed here).  Returns the slot or a negative code. */
-int mij_batch_add_stream(mij_batch *b, const mjg_scan *scan, uint8_t *stream, size_t stream_len);
+int mij_batch_add_stream(mij_batch *b, const mjg_scan *scan, uint8_t *stream, size_t stream_len); /* stream_len: everything mjh_extract_scan wrote, segment table included */
 /* H2D of the streams, the five kernels, D2H of the verdicts; waits.  fallback[0..*n_fallback) = slots the host
  * walk must redo (mij_batch_fallback_prepare, then decode into mij_batch_coef as usual). */
 int mij_batch_entropy_run(mij_batch *b, int *fallback, int cap, int *n_fallback);

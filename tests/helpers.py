@@ -308,3 +308,38 @@ def progressive_grey_from_444(plan, du, script=1):
     n = L.pw_write_progressive(ptrs, 1, plan.width, plan.height, one, one, qt.ctypes.data_as(C.c_void_p), int(script), out.ctypes.data_as(C.c_void_p), cap)
     assert 0 < n <= cap, n
     return out[:n].tobytes()
+
+
+def baseline_from_du(plan, du, restart_mcus=0, layout="native"):
+    """A baseline (SOF0) stream from a writer plan's data units through the test-side writer, with optimal tables
+    and, when restart_mcus > 0, a DRI segment and RSTn markers.  layout: "native" (the plan's own 4:2:0 or
+    4:4:4), "422" or "grey" (both from a 4:4:4 plan, see progressive_422_from_444)."""
+    L = C.CDLL(build_prog_writer())
+    L.pw_write_baseline.restype = C.c_long
+    L.pw_write_baseline.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, P_INT, P_INT, C.c_void_p, C.c_int, C.c_void_p, C.c_long]
+    planes, samp = du_to_planes(plan, du)
+    hs, vs = list(samp), list(samp)
+    if layout == "422":
+        assert plan.du_per_mcu == 3
+        mcu_x, mcu_y = (plan.width + 15) // 16, (plan.height + 7) // 8
+        y = np.zeros((mcu_y, 2 * mcu_x, 64), np.int16)
+        y[:, :planes[0].shape[1]] = planes[0]
+        new = [y]
+        for c in (1, 2):
+            sub = planes[c][:, 0::2]
+            p = np.zeros((mcu_y, mcu_x, 64), np.int16)
+            p[:, :sub.shape[1]] = sub
+            new.append(p)
+        planes, hs, vs = new, [2, 1, 1], [1, 1, 1]
+    elif layout == "grey":
+        assert plan.du_per_mcu == 3
+        planes, hs, vs = [np.ascontiguousarray(planes[0])], [1], [1]
+    n_c = len(planes)
+    ptrs = (C.c_void_p * n_c)(*[p.ctypes.data for p in planes])
+    qt = np.concatenate([np.frombuffer(bytes(plan.ytab), np.uint8), np.frombuffer(bytes(plan.ctab), np.uint8)])
+    cap = 4096 + sum(p.size for p in planes) * 3
+    out = np.empty(cap, np.uint8)
+    n = L.pw_write_baseline(ptrs, n_c, plan.width, plan.height, (C.c_int * n_c)(*hs), (C.c_int * n_c)(*vs), qt.ctypes.data_as(C.c_void_p),
+                            int(restart_mcus), out.ctypes.data_as(C.c_void_p), cap)
+    assert 0 < n <= cap, n
+    return out[:n].tobytes()

@@ -491,3 +491,181 @@ long pw_write_progressive(const int16_t *const *planes, int ncomp, int width, in
 	free(s);
 	return len;
 }
+
+/* ------------------------------------------------------------------ baseline (SOF0) twin with restart intervals
+ *
+ * One interleaved scan, optimal tables per class (table 0: component 0, table 1: the others), and, when
+ * restart_mcus > 0, a DRI segment plus an RSTn marker after every restart_mcus MCUs (T.81 E.1.4, F.1.1.5.3):
+ * the layout cameras write and the reference's own writer never does.
+ */
+typedef struct {
+	long freq[4][257]; /* DC0, DC1, AC0, AC1 */
+	uint16_t code[4][256];
+	uint8_t size[4][256];
+} bl_tabs;
+
+static void bl_symbol(pw_state *s, bl_tabs *t, int which, int sym)
+{
+	if (s->gather)
+		++t->freq[which][sym];
+	else
+		put_bits(s, t->code[which][sym], t->size[which][sym]);
+}
+
+static void bl_block(pw_state *s, bl_tabs *t, int cls, const int16_t *blk, int *pred)
+{
+	int diff = blk[0] - *pred, a = diff < 0 ? -diff : diff, nbits = bitlen((unsigned)a), k, r = 0;
+	*pred = blk[0];
+	bl_symbol(s, t, cls, nbits);
+	if (nbits)
+		emit_bits(s, (unsigned)(diff < 0 ? diff - 1 : diff), nbits);
+	for (k = 1; k < 64; ++k) {
+		int v = blk[k], m;
+		if (v == 0) {
+			++r;
+			continue;
+		}
+		while (r > 15) {
+			bl_symbol(s, t, 2 + cls, 0xf0);
+			r -= 16;
+		}
+		m = v < 0 ? -v : v;
+		nbits = bitlen((unsigned)m);
+		bl_symbol(s, t, 2 + cls, (r << 4) | nbits);
+		emit_bits(s, (unsigned)(v < 0 ? v - 1 : v), nbits);
+		r = 0;
+	}
+	if (r > 0)
+		bl_symbol(s, t, 2 + cls, 0x00);
+}
+
+static void bl_scan(pw_state *s, bl_tabs *t, pw_frame *f, int restart_mcus)
+{
+	int i, j, c, x, y, count = 0, rst = 0;
+	memset(f->dc_pred, 0, sizeof f->dc_pred);
+	for (j = 0; j < f->mcu_y; ++j)
+		for (i = 0; i < f->mcu_x; ++i) {
+			if (restart_mcus && count == restart_mcus) {
+				if (!s->gather) {
+					flush_bits(s);
+					put_u16(s, 0xffd0u + (unsigned)(rst & 7));
+				}
+				++rst;
+				count = 0;
+				memset(f->dc_pred, 0, sizeof f->dc_pred);
+			}
+			for (c = 0; c < f->ncomp; ++c)
+				for (y = 0; y < f->vs[c]; ++y)
+					for (x = 0; x < f->hs[c]; ++x)
+						bl_block(s, t, c == 0 ? 0 : 1, block_at(f, c, i * f->hs[c] + x, j * f->vs[c] + y), &f->dc_pred[c]);
+			++count;
+		}
+}
+
+long pw_write_baseline(const int16_t *const *planes, int ncomp, int width, int height, const int *hs, const int *vs, const uint8_t *qtab /* [2][64] */,
+							  int restart_mcus, uint8_t *out, long cap)
+{
+	pw_state *s;
+	bl_tabs *t;
+	pw_frame f;
+	int c, i, k;
+	long len;
+	if ((ncomp != 1 && ncomp != 3) || width < 1 || height < 1 || width > 65535 || height > 65535 || restart_mcus < 0 || restart_mcus > 65535)
+		return -1;
+	memset(&f, 0, sizeof f);
+	f.ncomp = ncomp;
+	f.width = width;
+	f.height = height;
+	for (c = 0; c < ncomp; ++c) {
+		if (hs[c] < 1 || hs[c] > 4 || vs[c] < 1 || vs[c] > 4)
+			return -1;
+		f.hs[c] = hs[c];
+		f.vs[c] = vs[c];
+		if (hs[c] > f.hmax)
+			f.hmax = hs[c];
+		if (vs[c] > f.vmax)
+			f.vmax = vs[c];
+		f.plane[c] = planes[c];
+	}
+	f.mcu_x = (width + 8 * f.hmax - 1) / (8 * f.hmax);
+	f.mcu_y = (height + 8 * f.vmax - 1) / (8 * f.vmax);
+	for (c = 0; c < ncomp; ++c) {
+		f.bw[c] = f.mcu_x * f.hs[c];
+		f.bh[c] = f.mcu_y * f.vs[c];
+	}
+	s = (pw_state *)calloc(1, sizeof *s);
+	t = (bl_tabs *)calloc(1, sizeof *t);
+	if (!s || !t) {
+		free(s);
+		free(t);
+		return -1;
+	}
+	s->out = out;
+	s->cap = cap;
+	s->gather = 1;
+	bl_scan(s, t, &f, restart_mcus);
+	s->gather = 0;
+	put_u16(s, 0xffd8);
+	for (i = 0; i < (ncomp == 1 ? 1 : 2); ++i) {
+		put_u16(s, 0xffdb);
+		put_u16(s, 67);
+		put_byte(s, (unsigned)i);
+		for (k = 0; k < 64; ++k)
+			put_byte(s, qtab[i * 64 + k]);
+	}
+	put_u16(s, 0xffc0);
+	put_u16(s, (unsigned)(8 + 3 * ncomp));
+	put_byte(s, 8);
+	put_u16(s, (unsigned)height);
+	put_u16(s, (unsigned)width);
+	put_byte(s, (unsigned)ncomp);
+	for (c = 0; c < ncomp; ++c) {
+		put_byte(s, (unsigned)c + 1);
+		put_byte(s, (unsigned)((f.hs[c] << 4) | f.vs[c]));
+		put_byte(s, c == 0 ? 0 : 1);
+	}
+	for (i = 0; i < 4; ++i) { /* DC0 DC1 AC0 AC1 */
+		uint8_t bits[17], vals[256];
+		unsigned code = 0;
+		int nvals, l, n, q = 0;
+		if (ncomp == 1 && (i & 1))
+			continue;
+		gen_table(t->freq[i], bits, vals, &nvals);
+		for (l = 1; l <= 16; ++l) {
+			for (n = 0; n < bits[l]; ++n, ++q) {
+				t->code[i][vals[q]] = (uint16_t)code++;
+				t->size[i][vals[q]] = (uint8_t)l;
+			}
+			code <<= 1;
+		}
+		put_u16(s, 0xffc4);
+		put_u16(s, (unsigned)(2 + 1 + 16 + nvals));
+		put_byte(s, (unsigned)(((i >> 1) << 4) | (i & 1)));
+		for (l = 1; l <= 16; ++l)
+			put_byte(s, bits[l]);
+		for (n = 0; n < nvals; ++n)
+			put_byte(s, vals[n]);
+	}
+	if (restart_mcus) {
+		put_u16(s, 0xffdd);
+		put_u16(s, 4);
+		put_u16(s, (unsigned)restart_mcus);
+	}
+	put_u16(s, 0xffda);
+	put_u16(s, (unsigned)(6 + 2 * ncomp));
+	put_byte(s, (unsigned)ncomp);
+	for (c = 0; c < ncomp; ++c) {
+		put_byte(s, (unsigned)c + 1);
+		put_byte(s, c == 0 ? 0x00 : 0x11);
+	}
+	put_byte(s, 0);
+	put_byte(s, 63);
+	put_byte(s, 0);
+	bl_scan(s, t, &f, restart_mcus);
+	flush_bits(s);
+	put_u16(s, 0xffd9);
+	len = s->len;
+	free(s);
+	free(t);
+	return len;
+}

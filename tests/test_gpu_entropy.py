@@ -45,7 +45,7 @@ def test_gpu_walk_refuses_what_it_should(ica, oracle, gpu_ctx, golden):
     and the host walk's result for those slots is what the oracle says."""
     b = ica.Batch(gpu_ctx, 16, 64 << 20, 64 << 20, 64 << 20)
     b.entropy_reserve(8 << 20)
-    for name in ("prog_420_64x64", "big_b444_rst_250x130"):
+    for name in ("prog_420_64x64", "dri_without_rst"):
         st, _ = b.add_jpeg_stream(golden.jpg(name), 3)
         assert st == 2, name
     st, _ = b.add_jpeg_stream(golden.jpg("garbage"), 3)
@@ -187,3 +187,49 @@ def test_wide_streams_in_every_fused_family_and_through_the_gpu_walk(golden, ica
             assert b.slot_path(s) == path
             assert np.array_equal(b.fetch(s), want), (gpu_entropy, path)
         b.close()
+
+
+def test_gpu_walk_restart_intervals_and_own_tables(ica, oracle, gpu_ctx, golden):
+    """Baseline streams with optimal (not the writer's standard) Huffman tables and restart intervals from one MCU
+    to more than the image holds, in 4:2:0, 4:4:4, 4:2:2 and grey: every interval is its own chain with fresh DC
+    predictors; planes equal to the host walk's, pixels to the oracle's, nothing handed back."""
+    import helpers
+    datas = [golden.jpg("big_b444_rst_250x130")]
+    for i, (w, h, q, dri, lay) in enumerate(((64, 48, 90, 0, "native"), (64, 48, 90, 1, "native"), (200, 133, 90, 4, "native"), (250, 131, 95, 17, "native"),
+                                             (250, 131, 95, 3, "422"), (97, 51, 95, 2, "grey"), (16, 16, 90, 1, "native"), (640, 480, 90, 40, "native"),
+                                             (640, 480, 75, 1000, "native"), (1920, 1080, 90, 120, "native"), (1920, 1080, 95, 60, "422"), (33, 17, 100, 2, "native"))):
+        plan, du = ica.host_transform(ica.synth_rgb(w, h, 60 + i) if i % 3 else np.random.default_rng(i).integers(0, 256, (h, w, 3)).astype(np.uint8), q)
+        datas.append(helpers.baseline_from_du(plan, du, dri, lay))
+    b = ica.Batch(gpu_ctx, len(datas), 8 << 20, 96 << 20, 96 << 20)
+    b.entropy_reserve(16 << 20)
+    slots = []
+    for d in datas:
+        st, slot = b.add_jpeg_stream(d, 3)
+        assert st == 1, (st, b.last_reason)
+        slots.append(slot)
+    assert b.entropy_run() == []
+    for d, s_ in zip(datas, slots):
+        desc, want = ica.HostDecoder.decode(d, 3)
+        got = b.fetch_coef(s_)
+        for ci, (pg, pw) in enumerate(zip(ica.detile_coefficients(desc, got), ica.detile_coefficients(desc, want))):
+            assert np.array_equal(pg, pw), (s_, ci, int((pg != pw).sum()))
+    b.submit()
+    b.wait()
+    for d, s_ in zip(datas, slots):
+        assert np.array_equal(b.fetch(s_), oracle.load(d, 3)[1]), s_
+    b.close()
+    # damaged restart streams through the front end: verdict, reason and pixels as the oracle says
+    fuzz = [helpers.mutate(datas[1 + k % 9], 2000 + k, n_mut=1 + k % 3, allow_markers=(k % 4 == 0)) for k in range(120)]
+    b = ica.Batch(gpu_ctx, len(fuzz), 64 << 20, 64 << 20, 64 << 20)
+    b.entropy_reserve(16 << 20)
+    ok, slots, reasons = b.decode_jpegs(fuzz, 3, threads=4, gpu_entropy=True)
+    b.submit()
+    b.wait()
+    for i, d in enumerate(fuzz):
+        kind, want, _ = oracle.load(d, 3)
+        if slots[i] >= 0:
+            assert kind == "ok", (i, want)
+            assert np.array_equal(b.fetch(slots[i]), want), i
+        else:
+            assert kind == "fail" and reasons[i] == want, (i, reasons[i], want)
+    b.close()

@@ -244,9 +244,18 @@ def _walk_extracted_scan(scan, stream):
 
     bpm = scan.blocks_per_mcu
     out = np.zeros((scan.nblocks, 64), np.int64)
+    table = np.frombuffer(stream, np.uint32, count=2 * max(1, scan.n_seg), offset=scan.seg_table_off).reshape(-1, 2)
+    per_seg = scan.restart_mcus * bpm if scan.n_seg else scan.nblocks
     pred = [0, 0, 0, 0]
     p = 0
+    slack = []
     for b in range(scan.nblocks):
+        if b % per_seg == 0:  # a restart interval starts byte aligned with fresh predictors
+            seg = b // per_seg
+            if seg:
+                slack.append(int(table[seg - 1, 0] + table[seg - 1, 1]) * 8 - p)
+            p = int(table[seg, 0]) * 8
+            pred = [0, 0, 0, 0]
         ci = scan.blk_comp[b % bpm]
         t, ln = symbol(tabs[scan.dc_tab[ci]], window(p))
         diff = extend(window(p), ln, t) if t else 0
@@ -267,7 +276,8 @@ def _walk_extracted_scan(scan, stream):
             out[b, k] = extend(window(p), ln, n)
             p += ln + n
             k += 1
-    return out.astype(np.int16), p
+    slack.append(int(table[-1, 0] + table[-1, 1]) * 8 - p)
+    return out.astype(np.int16), max(slack)
 
 
 def test_extracted_scan_walks_to_the_host_walk_coefficients(golden, ica):
@@ -280,13 +290,14 @@ def test_extracted_scan_walks_to_the_host_walk_coefficients(golden, ica):
     L.mjh_extract_scan.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(GpuScan), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_char_p)]
     zig = np.array([0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50,
                     43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63])
-    cases = [golden.jpg("b420_64x64_q90"), golden.jpg("b444_40x24_q95"), golden.jpg("grey_33x20"), ica.synth_jpeg(97, 51, 3, 75), ica.synth_jpeg(16, 16, 4, 100)]
+    cases = [golden.jpg("b420_64x64_q90"), golden.jpg("b444_40x24_q95"), golden.jpg("grey_33x20"), ica.synth_jpeg(97, 51, 3, 75), ica.synth_jpeg(16, 16, 4, 100),
+             golden.jpg("big_b444_rst_250x130")]  # the last one carries restart markers: one segment per interval
     for data in cases:
         scan, n, why = GpuScan(), C.c_size_t(), C.c_char_p()
         buf = np.zeros(len(data) + 64, np.uint8)
         assert L.mjh_extract_scan(data, len(data), 3, C.byref(scan), buf.ctypes.data_as(C.c_void_p), buf.size, C.byref(n), C.byref(why)) == 1
-        got, p_end = _walk_extracted_scan(scan, bytes(buf[:n.value]))
-        assert n.value * 8 - p_end < 8  # only the byte-alignment padding is left
+        got, slack = _walk_extracted_scan(scan, bytes(buf[:n.value]))
+        assert 0 <= slack < 8  # only the byte-alignment padding is left in every segment
         desc, arena = ica.HostDecoder.decode(data, 3)
         planes = ica.detile_coefficients(desc, arena)  # [bh, bw, 8, 8] natural order
         bpm, mcu_x = scan.blocks_per_mcu, desc.mcu_x
@@ -297,7 +308,7 @@ def test_extracted_scan_walks_to_the_host_walk_coefficients(golden, ica):
             by = (m // mcu_x) * desc.comp[ci].v + scan.blk_dy[c]
             want = planes[ci][by, bx].reshape(64)[zig]
             assert np.array_equal(got[b], want), (b, ci, bx, by)
-    for name in ("prog_420_64x64", "big_b444_rst_250x130", "trunc_noeoi"):
+    for name in ("prog_420_64x64", "trunc_noeoi", "dri_without_rst"):
         d = golden.jpg(name)
         scan, n, why = GpuScan(), C.c_size_t(), C.c_char_p()
         buf = np.zeros(len(d) + 64, np.uint8)
