@@ -79,11 +79,11 @@ def main():
             h = int(rng.integers(1, 96)) if rng.random() < 0.3 else int(rng.integers(1, 500))
             q = int(rng.choice([1, 10, 35, 50, 75, 85, 90, 91, 95, 100]))
             img = picture(rng, w, h)
-            layout = int(rng.integers(0, 6))
+            layout = int(rng.integers(0, 9))
             if layout <= 1:
                 datas.append(ica.stbi_write_jpg_to_memory(img, q))
             else:
-                plan, du = ica.host_transform(img, q if layout == 2 else max(q, 91))
+                plan, du = ica.host_transform(img, q if layout in (2, 6) else max(q, 91))
                 script = int(rng.integers(0, 2))
                 if layout == 2:
                     datas.append(helpers.progressive_from_du(plan, du, script))
@@ -91,8 +91,12 @@ def main():
                     datas.append(helpers.progressive_422_from_444(plan, du, script))
                 elif layout == 4:
                     datas.append(helpers.progressive_grey_from_444(plan, du, script))
-                else:
+                elif layout == 5:
                     datas.append(helpers.progressive_from_du(plan, du, script))
+                else:  # baseline with optimal tables and a random restart interval, in a random layout
+                    lay = ["native", "422", "grey"][layout - 6]
+                    dri = int(rng.choice([0, 1, 2, 5, 16, 100, 5000]))
+                    datas.append(helpers.baseline_from_du(plan, du, dri, lay))
         req = int(rng.integers(0, 5))
         wants = [oracle.load(d, req) for d in datas]
         for mode in ("fused", "generic", "gpu_walk"):
