@@ -1275,7 +1275,8 @@ done:
 /* ------------------------------------------------------------------ scan extraction for the GPU entropy stage
  *
  * Header parsing as above; then, if the file is what the GPU walk takes -- one baseline scan carrying all
- * components interleaved in frame order, no restart interval, the entropy segment followed by EOI -- the
+ * components interleaved in frame order, the entropy data (cut at RSTn markers if a restart interval is set)
+ * followed by EOI -- the
  * segment is copied out with its 0xFF00 stuffing removed (codec/jpeg.c:171-184) together with the tables.
  * Everything else returns 2 ("use the host walk"): that path then reproduces the reference's behaviour,
  * including its failure reasons, so nothing about odd files is decided here.
@@ -1325,7 +1326,7 @@ int mjh_extract_scan(const uint8_t *buf, int len, int req_comp, mjg_scan *scan, 
 		const uint32_t nmcu = (uint32_t)d->mcu_x * (uint32_t)d->mcu_y;
 		const uint32_t dri = (uint32_t)d->restart_interval;
 		const uint32_t want_seg = dri ? (nmcu + dri - 1) / dri : 1;
-		uint32_t seg_off[2], nseg = 0; /* the table itself is appended behind the data */
+		uint32_t nseg = 0; /* the table itself is appended behind the data */
 		size_t n = 0, seg_start = 0;
 		uint32_t *table = NULL;
 		int bpm = 0, at_eoi = 0;
@@ -1334,7 +1335,6 @@ int mjh_extract_scan(const uint8_t *buf, int len, int req_comp, mjg_scan *scan, 
 		table = (uint32_t *)malloc(sizeof(uint32_t) * 2 * want_seg);
 		if (!table)
 			goto done;
-		(void)seg_off;
 		while (!at_eoi) {
 			const uint8_t *f = (const uint8_t *)memchr(q, 0xff, (size_t)(end - q));
 			size_t run;

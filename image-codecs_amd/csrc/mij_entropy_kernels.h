@@ -1,7 +1,8 @@
 /*
  * mij_entropy_kernels.h -- the baseline Huffman walk on the GPU ("self-synchronising
- * GPU Huffman"), for the one layout that makes up batch work: a single interleaved baseline scan without
- * restart markers (what the reference's own writer emits, codec/jpeg_write.c:283-352).
+ * GPU Huffman"), for the layout that makes up batch work: a single interleaved baseline scan (what the
+ * reference's own writer emits, codec/jpeg_write.c:283-352), with or without restart intervals -- every interval
+ * is one independent DevScan.
  *
  * A JPEG entropy segment has no entry points, but Huffman codes re-synchronise: a decoder started at a
  * wrong bit position falls into step with the true symbol sequence after a few symbols.  The unstuffed

@@ -194,7 +194,7 @@ int mij_batch_slot_path(const mij_batch *b, int slot);
 int mij_batch_force_generic(mij_batch *b, int on);
 
 /* ---- GPU entropy stage (experimental): the baseline Huffman walk itself on the GPU, for single-scan interleaved
- * baseline files without restart markers.  The host only parses headers and removes
+ * baseline files, restart intervals included.  The host only parses headers and removes
  * the 0xFF00 byte stuffing (mjh_extract_scan, mij_host.h); coefficients never cross PCIe.  Any stream the GPU
  * walk does not like (invalid code, run past coefficient 63, early end, no convergence) is reported back and
  * must be re-done with the host walk, whose behaviour on malformed input is the reference's. ---- */
