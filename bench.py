@@ -322,7 +322,7 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "JPEG decode Mpixels/sec, 4:2:0 1080p batch",
+            "metric": "JPEG decode Mpixels/sec, 4:2:0 1080p batch, 1/2/4/8 GPU + %HBM roofline",  # BASELINE.json's string
             "value": round(total_px / t_max / 1e6, 1),
             "unit": "Mpix/s",
             "n_gpus": cp.world,
