@@ -56,3 +56,40 @@ def test_progressive_refinement_scans_use_eob_runs(ica):
             found = True
         pos += 2 + length
     assert found
+
+
+def test_writer_streams_pin_the_oracle_to_the_live_reference(ica, oracle):
+    """Build container only (the reference cannot travel): every kind of stream the test-side writers make --
+    progressive scripts, 4:2:2, grey, baseline with optimal tables and restart intervals -- decodes in the real
+    reference exactly as in the oracle, for every req_comp.  This is what lets the GPU box trust the oracle on them."""
+    if not helpers.Reference.available():
+        pytest.skip("the reference build exists only where /root/reference does")
+    ref = helpers.Reference()
+    rng = np.random.default_rng(5)
+    n = 0
+    for k in range(36):
+        w, h = int(rng.integers(1, 200)), int(rng.integers(1, 160))
+        img = rng.integers(0, 256, (h, w, 3)).astype(np.uint8) if k % 2 else ica.synth_rgb(w, h, k)
+        plan, du = ica.host_transform(img, int(rng.choice([30, 90, 95, 100])) if k % 3 else 95)
+        kind = k % 6
+        if kind == 0:
+            data = helpers.progressive_from_du(plan, du, k & 1)
+        elif kind == 1 and plan.du_per_mcu == 3:
+            data = helpers.progressive_422_from_444(plan, du, k & 1)
+        elif kind == 2 and plan.du_per_mcu == 3:
+            data = helpers.progressive_grey_from_444(plan, du, k & 1)
+        elif kind == 3:
+            data = helpers.baseline_from_du(plan, du, int(rng.choice([0, 1, 3, 50])), "native")
+        elif kind == 4 and plan.du_per_mcu == 3:
+            data = helpers.baseline_from_du(plan, du, int(rng.choice([1, 2, 7])), "422")
+        elif plan.du_per_mcu == 3:
+            data = helpers.baseline_from_du(plan, du, int(rng.choice([0, 2])), "grey")
+        else:
+            data = helpers.baseline_from_du(plan, du, 5, "native")
+        for req in (0, 1, 3, 4):
+            ko, po, _ = oracle.load(data, req)
+            kr, pr, _ = ref.load(data, req)
+            assert ko == kr == "ok", (k, req)
+            assert np.array_equal(po, pr), (k, req)
+            n += 1
+    assert n == 36 * 4
