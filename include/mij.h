@@ -225,8 +225,9 @@ typedef struct {
 int mij_batch_entropy_reserve(mij_batch *b, size_t stream_bytes);
 /* pinned region where the caller writes streams (capacity as reserved; reset by mij_batch_reset) */
 uint8_t *mij_batch_entropy_stage(mij_batch *b, size_t *capacity);
-/* new slot whose coefficients the GPU walk will produce; stream = pointer into the pinned region, followed by
- * at least 32 writable bytes (zeroed here).  Returns the slot or a negative code. */
+/* new slot whose coefficients the GPU walk will produce; stream = what mjh_extract_scan wrote (segments, each
+ * followed by 32 zero bytes, and the segment table), 4-byte aligned inside the pinned region.  Returns the slot
+ * or a negative code (MIJ_E_NOMEM also when the image has more restart intervals than the arena has room for). */
 int mij_batch_add_stream(mij_batch *b, const mjg_scan *scan, uint8_t *stream, size_t stream_len); /* stream_len: everything mjh_extract_scan wrote, segment table included */
 /* H2D of the streams, the five kernels, D2H of the verdicts; waits.  fallback[0..*n_fallback) = slots the host
  * walk must redo (mij_batch_fallback_prepare, then decode into mij_batch_coef as usual). */
