@@ -59,6 +59,8 @@ def encoder_stress(budget, rng):
                     raise SystemExit("ENCODER MISMATCH generic=%s shape=%s" % (generic, im.shape))
                 n += 1
             enc.close()
+        if n % 3200 == 0:
+            print("  ... %d encoder comparisons" % n, flush=True)
     print("encoder stress ok: %d comparisons in %.0f s" % (n, budget))
 
 
@@ -119,6 +121,8 @@ def main():
                 n_cmp += 1
             b.close()
         n_img += len(datas)
+        if rounds % 100 == 0:
+            print("  ... %d rounds, %d comparisons" % (rounds, n_cmp), flush=True)
     print("stress ok: %d rounds, %d pictures, %d comparisons in %.0f s" % (rounds, n_img, n_cmp, budget))
 
 
