@@ -78,15 +78,31 @@ __device__ __forceinline__ EsState es_unpack(uint64_t v)
 	return s;
 }
 
-/* 57+ valid bits starting at bit position p (big-endian bit order), from aligned dwords */
-__device__ __forceinline__ uint64_t es_window(const uint8_t *__restrict__ stream, uint32_t p)
-{
-	const uint32_t *w = reinterpret_cast<const uint32_t *>(stream) + (p >> 5);
-	const uint32_t d0 = __builtin_bswap32(w[0]), d1 = __builtin_bswap32(w[1]), d2 = __builtin_bswap32(w[2]);
-	const uint32_t sh = p & 31u;
-	const uint64_t hi = ((uint64_t)d0 << 32) | d1;
-	return sh ? (hi << sh) | ((uint64_t)d2 >> (32u - sh)) : hi;
-}
+/* the bit window (big-endian bit order) kept in registers: at least 32 valid bits at every symbol start, one
+ * aligned dword fetched whenever fewer are left (a symbol takes at most 16 + 16 bits) */
+struct EsBits {
+	const uint32_t *w;
+	uint64_t win;
+	uint32_t avail, idx;
+	__device__ __forceinline__ void start(const uint8_t *__restrict__ stream, uint32_t p)
+	{
+		w = reinterpret_cast<const uint32_t *>(stream);
+		idx = p >> 5;
+		const uint32_t sh = p & 31u;
+		win = (((uint64_t)__builtin_bswap32(w[idx]) << 32) | __builtin_bswap32(w[idx + 1])) << sh;
+		avail = 64u - sh;
+		idx += 2;
+	}
+	__device__ __forceinline__ void take(uint32_t n)
+	{
+		win <<= n;
+		avail -= n;
+		if (avail < 32u) {
+			win |= (uint64_t)__builtin_bswap32(w[idx++]) << (32u - avail);
+			avail += 32u;
+		}
+	}
+};
 
 /* codec/jpeg.c:193-243: returns the symbol and its code length, or -1 */
 __device__ __forceinline__ int es_symbol(const DevHuff &h, uint64_t win, uint32_t &len)
@@ -172,6 +188,8 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const DevHuff *
 {
 	uint32_t done = 0, guard = 0;
 	const uint32_t limit = sc.nbits + 64u; /* the arena is zero padded: never read far past the data */
+	EsBits br;
+	br.start(stream, s.p);
 	while (s.p < p_end && s.z != MIJ_ES_DEAD) {
 		if (++guard > MIJ_ES_BITS + 64u) { /* every symbol takes at least one bit: cannot happen, but a wave must always end */
 			s.z = MIJ_ES_DEAD;
@@ -179,7 +197,7 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const DevHuff *
 		}
 		if (WRITE && wr->ord >= sc.nblocks)
 			break;
-		const uint64_t win = es_window(stream, s.p);
+		const uint64_t win = br.win;
 		const uint32_t ci = sc.blk_comp[s.c];
 		uint32_t len = 0;
 		if (s.z == 0) {
@@ -187,6 +205,7 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const DevHuff *
 			if (t < 0 || t > 11 || len == 0) { /* the reference takes categories up to 16; nothing a conforming stream uses */
 				if (!WRITE) { /* a guessed start ran into a non-code: slip one bit and keep looking for the true sequence */
 					s.p += 1;
+					br.take(1);
 					continue;
 				}
 				atomicOr(anom, 1u);
@@ -197,12 +216,14 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const DevHuff *
 			if (WRITE)
 				wr->dcdiff[wr->ord] = (int16_t)diff;
 			s.p += len + (uint32_t)t;
+			br.take(len + (uint32_t)t);
 			s.z = 1;
 		} else {
 			const int rs = es_symbol(tabs[sc.ac_tab[ci]], win, len);
 			if (rs < 0 || len == 0) {
 				if (!WRITE) {
 					s.p += 1;
+					br.take(1);
 					continue;
 				}
 				atomicOr(anom, 1u);
@@ -212,6 +233,7 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const DevHuff *
 			const uint32_t r = (uint32_t)rs >> 4, n = (uint32_t)rs & 15u;
 			if (n == 0) {
 				s.p += len;
+				br.take(len);
 				if (r == 15u)
 					s.z += 16; /* ZRL */
 				else if (r == 0u)
@@ -225,6 +247,7 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const DevHuff *
 					if (WRITE)
 						atomicOr(anom, 1u);
 					s.p += len + n;
+					br.take(len + n);
 					s.z = 64;
 				} else {
 					const int v = es_extend(win, len, n);
@@ -234,6 +257,7 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const DevHuff *
 						wr->acc += (uint32_t)(dq < 0 ? -dq : dq);
 					}
 					s.p += len + n;
+					br.take(len + n);
 					s.z = k + 1;
 				}
 			}
