@@ -1,4 +1,4 @@
-"""GPU bring-up script (not a test): parity of the GPU path against the reference-built
+"""GPU bring-up script (not a test; lives under tests/ because it links the checker): parity of the GPU path against the reference-built
 oracle/_ref library on a spread of sizes, then a rough timing of the fused kernel."""
 import ctypes as C
 import os

@@ -1,14 +1,14 @@
 """Randomised parity stress (not part of the pytest suites): many small random pictures of random sizes,
 qualities, layouts (4:2:0 / 4:4:4 baseline from the writer, 4:2:2 / grey / progressive from the test-side
 writer) and req_comp through every decode route -- fused kernels, the two-pass family, the GPU Huffman walk --
-against the oracle.  python tools/stress.py [seconds] [seed]"""
+against the oracle.  python tests/stress.py [seconds] [seed] [enc]"""
 import os
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))  # lives under tests/: it uses the oracle, which only test code may
 import numpy as np  # noqa: E402
 import image_codecs_amd as ica  # noqa: E402
 import helpers  # noqa: E402
