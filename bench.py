@@ -61,8 +61,9 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(datas, want_seconds=12.0):
-    """Times the CPU checker on a bounded sample (all host cores, one image per task)."""
+def cpu_baseline(datas, want_seconds=12.0, gpu_pixels=None):
+    """Times the CPU checker on a bounded sample (all host cores, one image per task); with gpu_pixels(i) it also
+    acts as what it is -- the checker: its pixels for every distinct image must equal the GPU's."""
     ref_so = os.path.join(ROOT, "oracle", "_ref", "libstbref.so")
     port_so = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
     if os.path.exists(ref_so):
@@ -89,7 +90,24 @@ def cpu_baseline(datas, want_seconds=12.0):
     f(bufs, lens, n, cal_reps, cores, 3, C.byref(secs))
     reps = max(cal_reps, min(int(want_seconds / max(secs.value, 1e-3) * cal_reps), 4096))
     px = f(bufs, lens, n, reps, cores, 3, C.byref(secs))
+    parity = None
+    if gpu_pixels is not None:
+        load = L.stbi_load_from_memory if kind == "reference" else L.orc_load_from_memory
+        load.restype = C.POINTER(C.c_ubyte)
+        ints = [C.POINTER(C.c_int)] * 3
+        load.argtypes = [C.c_char_p, C.c_int] + ints + [C.c_int] + ([C.POINTER(C.c_char_p)] if kind == "port" else [])
+        parity = True
+        for i, d in enumerate(datas):
+            x, y, c = C.c_int(), C.c_int(), C.c_int()
+            extra = [C.byref(C.c_char_p())] if kind == "port" else []
+            ptr = load(d, len(d), C.byref(x), C.byref(y), C.byref(c), 3, *extra)
+            cpu = np.ctypeslib.as_array(ptr, shape=(y.value * x.value * 3,))
+            if not np.array_equal(cpu, gpu_pixels(i).reshape(-1)):
+                parity = False
+            (L.stbi_image_free if kind == "reference" else L.orc_free)(ptr)
+        assert parity, "GPU pixels differ from the CPU checker's"
     return {
+        "parity_with_gpu_output": parity,
         "value": round(px / secs.value / 1e6, 1),
         "unit": "Mpix/s",
         "cores": cores,
@@ -363,7 +381,7 @@ def main():
             out["end_to_end"] = e2e
         if cp.world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(datas)
+                out["cpu_baseline"] = cpu_baseline(datas, gpu_pixels=lambda i: batch.fetch(i))
             except Exception as exc:  # noqa: BLE001
                 out["cpu_baseline"] = {"value": None, "error": "%s: %s" % (type(exc).__name__, exc)}
     batch.close()
