@@ -276,9 +276,11 @@ static void bits_grow(mjh_decoder *d)
 				return;
 			}
 		}
-		/* code_bits can be negative on streams that ran dry at a marker; the byte is then 0 */
+		/* code_bits can be negative on streams that ran dry at a marker; the byte is then 0.  It can also exceed 24
+		 * here: a DC "category" above 16 from a damaged table makes the reference refill with a full buffer
+		 * (codec/jpeg.c:254), its shift count goes negative and x86 takes it modulo 32 -- spelled out */
 		if (b)
-			d->code_buffer |= b << (24 - d->code_bits);
+			d->code_buffer |= b << ((24 - d->code_bits) & 31);
 		d->code_bits += 8;
 	} while (d->code_bits <= 24);
 }

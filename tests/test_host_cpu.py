@@ -313,3 +313,45 @@ def test_extracted_scan_walks_to_the_host_walk_coefficients(golden, ica):
         scan, n, why = GpuScan(), C.c_size_t(), C.c_char_p()
         buf = np.zeros(len(d) + 64, np.uint8)
         assert L.mjh_extract_scan(d, len(d), 3, C.byref(scan), buf.ctypes.data_as(C.c_void_p), buf.size, C.byref(n), C.byref(why)) == 2, name
+
+
+def test_host_stage_is_clean_under_sanitizers(golden, ica, tmp_path):
+    """jpeg_entropy.c (probe, walk, scan extraction) built with -fsanitize=address,undefined and fed damaged files --
+    entropy mutations with and without new markers, header bytes hit, truncations, insertions: no report."""
+    import subprocess
+    import helpers
+    root = helpers.ROOT
+    exe = str(tmp_path / "san_harness")
+    cmd = ["gcc", "-std=gnu11", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
+           "-I" + root + "/include", "-I" + root + "/image-codecs_amd/csrc", "-o", exe,
+           root + "/tests/support/san_harness.c", root + "/image-codecs_amd/csrc/jpeg_entropy.c"]
+    build = subprocess.run(cmd, capture_output=True, text=True)
+    if build.returncode != 0 and "sanitize" in build.stderr:
+        pytest.skip("no sanitizer runtime in this toolchain")
+    assert build.returncode == 0, build.stderr
+    bases = [golden.jpg(n) for n in golden.names if len(golden.jpg(n)) > 16]
+    plan, du = ica.host_transform(ica.synth_rgb(97, 51, 1), 95)
+    bases += [helpers.baseline_from_du(plan, du, 3, "native"), helpers.progressive_from_du(plan, du, 1)]
+    rng = np.random.default_rng(1)
+    files = []
+    for k in range(400):
+        b = bases[k % len(bases)]
+        d = bytearray(b)
+        mode = k % 4
+        if mode == 0:
+            d = bytearray(helpers.mutate(b, k, n_mut=1 + k % 5, allow_markers=True))
+        elif mode == 1:
+            for _ in range(1 + k % 4):
+                d[int(rng.integers(0, len(d)))] = int(rng.integers(0, 256))
+        elif mode == 2:
+            d = d[:int(rng.integers(2, len(d)))]
+        else:
+            pos = int(rng.integers(0, len(d)))
+            d[pos:pos] = bytes(rng.integers(0, 256, int(rng.integers(1, 8))).astype(np.uint8))
+        f = tmp_path / ("%04d.jpg" % k)
+        f.write_bytes(bytes(d))
+        files.append(str(f))
+    run = subprocess.run([exe] + files, capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+    assert run.returncode == 0, run.stderr[-2000:]
+    assert "runtime error" not in run.stderr and "AddressSanitizer" not in run.stderr, run.stderr[-2000:]
+    assert "decoded ok" in run.stdout
