@@ -122,7 +122,7 @@ static inline void put_bits(jw_sink *s, unsigned code, int len)
 		sink_byte(s, c);
 		if (c == 255)
 			sink_byte(s, 0);
-		buf <<= 8;
+		buf = (int)((unsigned)buf << 8); /* the reference shifts the int itself (:17); same bits, no signed overflow */
 		cnt -= 8;
 	}
 	s->bit_buf = buf;
