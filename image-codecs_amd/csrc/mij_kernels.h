@@ -310,6 +310,13 @@ __device__ __forceinline__ void load_block(const uint8_t *__restrict__ plane, ui
 #pragma unroll
 	for (int k = 0; k < 8; ++k) {
 		const uint8_t *p = plane + tile_chunk_off((MIJ_VARIANT & 2) ? (L & 63u) : L, k); /* ablation bit 2: one cache-resident tile */
+		if (MIJ_VARIANT & 16) { /* ablation: what byte-sized AC coefficients would cost and save -- half the bytes, one v_perm per pair */
+			const uint8_t *p8 = plane + tile_chunk_off(L, k) / 2;
+			const uint2 h = *reinterpret_cast<const uint2 *>(p8);
+			c[k] = make_uint4(__builtin_amdgcn_perm(0, h.x, 0x0c010c00u), __builtin_amdgcn_perm(0, h.x, 0x0c030c02u), __builtin_amdgcn_perm(0, h.y, 0x0c010c00u),
+									__builtin_amdgcn_perm(0, h.y, 0x0c030c02u));
+			continue;
+		}
 		/* coefficients are read once, pixels written once: streaming (nt) accesses, measured -2.4 % kernel time */
 		const u4v v = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(p));
 		c[k] = make_uint4(v.x, v.y, v.z, v.w);
