@@ -1379,21 +1379,6 @@ extern "C" int mij_batch_fetch_coef(mij_batch *b, int slot, int16_t *dst, size_t
 	return MIJ_OK;
 }
 
-/* debugging aid (not in mij.h): the state words of a slot's subsequences after the last entropy_run */
-extern "C" int mij_batch_entropy_debug_states(mij_batch *b, int slot, uint64_t *start, uint64_t *end0, uint64_t *end1, uint32_t *cnt, size_t cap)
-{
-	if (!b || !b->es || slot < 0 || slot >= (int)b->slots.size() || b->slots[(size_t)slot].es_index < 0)
-		return -1;
-	const DevScan &d = b->es->h_scans[b->slots[(size_t)slot].es_index];
-	if (cap < d.nsub)
-		return -2;
-	(void)hipMemcpy(start, b->es->d_start + d.sub_off, sizeof(uint64_t) * d.nsub, hipMemcpyDeviceToHost);
-	(void)hipMemcpy(end0, b->es->d_end[0] + d.sub_off, sizeof(uint64_t) * d.nsub, hipMemcpyDeviceToHost);
-	(void)hipMemcpy(end1, b->es->d_end[1] + d.sub_off, sizeof(uint64_t) * d.nsub, hipMemcpyDeviceToHost);
-	(void)hipMemcpy(cnt, b->es->d_cnt + d.sub_off, sizeof(uint32_t) * d.nsub, hipMemcpyDeviceToHost);
-	return (int)d.nsub;
-}
-
 extern "C" int mij_batch_entropy_rounds(const mij_batch *b) { return b && b->es ? b->es->last_rounds : 0; }
 
 /* ------------------------------------------------------------------ encoder (mij_enc_*)
