@@ -106,8 +106,17 @@ def cpu_baseline(datas, want_seconds=12.0, gpu_pixels=None):
                 parity = False
             (L.stbi_image_free if kind == "reference" else L.orc_free)(ptr)
         assert parity, "GPU pixels differ from the CPU checker's"
+    model = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {
         "parity_with_gpu_output": parity,
+        "cpu_model": model,
         "value": round(px / secs.value / 1e6, 1),
         "unit": "Mpix/s",
         "cores": cores,
