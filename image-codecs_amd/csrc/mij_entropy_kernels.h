@@ -57,6 +57,7 @@ struct DevScan {
 	uint32_t bpm, mcu_x;
 	uint32_t first_mcu;  /* restart intervals: the MCU this segment starts at (0 without restart markers) */
 	uint32_t last_seg;   /* the segment that ends at EOI */
+	uint32_t fmt;        /* 1: byte-coefficient planes (MIJ_DEV_COEF_BYTES): AC as value + 128, DC in its own int16 array */
 	uint8_t blk_comp[12], blk_dx[12], blk_dy[12]; /* block-in-MCU -> component and position inside the MCU */
 	uint8_t dc_tab[4], ac_tab[4];                 /* component -> table index (0..3 DC, 4..7 AC) of this scan's eight tables */
 	uint32_t tab_off;    /* first of the eight DevHuff of this scan */
@@ -146,7 +147,10 @@ struct EsWriter { /* where the blocks of the write pass go */
 	bool stop_after_block;
 	uint32_t ord;        /* ordinal of the current block */
 	uint32_t mx, my;     /* its MCU */
-	int16_t *blk;        /* its tile slot */
+	int16_t *blk;        /* its tile slot (int16 planes) */
+	uint8_t *blk8;       /* its tile slot (byte planes) */
+	uint32_t L;          /* its index in the component's block grid */
+	uint32_t *anom8;     /* verdict word: a coefficient that does not fit a byte sends the image back */
 	uint32_t acc;        /* L1 of the AC coefficients written by this thread into it */
 	uint32_t *pfinal;    /* where the bit position after the scan's last block is recorded */
 	__device__ __forceinline__ void locate(uint32_t c)
@@ -154,12 +158,24 @@ struct EsWriter { /* where the blocks of the write pass go */
 		const uint32_t ci = sc->blk_comp[c];
 		const DevComp &cp = im->comp[ci];
 		const uint32_t bx = mx * (uint32_t)cp.h + sc->blk_dx[c], by = my * (uint32_t)cp.v + sc->blk_dy[c];
-		const uint32_t L = bx + by * (uint32_t)cp.bw;
-		blk = reinterpret_cast<int16_t *>(reinterpret_cast<uint8_t *>(coef) + cp.coef_off) + ((size_t)(L >> 6) << 12) + ((L & 63u) << 3);
+		L = bx + by * (uint32_t)cp.bw;
+		uint8_t *plane = reinterpret_cast<uint8_t *>(coef) + cp.coef_off;
+		blk = reinterpret_cast<int16_t *>(plane) + ((size_t)(L >> 6) << 12) + ((L & 63u) << 3);
+		blk8 = plane + ((size_t)(L >> 6) << 12) + ((L & 63u) << 3);
 	}
-	/* the staged block -> its eight 16-byte chunks in the tile (complete, zeros included: the planes need no clearing) */
+	/* the staged block -> its eight chunks in the tile (complete, zeros included: the planes need no clearing) */
 	__device__ __forceinline__ void flush()
 	{
+		if (sc->fmt) {
+#pragma unroll
+			for (int c = 0; c < 8; ++c) {
+				uint2 *src = reinterpret_cast<uint2 *>(reinterpret_cast<uint8_t *>(buf) + 8 * c);
+				const uint2 v = *src;
+				*src = make_uint2(0x80808080u, 0x80808080u);
+				*reinterpret_cast<uint2 *>(blk8 + (c << 9)) = v;
+			}
+			return;
+		}
 #pragma unroll
 		for (int c = 0; c < 8; ++c) {
 			uint4 *src = reinterpret_cast<uint4 *>(buf + 8 * c);
@@ -170,7 +186,15 @@ struct EsWriter { /* where the blocks of the write pass go */
 	}
 	__device__ __forceinline__ void put(uint32_t k, int v)
 	{
-		if (buf)
+		if (sc->fmt) {
+			if ((uint32_t)(v + 128) > 255u)
+				atomicOr(anom8, 128u);
+			const uint8_t u = (uint8_t)(v + 128);
+			if (buf)
+				reinterpret_cast<uint8_t *>(buf)[zpos[k]] = u;
+			else
+				blk8[toff[k]] = u;
+		} else if (buf)
 			buf[zpos[k]] = (int16_t)v;
 		else
 			blk[toff[k]] = (int16_t)v;
@@ -419,8 +443,11 @@ __global__ __launch_bounds__(256) void k_es_write(const DevScan *__restrict__ sc
 	const DevScan &sc = scans[wk.scan];
 	if (threadIdx.x < 64)
 		zpos[threadIdx.x] = mij_zigzag_pos[threadIdx.x];
-	for (uint32_t i = threadIdx.x; i < 256u * MIJ_ES_BUFPITCH / 16u; i += 256)
-		reinterpret_cast<uint4 *>(stage)[i] = make_uint4(0, 0, 0, 0);
+	{
+		const uint32_t fill = sc.fmt ? 0x80808080u : 0u; /* "no coefficient" in either format */
+		for (uint32_t i = threadIdx.x; i < 256u * MIJ_ES_BUFPITCH / 16u; i += 256)
+			reinterpret_cast<uint4 *>(stage)[i] = make_uint4(fill, fill, fill, fill);
+	}
 	es_load_tables(huff + sc.tab_off, tabs);
 	const uint32_t i = wk.first + threadIdx.x;
 	if (i >= sc.nsub)
@@ -441,6 +468,7 @@ __global__ __launch_bounds__(256) void k_es_write(const DevScan *__restrict__ sc
 	wr.ord = base[slot];
 	wr.acc = 0;
 	wr.pfinal = &pfinal[wk.scan];
+	wr.anom8 = &anom[wk.scan];
 	if (wr.ord >= sc.nblocks)
 		return;
 	const uint32_t ml = wr.ord / sc.bpm, m = sc.first_mcu + ml;
@@ -492,6 +520,7 @@ __global__ __launch_bounds__(256) void k_es_tails(const DevScan *__restrict__ sc
 	wr.ord = base[slot];
 	wr.acc = 0;
 	wr.pfinal = scratch; /* never reached: the walk stops at the end of this block */
+	wr.anom8 = scratch + 1;
 	if (wr.ord >= sc.nblocks)
 		return;
 	const uint32_t ml = wr.ord / sc.bpm, m = sc.first_mcu + ml;
@@ -569,8 +598,10 @@ __global__ __launch_bounds__(256) void k_es_dc(const DevScan *__restrict__ scans
 			pred[ci] = (int)((unsigned)pred[ci] + (unsigned)(int)dd[m * sc.bpm + c]);
 			const uint32_t bx = mx * (uint32_t)cp.h + sc.blk_dx[c], by = my * (uint32_t)cp.v + sc.blk_dy[c];
 			const uint32_t L = bx + by * (uint32_t)cp.bw;
-			int16_t *blk = reinterpret_cast<int16_t *>(reinterpret_cast<uint8_t *>(coef) + cp.coef_off) + ((size_t)(L >> 6) << 12) + ((L & 63u) << 3);
-			blk[0] = (int16_t)pred[ci];
+			if (sc.fmt)
+				reinterpret_cast<int16_t *>(reinterpret_cast<uint8_t *>(coef) + cp.dc_off)[L] = (int16_t)pred[ci];
+			else
+				(reinterpret_cast<int16_t *>(reinterpret_cast<uint8_t *>(coef) + cp.coef_off) + ((size_t)(L >> 6) << 12) + ((L & 63u) << 3))[0] = (int16_t)pred[ci];
 			const int dq = (int)(int16_t)((uint32_t)pred[ci] * sc.qz[ci][0]);
 			const uint32_t tot = bl1[m * sc.bpm + c] + (uint32_t)(dq < 0 ? -dq : dq);
 			mymax = tot > mymax ? tot : mymax;

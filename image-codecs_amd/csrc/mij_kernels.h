@@ -42,7 +42,10 @@ struct DevComp {
 	int32_t hs, vs;       /* h_max / h, v_max / v (integer division, codec/jpeg.c:2273-2274) */
 	uint64_t coef_off;    /* byte offset of the component's tile-layout plane in the coefficient arena */
 	uint64_t plane_off;   /* byte offset of its u8 sample plane in the scratch arena (two-pass path) */
+	uint64_t dc_off;      /* byte-coefficient planes (MIJ_DEV_COEF_BYTES): offset of the int16 DC array, one per block */
 };
+
+#define MIJ_DEV_COEF_BYTES 0x100 /* DevImage.flags: AC coefficients are biased bytes, DC separate (GPU entropy stage only) */
 
 struct DevImage {
 	int32_t width, height, n_out, color;
@@ -321,6 +324,32 @@ __device__ __forceinline__ void load_block(const uint8_t *__restrict__ plane, ui
 		const u4v v = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(p));
 		c[k] = make_uint4(v.x, v.y, v.z, v.w);
 	}
+}
+
+/* The same block from a byte-coefficient plane (experimental; written by the GPU entropy stage): tiles of 4 KiB,
+ * chunk k = column k as eight biased bytes (value + 128) in the row order of the int16 layout, DC (row 0 of column
+ * 0) in its own int16 array.  One v_perm + one v_pk_sub_u16 per pair rebuild the int16 pairs; half the bytes. */
+__device__ __forceinline__ void load_block_b8(const uint8_t *__restrict__ plane, const uint8_t *__restrict__ dcarr, uint32_t L, uint4 (&c)[8])
+{
+	const uint32_t bias = vreg(0x00800080u);
+	const uint8_t *base = plane + ((size_t)(L >> 6) << 12) + ((size_t)(L & 63u) << 3);
+	uint2 h[8];
+#pragma unroll
+	for (int k = 0; k < 8; ++k) {
+		typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+		const u2v v = __builtin_nontemporal_load(reinterpret_cast<const u2v *>(base + (k << 9)));
+		h[k] = make_uint2(v.x, v.y);
+	}
+	const uint32_t dc = *reinterpret_cast<const uint16_t *>(dcarr + 2u * (size_t)L);
+#pragma unroll
+	for (int k = 0; k < 8; ++k) {
+		v2u a = __builtin_bit_cast(v2u, __builtin_amdgcn_perm(0, h[k].x, 0x0c010c00u)) - __builtin_bit_cast(v2u, bias);
+		v2u b = __builtin_bit_cast(v2u, __builtin_amdgcn_perm(0, h[k].x, 0x0c030c02u)) - __builtin_bit_cast(v2u, bias);
+		v2u e = __builtin_bit_cast(v2u, __builtin_amdgcn_perm(0, h[k].y, 0x0c010c00u)) - __builtin_bit_cast(v2u, bias);
+		v2u f = __builtin_bit_cast(v2u, __builtin_amdgcn_perm(0, h[k].y, 0x0c030c02u)) - __builtin_bit_cast(v2u, bias);
+		c[k] = make_uint4(__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b), __builtin_bit_cast(uint32_t, e), __builtin_bit_cast(uint32_t, f));
+	}
+	c[0].x = __builtin_amdgcn_perm(c[0].x, dc, 0x07060100u); /* (DC, r4) */
 }
 
 /* ------------------------------------------------------------------ colour (codec/jpeg.c:1976-2018)
@@ -802,7 +831,7 @@ __device__ __forceinline__ void strip_row(const ColorK &K, uint32_t wk, uint32_t
 	store_px4<NOUT>(dst, p0, p1, p2, p3);
 }
 
-template <int NOUT, bool WIDE>
+template <int NOUT, bool WIDE, bool B8 = false>
 __global__ __launch_bounds__(256) void k_fused420(const DevImage *__restrict__ imgs, const WorkBand *__restrict__ work, const uint8_t *__restrict__ coef,
 																  uint8_t *__restrict__ outbase)
 {
@@ -829,6 +858,7 @@ __global__ __launch_bounds__(256) void k_fused420(const DevImage *__restrict__ i
 	const uint8_t *const coefY = coef + im.comp[0].coef_off;
 	const uint8_t *const coefCb = coef + im.comp[1].coef_off;
 	const uint8_t *const coefCr = coef + im.comp[2].coef_off;
+	const uint8_t *const dcY = coef + im.comp[0].dc_off, *const dcCb = coef + im.comp[1].dc_off, *const dcCr = coef + im.comp[2].dc_off;
 	uint8_t *const out = outbase + im.out_off;
 	const uint32_t opitch = (uint32_t)W * NOUT;
 
@@ -853,7 +883,10 @@ __global__ __launch_bounds__(256) void k_fused420(const DevImage *__restrict__ i
 			if (bx < bwC) {
 				uint4 c[8];
 				uint2 rows[8];
-				load_block(comp == 1 ? coefCb : coefCr, (uint32_t)(mc * bwC + bx), c);
+				if (B8)
+					load_block_b8(comp == 1 ? coefCb : coefCr, comp == 1 ? dcCb : dcCr, (uint32_t)(mc * bwC + bx), c);
+				else
+					load_block(comp == 1 ? coefCb : coefCr, (uint32_t)(mc * bwC + bx), c);
 				idct_block<WIDE>(KI, c, im.dq[comp], rows);
 				*reinterpret_cast<uint2 *>((comp == 1 ? dstCb : dstCr) + 8 * bx) = keep ? rows[7] : rows[0];
 			}
@@ -953,7 +986,10 @@ __global__ __launch_bounds__(256) void k_fused420(const DevImage *__restrict__ i
 			if (ww < nYw) {
 				const int i = ww * 64 + lane; /* block of the two luma block rows 2m, 2m+1 (contiguous in L) */
 				if (i < 2 * bwY) {
-					load_block(coefY, (uint32_t)(2 * m * bwY + i), c);
+					if (B8)
+						load_block_b8(coefY, dcY, (uint32_t)(2 * m * bwY + i), c);
+					else
+						load_block(coefY, (uint32_t)(2 * m * bwY + i), c);
 					idct_block<WIDE>(KI, c, im.dq[0], rows);
 					const int by = i >= bwY ? 1 : 0, bx = i - by * bwY;
 					uint8_t *dst = sY + (8 * by) * YP + 8 * bx;
@@ -965,7 +1001,10 @@ __global__ __launch_bounds__(256) void k_fused420(const DevImage *__restrict__ i
 				const int comp = (ww - nYw) < nCw ? 1 : 2;
 				const int bx = ((ww - nYw) - (comp == 2 ? nCw : 0)) * 64 + lane;
 				if (bx < bwC) {
-					load_block(comp == 1 ? coefCb : coefCr, (uint32_t)(m * bwC + bx), c);
+					if (B8)
+						load_block_b8(comp == 1 ? coefCb : coefCr, comp == 1 ? dcCb : dcCr, (uint32_t)(m * bwC + bx), c);
+					else
+						load_block(comp == 1 ? coefCb : coefCr, (uint32_t)(m * bwC + bx), c);
 					idct_block<WIDE>(KI, c, im.dq[comp], rows);
 					uint8_t *dst = (comp == 1 ? sCb : sCr) + 8 * bx;
 #pragma unroll

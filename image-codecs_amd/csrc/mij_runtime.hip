@@ -91,6 +91,10 @@ extern "C" int mij_ctx_create(int device, mij_ctx **out)
 	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused420<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
 	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused420<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
 	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused420<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused420<3, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused420<3, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused420<4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused420<4, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
 	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_encode420), hipFuncAttributeMaxDynamicSharedMemorySize, MIJ_ENC_LDS);
 	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused422<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
 	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused422<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
@@ -129,6 +133,7 @@ struct Slot {
 	int clone_of;      /* -1: own staging */
 	int dev_coef;      /* 1: the GPU entropy stage wrote the coefficient planes in HBM; nothing to upload */
 	int es_index;      /* index into the entropy arena's scan list, or -1 */
+	int coef_bytes_fmt; /* 1: byte-coefficient planes (experimental, MIJ_COEF_BYTES=1): AC as biased bytes, DC array aside */
 	int path;          /* 0 none, 1 fused 4:2:0, 2 two-pass, 3 fused 4:4:4 */
 };
 
@@ -156,6 +161,7 @@ struct mij_batch {
 	/* launch plan built by upload */
 	struct BandLaunch {
 		int nout, wide;
+		bool b8;
 		size_t first, count;
 		size_t lds;
 	};
@@ -373,6 +379,16 @@ static void fill_dev_image(Slot &s, size_t coef_off, size_t out_off)
 
 #define MIJ_NO_STAGE ((size_t)-1)
 
+/* byte-coefficient planes: flag and DC arrays (behind each component's 4 KiB tiles, inside the same plane region) */
+static void apply_coef_bytes(Slot &s)
+{
+	s.dev.flags |= MIJ_DEV_COEF_BYTES;
+	for (int c = 0; c < s.desc.ncomp; ++c) {
+		const size_t ntile = ((size_t)(s.desc.comp[c].bw * s.desc.comp[c].bh) + 63) >> 6;
+		s.dev.comp[c].dc_off = s.dev.comp[c].coef_off + (ntile << 12);
+	}
+}
+
 /* lazy_stage: a slot of the GPU entropy stage -- its staging planes are only needed if the host walk has to
  * redo it, so they are neither required nor cleared here (mij_batch_fallback_prepare does that) */
 static int add_common(mij_batch *b, const mij_image_desc *d, int clone_of, bool lazy_stage = false)
@@ -389,6 +405,7 @@ static int add_common(mij_batch *b, const mij_image_desc *d, int clone_of, bool 
 	s.clone_of = clone_of;
 	s.dev_coef = 0;
 	s.es_index = -1;
+	s.coef_bytes_fmt = clone_of >= 0 ? b->slots[(size_t)clone_of].coef_bytes_fmt : 0;
 	s.coef_bytes = cbytes;
 	s.path = 0;
 	if (clone_of < 0) {
@@ -406,6 +423,8 @@ static int add_common(mij_batch *b, const mij_image_desc *d, int clone_of, bool 
 		s.stage_off = b->slots[(size_t)clone_of].stage_off;
 	}
 	fill_dev_image(s, b->coef_used, b->out_used);
+	if (s.coef_bytes_fmt)
+		apply_coef_bytes(s); /* a clone of a byte-plane slot */
 	b->coef_used += cbytes;
 	b->out_used += obytes;
 	b->slots.push_back(s);
@@ -454,7 +473,7 @@ extern "C" int mij_batch_set_flags(mij_batch *b, int slot, uint32_t flags)
 	if (!b || slot < 0 || slot >= (int)b->slots.size())
 		return set_err(MIJ_E_ARG, "bad slot");
 	b->slots[(size_t)slot].desc.flags = flags;
-	b->slots[(size_t)slot].dev.flags = (int32_t)flags;
+	b->slots[(size_t)slot].dev.flags = (int32_t)flags | (b->slots[(size_t)slot].coef_bytes_fmt ? MIJ_DEV_COEF_BYTES : 0);
 	b->uploaded = b->launched = false;
 	return MIJ_OK;
 }
@@ -556,12 +575,12 @@ extern "C" int mij_batch_upload(mij_batch *b)
 		return set_err(MIJ_E_STATE, "batch is empty");
 
 	/* ---- plan: group fused images by (n_out, wide); everything else goes two-pass */
-	std::vector<WorkBand> bands[4];
+	std::vector<WorkBand> bands[8]; /* (n_out 3/4) x (narrow, wide) x (int16, byte planes) */
 	std::vector<WorkIdct> idct[13]; /* 0,1: two-pass (narrow, wide); 2..5: fused 4:4:4 (n_out 3/4 x narrow/wide); 6: two-pass pass 2 (row groups);
 	                                  7..10: fused 4:2:2 bands (n_out 3/4 x narrow/wide; comp = first MCU row, first = end MCU row);
 	                                  11,12: fused grey (narrow, wide) */
 	size_t lds422[4] = {0, 0, 0, 0};
-	size_t band_lds[4] = {0, 0, 0, 0};
+	size_t band_lds[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	b->twopass_slots.clear();
 	size_t planes_need = 0, planes_off = 0;
 	const int cu = b->ctx->prop.multiProcessorCount > 0 ? b->ctx->prop.multiProcessorCount : 256;
@@ -608,7 +627,7 @@ extern "C" int mij_batch_upload(mij_batch *b)
 		}
 		if (fused420_ok(b, d)) {
 			s.path = 1;
-			const int g = (d.n_out == 4 ? 2 : 0) + wide;
+			const int g = (d.n_out == 4 ? 2 : 0) + wide + (s.coef_bytes_fmt ? 4 : 0);
 			/* split mcu_y into nb equal-ish bands */
 			int nb = b->band_rows > 0 ? (d.mcu_y + b->band_rows - 1) / b->band_rows : auto_nb;
 			if (nb > d.mcu_y)
@@ -713,7 +732,7 @@ extern "C" int mij_batch_upload(mij_batch *b)
 
 	/* ---- work lists */
 	size_t nb_total = 0, ni_total = 0;
-	for (int g = 0; g < 4; ++g)
+	for (int g = 0; g < 8; ++g)
 		nb_total += bands[g].size();
 	for (int g = 0; g < 13; ++g)
 		ni_total += idct[g].size();
@@ -727,13 +746,14 @@ extern "C" int mij_batch_upload(mij_batch *b)
 	b->band_launches.clear();
 	b->idct_launches.clear();
 	size_t pos = 0;
-	for (int g = 0; g < 4; ++g) {
+	for (int g = 0; g < 8; ++g) {
 		if (bands[g].empty())
 			continue;
 		memcpy(b->h_bands + pos, bands[g].data(), bands[g].size() * sizeof(WorkBand));
 		mij_batch::BandLaunch L;
 		L.nout = (g & 2) ? 4 : 3;
 		L.wide = g & 1;
+		L.b8 = (g & 4) != 0;
 		L.first = pos;
 		L.count = bands[g].size();
 		L.lds = band_lds[g];
@@ -807,7 +827,16 @@ extern "C" int mij_batch_launch(mij_batch *b)
 	for (const auto &L : b->band_launches) {
 		const dim3 grid((unsigned)L.count), block(256);
 		const WorkBand *wk = b->d_bands + L.first;
-		if (L.nout == 3 && !L.wide)
+		if (L.b8) {
+			if (L.nout == 3 && !L.wide)
+				hipLaunchKernelGGL((k_fused420<3, false, true>), grid, block, L.lds, b->stream, b->d_imgs, wk, b->d_coef, b->d_out);
+			else if (L.nout == 3)
+				hipLaunchKernelGGL((k_fused420<3, true, true>), grid, block, L.lds, b->stream, b->d_imgs, wk, b->d_coef, b->d_out);
+			else if (!L.wide)
+				hipLaunchKernelGGL((k_fused420<4, false, true>), grid, block, L.lds, b->stream, b->d_imgs, wk, b->d_coef, b->d_out);
+			else
+				hipLaunchKernelGGL((k_fused420<4, true, true>), grid, block, L.lds, b->stream, b->d_imgs, wk, b->d_coef, b->d_out);
+		} else if (L.nout == 3 && !L.wide)
 			hipLaunchKernelGGL((k_fused420<3, false>), grid, block, L.lds, b->stream, b->d_imgs, wk, b->d_coef, b->d_out);
 		else if (L.nout == 3)
 			hipLaunchKernelGGL((k_fused420<3, true>), grid, block, L.lds, b->stream, b->d_imgs, wk, b->d_coef, b->d_out);
@@ -1009,7 +1038,7 @@ struct EsArena {
 	std::vector<int> scan_slot; /* scan index -> batch slot */
 	size_t sub_used, blk_used, work_used, scan_cap, n_tabs;
 	int last_rounds, cur;
-	bool in_flight;
+	bool in_flight, coef_bytes_optin;
 };
 
 static const int ES_MAX_ROUNDS = 96;
@@ -1090,6 +1119,7 @@ extern "C" int mij_batch_entropy_reserve(mij_batch *b, size_t stream_bytes)
 		es_free(e);
 		return set_err(r == hipErrorOutOfMemory ? MIJ_E_NOMEM : MIJ_E_HIP, "mij_batch_entropy_reserve: %s", hipGetErrorString(r));
 	}
+	e->coef_bytes_optin = getenv("MIJ_COEF_BYTES") != nullptr && atoi(getenv("MIJ_COEF_BYTES")) != 0;
 	b->es = e;
 	return MIJ_OK;
 }
@@ -1138,6 +1168,20 @@ extern "C" int mij_batch_add_stream(mij_batch *b, const mjg_scan *scan, uint8_t 
 	Slot &s = b->slots[(size_t)slot];
 	s.dev_coef = 1;
 	s.es_index = (int)e->scan_slot.size();
+	/* Byte-coefficient planes (opt-in, MIJ_COEF_BYTES=1): only where the fused 4:2:0 kernel reads them, and only with
+	 * quantisers up to 128 (a biased byte times the quantiser must stay a positive int16 in the unpack).  A
+	 * coefficient outside -128..127 raises the verdict and the image goes to the host walk and int16 planes. */
+	s.coef_bytes_fmt = 0;
+	if (e->coef_bytes_optin && fused420_ok(b, scan->desc)) {
+		unsigned qmax = 0;
+		for (int c = 0; c < scan->desc.ncomp; ++c)
+			for (int k = 0; k < 64; ++k)
+				qmax = scan->qz[c][k] > qmax ? scan->qz[c][k] : qmax;
+		if (qmax <= 128) {
+			s.coef_bytes_fmt = 1;
+			apply_coef_bytes(s);
+		}
+	}
 	static_assert(sizeof(DevHuff) == sizeof(mjg_huff), "mjg_huff and DevHuff must match");
 	const size_t tab = e->n_tabs++;
 	memcpy(&e->h_huff[8 * tab], scan->huff, sizeof(mjg_huff) * 8);
@@ -1160,6 +1204,7 @@ extern "C" int mij_batch_add_stream(mij_batch *b, const mjg_scan *scan, uint8_t 
 		d.mcu_x = (uint32_t)scan->desc.mcu_x;
 		d.first_mcu = first_mcu;
 		d.last_seg = g + 1 == nseg;
+		d.fmt = (uint32_t)s.coef_bytes_fmt;
 		memcpy(d.blk_comp, scan->blk_comp, 12);
 		memcpy(d.blk_dx, scan->blk_dx, 12);
 		memcpy(d.blk_dy, scan->blk_dy, 12);
@@ -1360,6 +1405,8 @@ extern "C" int mij_batch_fallback_prepare(mij_batch *b, int slot)
 	if (s.stage_off == MIJ_NO_STAGE)
 		return set_err(MIJ_E_NOMEM, "slot %d has no staging planes (the staging arena was too small when it was added)", slot);
 	s.dev_coef = 0;
+	s.coef_bytes_fmt = 0;
+	s.dev.flags &= ~(int32_t)MIJ_DEV_COEF_BYTES;
 	s.desc.flags &= ~(uint32_t)MIJ_FLAG_WIDE_IDCT;
 	memset(b->stage + s.stage_off, 0, s.coef_bytes);
 	b->uploaded = b->launched = false;
