@@ -284,32 +284,75 @@ def main():
     datas = [ica.synth_jpeg(W, H, seed=s, quality=90) for s in range(distinct)]
     d0 = ica.HostDecoder.probe(datas[0], 3)
     cbytes, obytes = ica.Batch.coef_bytes(d0), ica.Batch.out_bytes(d0)
-    batch = ica.Batch(ctx, n_img, cbytes * distinct, cbytes * n_img, obytes * n_img)
-    t0 = time.time()
-    for d in datas:
-        batch.add_jpeg(d, 3)  # host Huffman walk straight into pinned staging
-    host_stage_s = time.time() - t0
-    for i in range(distinct, n_img):
-        batch.add_clone(i % distinct)  # own device buffers, filled device-to-device
-    batch.upload()
-    batch.wait()
+    nocheck = bool(os.environ.get("MIJ_BENCH_NOCHECK"))  # ablation builds (tools/ab.sh) write wrong or no pixels on purpose
+
+    def warm(bt):
+        t_w = time.perf_counter()
+        k = 0
+        while k < max(1, args.warmup) or (time.perf_counter() - t_w) * 1e3 < args.settle_ms:
+            bt.launch()
+            k += 1
+            if k % 8 == 0:
+                bt.wait()  # bound the queue depth while watching the wall clock
+        bt.wait()
+        return k
+
+    def int16_batch(count):
+        """North-star pipeline: host Huffman walk -> int16 tile planes -> H2D; `count` images (clones beyond `distinct`)."""
+        bt = ica.Batch(ctx, count, cbytes * distinct, cbytes * count, obytes * count)
+        t0 = time.time()
+        for d in datas:
+            bt.add_jpeg(d, 3)  # host Huffman walk straight into pinned staging
+        dt = time.time() - t0
+        for i in range(distinct, count):
+            bt.add_clone(i % distinct)  # own device buffers, filled device-to-device
+        bt.upload()
+        bt.wait()
+        return bt, dt
+
+    # reference pixels of the distinct images: host walk, int16 planes
+    ref_batch, host_stage_s = int16_batch(distinct)
+    ref_batch.launch()
+    ref_batch.wait()
+    assert {ref_batch.slot_path(s) for s in range(distinct)} == {1}, "the fused kernel did not take the batch"
+    src_hash = [ref_batch.hash_out(s) for s in range(distinct)]
+    ref_batch.close()
+
+    # the resident coefficient planes of the timed batch: byte planes written by the GPU Huffman walk (half the
+    # coefficient bytes; experimental) when they reproduce the reference pixels here and now, int16 planes otherwise
+    batch, planes, planes_note = None, "int16", None
+    if not os.environ.get("MIJ_BENCH_INT16"):
+        bb = None
+        try:
+            os.environ["MIJ_COEF_BYTES"] = "1"
+            bb = ica.Batch(ctx, n_img, cbytes * 2, cbytes * n_img, obytes * n_img)
+            bb.entropy_reserve(sum(len(x) * 9 // 8 + 4352 for x in datas))
+            ok, slots, reasons = bb.decode_jpegs(datas, 3, threads=usable_cores(), gpu_entropy=True)
+            if ok != distinct or slots != list(range(distinct)) or not all(bb.slot_coef_bytes(s) for s in slots):
+                raise RuntimeError("the GPU walk did not leave byte planes for every image: %r" % (reasons,))
+            for i in range(distinct, n_img):
+                bb.add_clone(i % distinct)
+            bb.submit()
+            bb.wait()
+            if not nocheck and [bb.hash_out(s) for s in range(distinct)] != src_hash:
+                raise RuntimeError("byte-plane pixels differ from the int16 pipeline's")
+            batch, planes, bb = bb, "bytes", None
+        except Exception as exc:  # noqa: BLE001 -- the experimental format must never cost the benchmark its line
+            planes_note = "%s: %s" % (type(exc).__name__, exc)
+        finally:
+            os.environ.pop("MIJ_COEF_BYTES", None)
+            if bb is not None:
+                bb.close()
+    if batch is None:
+        batch, _ = int16_batch(n_img)
 
     # ---- warm-up (untimed) + parity of what the kernel writes
-    t_w = time.perf_counter()
-    n_warm = 0
-    while n_warm < max(1, args.warmup) or (time.perf_counter() - t_w) * 1e3 < args.settle_ms:
-        batch.launch()
-        n_warm += 1
-        if n_warm % 8 == 0:
-            batch.wait()  # bound the queue depth while watching the wall clock
-    batch.wait()
+    n_warm = warm(batch)
     paths = {batch.slot_path(s) for s in range(n_img)}
     assert paths == {1}, "the fused kernel did not take the batch: %r" % paths
-    src_hash = [batch.hash_out(s) for s in range(distinct)]
     rng = np.random.default_rng(cp.rank)
-    nocheck = bool(os.environ.get("MIJ_BENCH_NOCHECK"))  # ablation builds (tools/ab.sh) write wrong or no pixels on purpose
-    for s in [] if nocheck else [int(v) for v in rng.integers(distinct, n_img, min(24, max(0, n_img - distinct)))] + ([n_img - 1] if n_img > distinct else []):
-        assert batch.hash_out(s) == src_hash[s % distinct], "clone %d differs from its source" % s
+    for s in [] if nocheck else list(range(distinct)) + [int(v) for v in rng.integers(distinct, n_img, min(24, max(0, n_img - distinct)))] + ([n_img - 1] if n_img > distinct else []):
+        assert batch.hash_out(s) == src_hash[s % distinct], "image %d differs from the reference pipeline's pixels" % s
 
     # ---- timed region: exactly K steps, barrier + device sync on both sides
     cp.barrier()
@@ -330,6 +373,27 @@ def main():
     kernel_ms_max = cp.max(kernel_ms)
 
     # ---- outside the timed region: the end-to-end path (bitstream in host RAM -> RGB in HBM), rank 0
+    # ---- outside the timed region: the same kernel family on the north-star pipeline's int16 planes, for comparison
+    int16_cmp = None
+    if planes == "bytes" and cp.rank == 0 and cp.world == 1:
+        try:
+            ib, _ = int16_batch(n_img)
+            warm(ib)
+            ib.timer_begin()
+            for _ in range(args.steps):
+                ib.launch()
+            ib.timer_end()
+            ib.wait()
+            ms16 = ib.timer_ms() / args.steps
+            assert nocheck or ib.hash_out(n_img - 1) == src_hash[(n_img - 1) % distinct]
+            ib.close()
+            int16_cmp = {"kernel": "mij::k_fused420<3,false>", "kernel_ms_per_launch": round(ms16, 4),
+                         "achieved": round(ALGO_BYTES_PER_IMAGE * n_img / (ms16 * 1e-3) / 1e9, 1), "unit": "GB/s",
+                         "frac": round(ALGO_BYTES_PER_IMAGE * n_img / (ms16 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "note": "host Huffman walk -> int16 coefficient planes (6 266 880 B per image actually read)"}
+        except Exception as exc:  # noqa: BLE001
+            int16_cmp = {"error": "%s: %s" % (type(exc).__name__, exc)}
+
     # ---- outside the timed region: the end-to-end path (bitstream in host RAM -> RGB in HBM), rank 0.  It must never
     # cost the benchmark its JSON line: any failure is reported inside the line instead
     e2e = None
@@ -348,7 +412,7 @@ def main():
             try:
                 tj = json.load(open(tf))
                 if tj.get("images_per_launch") == n_img:
-                    traffic = tj.get("hbm_bytes_per_launch")
+                    traffic = tj.get("hbm_bytes_per_launch_byte_planes" if planes == "bytes" else "hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -369,6 +433,9 @@ def main():
                 "images_per_gpu": n_img,
                 "distinct_images": distinct,
                 "sharding": "independent images, contiguous slices per GPU, no collective",
+                "coefficient_planes": ("bytes: AC coefficients as biased bytes + int16 DC array, written by the GPU Huffman walk (experimental); "
+                                       "pixels verified against the host-walk / int16 pipeline in this run") if planes == "bytes" else "int16 tile layout (host Huffman walk)",
+                "coefficient_planes_note": planes_note,
                 "warmup_launches_issued": n_warm,
                 "device": arch,
                 "compute_units": cus,
@@ -380,7 +447,7 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
-                "kernel": "mij::k_fused420<3,false>",
+                "kernel": "mij::k_fused420<3,false,true>" if planes == "bytes" else "mij::k_fused420<3,false>",
                 "kernel_ms_per_launch": round(kernel_ms_max, 4),
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_IMAGE * n_img,
             },
@@ -389,6 +456,8 @@ def main():
                 "note": "host entropy stage, 1 thread, writing pinned staging; outside the timed region",
             },
         }
+        if int16_cmp is not None:
+            out["roofline_int16_planes"] = int16_cmp
         if e2e is not None:
             out["end_to_end"] = e2e
         if cp.world == 1 and not args.no_cpu_baseline:

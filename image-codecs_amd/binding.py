@@ -364,6 +364,11 @@ class Batch:
         _check(L.mij_batch_entropy_run(self._h, fb, n, C.byref(cnt)), "mij_batch_entropy_run")
         return list(fb[:cnt.value])
 
+    def slot_coef_bytes(self, slot):
+        L = lib()
+        L.mij_batch_slot_coef_bytes.argtypes = [C.c_void_p, C.c_int]
+        return L.mij_batch_slot_coef_bytes(self._h, int(slot))
+
     def entropy_rounds(self):
         L = lib()
         L.mij_batch_entropy_rounds.argtypes = [C.c_void_p]

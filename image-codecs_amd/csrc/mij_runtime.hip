@@ -1426,6 +1426,13 @@ extern "C" int mij_batch_fetch_coef(mij_batch *b, int slot, int16_t *dst, size_t
 	return MIJ_OK;
 }
 
+extern "C" int mij_batch_slot_coef_bytes(const mij_batch *b, int slot)
+{
+	if (!b || slot < 0 || slot >= (int)b->slots.size())
+		return 0;
+	return b->slots[(size_t)slot].coef_bytes_fmt;
+}
+
 extern "C" int mij_batch_entropy_rounds(const mij_batch *b) { return b && b->es ? b->es->last_rounds : 0; }
 
 /* ------------------------------------------------------------------ encoder (mij_enc_*)

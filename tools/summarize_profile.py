@@ -12,7 +12,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
-KERNEL = "k_fused420<3, false>"
+KERNEL = "k_fused420<3, false"  # matches the int16 instantiation <3, false> and the byte-plane one <3, false, true>
 N_IMAGES = 1024
 ALGO = 12487680 * N_IMAGES
 
@@ -58,9 +58,13 @@ if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
               "read  %.4e B  (algorithmic %.4e, x%.3f)" % (rd, 6266880 * N_IMAGES, rd / (6266880 * N_IMAGES)),
               "write %.4e B  (algorithmic %.4e, x%.3f)" % (wr, 6220800 * N_IMAGES, wr / (6220800 * N_IMAGES)),
               "total %.4e B vs algorithmic %.4e (x%.3f)" % (rd + wr, ALGO, (rd + wr) / ALGO), ""]
-    json.dump({"tag": tag, "images_per_launch": N_IMAGES, "hbm_bytes_per_launch": int(rd + wr), "read_bytes": int(rd), "write_bytes": int(wr),
-               "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; KiB units; gfx950 FETCH_SIZE x2"},
-              open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    byte_planes = any("false, true>" in r["Kernel_Name"] for r in rows)
+    key = "hbm_bytes_per_launch_byte_planes" if byte_planes else "hbm_bytes_per_launch"
+    tj.update({"images_per_launch": N_IMAGES, key: int(rd + wr), key + "_read": int(rd), key + "_write": int(wr), key + "_tag": tag,
+               "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; KiB units; gfx950 FETCH_SIZE x2"})
+    json.dump(tj, open(tpath, "w"), indent=1)
 if "SQ_INSTS_VALU" in counters:
     lines += ["## 4. VALU", "SQ_INSTS_VALU %.4g wave-instr per launch = %.1f lane-ops per pixel" % (counters["SQ_INSTS_VALU"], counters["SQ_INSTS_VALU"] * 64 / (N_IMAGES * 1920 * 1080)), ""]
 
