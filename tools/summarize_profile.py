@@ -26,10 +26,15 @@ lines = ["# rocprofv3 summary %s" % tag, ""]
 # ---- pass 1: kernel trace
 kt = one("trace/**/*kernel_trace.csv")
 rows = [r for r in csv.DictReader(open(kt)) if KERNEL in r["Kernel_Name"]]
+# bench.py times the byte-plane instantiation when it validates, and the int16 one beside it: summarise the timed one
+BYTE_PLANES = any("false, true>" in r["Kernel_Name"] for r in rows)
+def timed(name):
+    return KERNEL in name and (("false, true>" in name) == BYTE_PLANES)
+rows = [r for r in rows if timed(r["Kernel_Name"])]
 big = max(int(r["Grid_Size_X"]) for r in rows)
 durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows if int(r["Grid_Size_X"]) == big]
 lines += ["## 1. `rocprofv3 --kernel-trace --stats -- python3 bench.py --images 1024 --steps 5 --warmup 1 --no-cpu-baseline --no-e2e`",
-          "mij::%s: %d launches of %d threads, avg %.4f ms, min %.4f, max %.4f" % (KERNEL, len(durs), big, sum(durs) / len(durs) / 1e6, min(durs) / 1e6, max(durs) / 1e6),
+          "mij::%s: %d launches of %d threads, avg %.4f ms, min %.4f, max %.4f" % (rows[0]["Kernel_Name"].split("(")[0].replace("void ", "").replace("mij::", ""), len(durs), big, sum(durs) / len(durs) / 1e6, min(durs) / 1e6, max(durs) / 1e6),
           "", "raw --stats table:", "```"]
 ks = one("trace/**/*kernel_stats.csv")
 lines += [l.rstrip() for l in open(ks)] + ["```", ""]
@@ -43,7 +48,7 @@ for name in ("fetch", "write", "sq", "lds"):
         continue
     per = {}
     for r in csv.DictReader(open(f)):
-        if KERNEL in r["Kernel_Name"] and int(r["Grid_Size"]) == big:
+        if timed(r["Kernel_Name"]) and int(r["Grid_Size"]) == big:
             per.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     for k, v in per.items():
         counters[k] = sum(v) / len(v)
@@ -60,7 +65,7 @@ if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
               "total %.4e B vs algorithmic %.4e (x%.3f)" % (rd + wr, ALGO, (rd + wr) / ALGO), ""]
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
-    byte_planes = any("false, true>" in r["Kernel_Name"] for r in rows)
+    byte_planes = BYTE_PLANES
     key = "hbm_bytes_per_launch_byte_planes" if byte_planes else "hbm_bytes_per_launch"
     tj.update({"images_per_launch": N_IMAGES, key: int(rd + wr), key + "_read": int(rd), key + "_write": int(wr), key + "_tag": tag,
                "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; KiB units; gfx950 FETCH_SIZE x2"})
