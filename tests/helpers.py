@@ -255,7 +255,7 @@ def progressive_from_du(plan, du, script=1):
     hs = (C.c_int * 3)(*samp)
     vs = (C.c_int * 3)(*samp)
     qt = np.concatenate([np.frombuffer(bytes(plan.ytab), np.uint8), np.frombuffer(bytes(plan.ctab), np.uint8)])
-    cap = 64 + sum(p.size for p in planes) * 3
+    cap = 4096 + sum(p.size for p in planes) * 3  # headers and ten scans' tables dominate tiny pictures
     out = np.empty(cap, np.uint8)
     n = L.pw_write_progressive(ptrs, 3, plan.width, plan.height, hs, vs, qt.ctypes.data_as(C.c_void_p), int(script), out.ctypes.data_as(C.c_void_p), cap)
     assert 0 < n <= cap, n
