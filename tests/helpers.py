@@ -285,7 +285,7 @@ def progressive_422_from_444(plan, du, script=1):
     hs = (C.c_int * 3)(2, 1, 1)
     vs = (C.c_int * 3)(1, 1, 1)
     qt = np.concatenate([np.frombuffer(bytes(plan.ytab), np.uint8), np.frombuffer(bytes(plan.ctab), np.uint8)])
-    cap = 1024 + sum(p.size for p in planes) * 3
+    cap = 4096 + sum(p.size for p in planes) * 3
     out = np.empty(cap, np.uint8)
     n = L.pw_write_progressive(ptrs, 3, plan.width, plan.height, hs, vs, qt.ctypes.data_as(C.c_void_p), int(script), out.ctypes.data_as(C.c_void_p), cap)
     assert 0 < n <= cap, n
@@ -303,7 +303,7 @@ def progressive_grey_from_444(plan, du, script=1):
     ptrs = (C.c_void_p * 1)(y.ctypes.data)
     one = (C.c_int * 1)(1)
     qt = np.concatenate([np.frombuffer(bytes(plan.ytab), np.uint8), np.frombuffer(bytes(plan.ctab), np.uint8)])
-    cap = 1024 + y.size * 3
+    cap = 4096 + y.size * 3
     out = np.empty(cap, np.uint8)
     n = L.pw_write_progressive(ptrs, 1, plan.width, plan.height, one, one, qt.ctypes.data_as(C.c_void_p), int(script), out.ctypes.data_as(C.c_void_p), cap)
     assert 0 < n <= cap, n
