@@ -12,7 +12,11 @@ when the timed region starts (host Huffman walk + H2D happen before it; see DESI
 PCIe/host-inclusive rate, which is never `value`).  Each rank owns `--images` images (default
 1024 = BASELINE configs[1]) in its own device buffers -- every slot has its own coefficient and
 pixel memory (12.8 GB per GPU >> the 256 MiB Infinity Cache) -- and there is no data-path
-collective: images are independent (weak scaling).
+collective: images are independent (weak scaling).  The resident planes of the timed batch are byte-coefficient planes
+written by the (experimental) GPU Huffman walk -- AC coefficients as biased bytes, DC aside: half the coefficient bytes --
+whenever they reproduce, in this very run, the pixels of the north-star pipeline (host walk -> int16 planes); that
+pipeline's own kernel figure is reported beside it as `roofline_int16_planes`, and it is the fallback (MIJ_BENCH_INT16=1
+forces it).  `roofline.achieved` keeps the ALGORITHMIC bytes (int16 coefficients) in the numerator either way.
 
 The one JSON line (rank 0) also carries
   roofline      the fused kernel against the HBM roofline: algorithmic bytes per launch
