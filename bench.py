@@ -13,7 +13,7 @@ PCIe/host-inclusive rate, which is never `value`).  Each rank owns `--images` im
 1024 = BASELINE configs[1]) in its own device buffers -- every slot has its own coefficient and
 pixel memory (12.8 GB per GPU >> the 256 MiB Infinity Cache) -- and there is no data-path
 collective: images are independent (weak scaling).  The resident planes of the timed batch are byte-coefficient planes
-written by the (experimental) GPU Huffman walk -- AC coefficients as biased bytes, DC aside: half the coefficient bytes --
+written by the (experimental) GPU Huffman walk -- AC coefficients as signed bytes, DC aside: half the coefficient bytes --
 whenever they reproduce, in this very run, the pixels of the north-star pipeline (host walk -> int16 planes); that
 pipeline's own kernel figure is reported beside it as `roofline_int16_planes`, and it is the fallback (MIJ_BENCH_INT16=1
 forces it).  `roofline.achieved` keeps the ALGORITHMIC bytes (int16 coefficients) in the numerator either way.
@@ -437,7 +437,7 @@ def main():
                 "images_per_gpu": n_img,
                 "distinct_images": distinct,
                 "sharding": "independent images, contiguous slices per GPU, no collective",
-                "coefficient_planes": ("bytes: AC coefficients as biased bytes + int16 DC array, written by the GPU Huffman walk (experimental); "
+                "coefficient_planes": ("bytes: AC coefficients as signed bytes + int16 DC array, written by the GPU Huffman walk (experimental); "
                                        "pixels verified against the host-walk / int16 pipeline in this run") if planes == "bytes" else "int16 tile layout (host Huffman walk)",
                 "coefficient_planes_note": planes_note,
                 "warmup_launches_issued": n_warm,

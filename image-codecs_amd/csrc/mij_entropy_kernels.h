@@ -57,7 +57,7 @@ struct DevScan {
 	uint32_t bpm, mcu_x;
 	uint32_t first_mcu;  /* restart intervals: the MCU this segment starts at (0 without restart markers) */
 	uint32_t last_seg;   /* the segment that ends at EOI */
-	uint32_t fmt;        /* 1: byte-coefficient planes (MIJ_DEV_COEF_BYTES): AC as value + 128, DC in its own int16 array */
+	uint32_t fmt;        /* 1: byte-coefficient planes (MIJ_DEV_COEF_BYTES): AC as signed bytes, DC in its own int16 array */
 	uint8_t blk_comp[12], blk_dx[12], blk_dy[12]; /* block-in-MCU -> component and position inside the MCU */
 	uint8_t dc_tab[4], ac_tab[4];                 /* component -> table index (0..3 DC, 4..7 AC) of this scan's eight tables */
 	uint32_t tab_off;    /* first of the eight DevHuff of this scan */
@@ -171,7 +171,7 @@ struct EsWriter { /* where the blocks of the write pass go */
 			for (int c = 0; c < 8; ++c) {
 				uint2 *src = reinterpret_cast<uint2 *>(reinterpret_cast<uint8_t *>(buf) + 8 * c);
 				const uint2 v = *src;
-				*src = make_uint2(0x80808080u, 0x80808080u);
+				*src = make_uint2(0, 0);
 				*reinterpret_cast<uint2 *>(blk8 + (c << 9)) = v;
 			}
 			return;
@@ -189,7 +189,7 @@ struct EsWriter { /* where the blocks of the write pass go */
 		if (sc->fmt) {
 			if ((uint32_t)(v + 128) > 255u)
 				atomicOr(anom8, 128u);
-			const uint8_t u = (uint8_t)(v + 128);
+			const uint8_t u = (uint8_t)v; /* two's complement byte */
 			if (buf)
 				reinterpret_cast<uint8_t *>(buf)[zpos[k]] = u;
 			else
@@ -444,9 +444,8 @@ __global__ __launch_bounds__(256) void k_es_write(const DevScan *__restrict__ sc
 	if (threadIdx.x < 64)
 		zpos[threadIdx.x] = mij_zigzag_pos[threadIdx.x];
 	{
-		const uint32_t fill = sc.fmt ? 0x80808080u : 0u; /* "no coefficient" in either format */
 		for (uint32_t i = threadIdx.x; i < 256u * MIJ_ES_BUFPITCH / 16u; i += 256)
-			reinterpret_cast<uint4 *>(stage)[i] = make_uint4(fill, fill, fill, fill);
+			reinterpret_cast<uint4 *>(stage)[i] = make_uint4(0, 0, 0, 0);
 	}
 	es_load_tables(huff + sc.tab_off, tabs);
 	const uint32_t i = wk.first + threadIdx.x;

@@ -45,7 +45,7 @@ struct DevComp {
 	uint64_t dc_off;      /* byte-coefficient planes (MIJ_DEV_COEF_BYTES): offset of the int16 DC array, one per block */
 };
 
-#define MIJ_DEV_COEF_BYTES 0x100 /* DevImage.flags: AC coefficients are biased bytes, DC separate (GPU entropy stage only) */
+#define MIJ_DEV_COEF_BYTES 0x100 /* DevImage.flags: AC coefficients are signed bytes, DC separate (GPU entropy stage only) */
 
 struct DevImage {
 	int32_t width, height, n_out, color;
@@ -262,9 +262,11 @@ __device__ __forceinline__ void pack_row(const Idct1D &r, uint32_t &lo, uint32_t
  * (32 dwords, wave-uniform -> scalar registers).  rows[i] = the 8 output samples of row i.
  * WIDE = false requires every first-pass output to fit int16 (host guarantee, mij.h).
  */
-template <bool WIDE>
+/* PREDEQ: the inputs are de-quantised already (byte-coefficient planes, load_block_b8) */
+template <bool WIDE, bool PREDEQ = false>
 __device__ __forceinline__ void idct_block(const IdctK &K, const uint4 (&c)[8], const uint32_t *__restrict__ dq, uint2 (&rows)[8])
 {
+	auto deq = [&](uint32_t v, uint32_t q) { return PREDEQ ? v : pkmul(v, q); };
 	if constexpr (!WIDE) {
 		/* pk[i][g]: row i, column pair g = (0,4) (2,6) (1,3) (5,7) */
 		uint32_t pk[8][4];
@@ -272,10 +274,10 @@ __device__ __forceinline__ void idct_block(const IdctK &K, const uint4 (&c)[8], 
 #pragma unroll
 		for (int g = 0; g < 4; ++g) {
 			const int a = ca[g], b = cb[g];
-			Idct1D va = idct1d_packed(K, K.bias1, pkmul(c[a].x, dq[4 * a + 0]), pkmul(c[a].y, dq[4 * a + 1]), pkmul(c[a].z, dq[4 * a + 2]),
-											  pkmul(c[a].w, dq[4 * a + 3]));
-			Idct1D vb = idct1d_packed(K, K.bias1, pkmul(c[b].x, dq[4 * b + 0]), pkmul(c[b].y, dq[4 * b + 1]), pkmul(c[b].z, dq[4 * b + 2]),
-											  pkmul(c[b].w, dq[4 * b + 3]));
+			Idct1D va = idct1d_packed(K, K.bias1, deq(c[a].x, dq[4 * a + 0]), deq(c[a].y, dq[4 * a + 1]), deq(c[a].z, dq[4 * a + 2]),
+											  deq(c[a].w, dq[4 * a + 3]));
+			Idct1D vb = idct1d_packed(K, K.bias1, deq(c[b].x, dq[4 * b + 0]), deq(c[b].y, dq[4 * b + 1]), deq(c[b].z, dq[4 * b + 2]),
+											  deq(c[b].w, dq[4 * b + 3]));
 			uint32_t pg[8];
 			shr_pack8_i16<10>(va.o, vb.o, pg);
 #pragma unroll
@@ -291,8 +293,8 @@ __device__ __forceinline__ void idct_block(const IdctK &K, const uint4 (&c)[8], 
 		int v[8][8]; /* v[row][col] */
 #pragma unroll
 		for (int k = 0; k < 8; ++k) {
-			Idct1D col = idct1d_packed(K, K.bias1, pkmul(c[k].x, dq[4 * k + 0]), pkmul(c[k].y, dq[4 * k + 1]), pkmul(c[k].z, dq[4 * k + 2]),
-												pkmul(c[k].w, dq[4 * k + 3]));
+			Idct1D col = idct1d_packed(K, K.bias1, deq(c[k].x, dq[4 * k + 0]), deq(c[k].y, dq[4 * k + 1]), deq(c[k].z, dq[4 * k + 2]),
+												deq(c[k].w, dq[4 * k + 3]));
 #pragma unroll
 			for (int i = 0; i < 8; ++i)
 				v[i][k] = col.o[i] >> 10;
@@ -327,11 +329,14 @@ __device__ __forceinline__ void load_block(const uint8_t *__restrict__ plane, ui
 }
 
 /* The same block from a byte-coefficient plane (experimental; written by the GPU entropy stage): tiles of 4 KiB,
- * chunk k = column k as eight biased bytes (value + 128) in the row order of the int16 layout, DC (row 0 of column
- * 0) in its own int16 array.  One v_perm + one v_pk_sub_u16 per pair rebuild the int16 pairs; half the bytes. */
-__device__ __forceinline__ void load_block_b8(const uint8_t *__restrict__ plane, const uint8_t *__restrict__ dcarr, uint32_t L, uint4 (&c)[8])
+ * chunk k = column k as eight signed bytes in the row order of the int16 layout, DC (row 0 of column 0) in its own
+ * int16 array.  Unpacking and de-quantising are one step: v_mul_i32_i24 with an SDWA byte select (sign-extended)
+ * times the 16-bit quantiser, its low half written into one half of the destination -- two instructions per pair,
+ * the pair comes out as (short)(coef * dequant) (codec/jpeg.c:325-365).  dq = the component's table in the
+ * in-block pair order (wave-uniform).  Half the bytes of the int16 plane. */
+__device__ __forceinline__ void load_block_b8(const uint8_t *__restrict__ plane, const uint8_t *__restrict__ dcarr, uint32_t L, const uint32_t *__restrict__ dq,
+															 uint4 (&c)[8])
 {
-	const uint32_t bias = vreg(0x00800080u);
 	const uint8_t *base = plane + ((size_t)(L >> 6) << 12) + ((size_t)(L & 63u) << 3);
 	uint2 h[8];
 #pragma unroll
@@ -341,15 +346,23 @@ __device__ __forceinline__ void load_block_b8(const uint8_t *__restrict__ plane,
 		h[k] = make_uint2(v.x, v.y);
 	}
 	const uint32_t dc = *reinterpret_cast<const uint16_t *>(dcarr + 2u * (size_t)L);
+#define MIJ_DQ2(dst, src, q, b0, b1)                                                                                                            \
+	"v_mul_i32_i24_sdwa " dst ", sext(" src "), " q " dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:" b0 " src1_sel:WORD_0\n\t"                   \
+	"v_mul_i32_i24_sdwa " dst ", sext(" src "), " q " dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:" b1 " src1_sel:WORD_1\n\t"
 #pragma unroll
 	for (int k = 0; k < 8; ++k) {
-		v2u a = __builtin_bit_cast(v2u, __builtin_amdgcn_perm(0, h[k].x, 0x0c010c00u)) - __builtin_bit_cast(v2u, bias);
-		v2u b = __builtin_bit_cast(v2u, __builtin_amdgcn_perm(0, h[k].x, 0x0c030c02u)) - __builtin_bit_cast(v2u, bias);
-		v2u e = __builtin_bit_cast(v2u, __builtin_amdgcn_perm(0, h[k].y, 0x0c010c00u)) - __builtin_bit_cast(v2u, bias);
-		v2u f = __builtin_bit_cast(v2u, __builtin_amdgcn_perm(0, h[k].y, 0x0c030c02u)) - __builtin_bit_cast(v2u, bias);
-		c[k] = make_uint4(__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b), __builtin_bit_cast(uint32_t, e), __builtin_bit_cast(uint32_t, f));
+		uint32_t x, y, z, w;
+		asm(MIJ_DQ2("%0", "%4", "%6", "BYTE_0", "BYTE_1") MIJ_DQ2("%1", "%4", "%7", "BYTE_2", "BYTE_3") MIJ_DQ2("%2", "%5", "%8", "BYTE_0", "BYTE_1")
+				 MIJ_DQ2("%3", "%5", "%9", "BYTE_2", "BYTE_3") "s_nop 0"
+			 : "=&v"(x), "=&v"(y), "=&v"(z), "=&v"(w)
+			 : "v"(h[k].x), "v"(h[k].y), "s"(dq[4 * k + 0]), "s"(dq[4 * k + 1]), "s"(dq[4 * k + 2]), "s"(dq[4 * k + 3]));
+		c[k] = make_uint4(x, y, z, w);
 	}
-	c[0].x = __builtin_amdgcn_perm(c[0].x, dc, 0x07060100u); /* (DC, r4) */
+#undef MIJ_DQ2
+	/* (short)(DC * dequant[0]) into the low half of the (r0, r4) pair of column 0 */
+	asm("v_mul_i32_i24_sdwa %0, sext(%1), %2 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0\n\ts_nop 0"
+		 : "+v"(c[0].x)
+		 : "v"(dc), "s"(dq[0]));
 }
 
 /* ------------------------------------------------------------------ colour (codec/jpeg.c:1976-2018)
@@ -884,10 +897,10 @@ __global__ __launch_bounds__(256) void k_fused420(const DevImage *__restrict__ i
 				uint4 c[8];
 				uint2 rows[8];
 				if (B8)
-					load_block_b8(comp == 1 ? coefCb : coefCr, comp == 1 ? dcCb : dcCr, (uint32_t)(mc * bwC + bx), c);
+					load_block_b8(comp == 1 ? coefCb : coefCr, comp == 1 ? dcCb : dcCr, (uint32_t)(mc * bwC + bx), im.dq[comp], c);
 				else
 					load_block(comp == 1 ? coefCb : coefCr, (uint32_t)(mc * bwC + bx), c);
-				idct_block<WIDE>(KI, c, im.dq[comp], rows);
+				idct_block<WIDE, B8>(KI, c, im.dq[comp], rows);
 				*reinterpret_cast<uint2 *>((comp == 1 ? dstCb : dstCr) + 8 * bx) = keep ? rows[7] : rows[0];
 			}
 		}
@@ -987,10 +1000,10 @@ __global__ __launch_bounds__(256) void k_fused420(const DevImage *__restrict__ i
 				const int i = ww * 64 + lane; /* block of the two luma block rows 2m, 2m+1 (contiguous in L) */
 				if (i < 2 * bwY) {
 					if (B8)
-						load_block_b8(coefY, dcY, (uint32_t)(2 * m * bwY + i), c);
+						load_block_b8(coefY, dcY, (uint32_t)(2 * m * bwY + i), im.dq[0], c);
 					else
 						load_block(coefY, (uint32_t)(2 * m * bwY + i), c);
-					idct_block<WIDE>(KI, c, im.dq[0], rows);
+					idct_block<WIDE, B8>(KI, c, im.dq[0], rows);
 					const int by = i >= bwY ? 1 : 0, bx = i - by * bwY;
 					uint8_t *dst = sY + (8 * by) * YP + 8 * bx;
 #pragma unroll
@@ -1002,10 +1015,10 @@ __global__ __launch_bounds__(256) void k_fused420(const DevImage *__restrict__ i
 				const int bx = ((ww - nYw) - (comp == 2 ? nCw : 0)) * 64 + lane;
 				if (bx < bwC) {
 					if (B8)
-						load_block_b8(comp == 1 ? coefCb : coefCr, comp == 1 ? dcCb : dcCr, (uint32_t)(m * bwC + bx), c);
+						load_block_b8(comp == 1 ? coefCb : coefCr, comp == 1 ? dcCb : dcCr, (uint32_t)(m * bwC + bx), im.dq[comp], c);
 					else
 						load_block(comp == 1 ? coefCb : coefCr, (uint32_t)(m * bwC + bx), c);
-					idct_block<WIDE>(KI, c, im.dq[comp], rows);
+					idct_block<WIDE, B8>(KI, c, im.dq[comp], rows);
 					uint8_t *dst = (comp == 1 ? sCb : sCr) + 8 * bx;
 #pragma unroll
 					for (int r = 0; r < 8; ++r)

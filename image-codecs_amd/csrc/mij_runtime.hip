@@ -133,7 +133,7 @@ struct Slot {
 	int clone_of;      /* -1: own staging */
 	int dev_coef;      /* 1: the GPU entropy stage wrote the coefficient planes in HBM; nothing to upload */
 	int es_index;      /* index into the entropy arena's scan list, or -1 */
-	int coef_bytes_fmt; /* 1: byte-coefficient planes (experimental, MIJ_COEF_BYTES=1): AC as biased bytes, DC array aside */
+	int coef_bytes_fmt; /* 1: byte-coefficient planes (experimental, MIJ_COEF_BYTES=1): AC as signed bytes, DC array aside */
 	int path;          /* 0 none, 1 fused 4:2:0, 2 two-pass, 3 fused 4:4:4 */
 };
 
@@ -1168,19 +1168,14 @@ extern "C" int mij_batch_add_stream(mij_batch *b, const mjg_scan *scan, uint8_t 
 	Slot &s = b->slots[(size_t)slot];
 	s.dev_coef = 1;
 	s.es_index = (int)e->scan_slot.size();
-	/* Byte-coefficient planes (opt-in, MIJ_COEF_BYTES=1): only where the fused 4:2:0 kernel reads them, and only with
-	 * quantisers up to 128 (a biased byte times the quantiser must stay a positive int16 in the unpack).  A
-	 * coefficient outside -128..127 raises the verdict and the image goes to the host walk and int16 planes. */
+	/* Byte-coefficient planes (opt-in, MIJ_COEF_BYTES=1): only where the fused 4:2:0 kernel reads them.  Any
+	 * quantiser will do: the unpack multiplies the sign-extended byte by the 16-bit quantiser and keeps the low
+	 * half, which is the reference's (short)(v * dequant).  A coefficient outside -128..127 raises the verdict
+	 * and the image goes to the host walk and int16 planes. */
 	s.coef_bytes_fmt = 0;
 	if (e->coef_bytes_optin && fused420_ok(b, scan->desc)) {
-		unsigned qmax = 0;
-		for (int c = 0; c < scan->desc.ncomp; ++c)
-			for (int k = 0; k < 64; ++k)
-				qmax = scan->qz[c][k] > qmax ? scan->qz[c][k] : qmax;
-		if (qmax <= 128) {
-			s.coef_bytes_fmt = 1;
-			apply_coef_bytes(s);
-		}
+		s.coef_bytes_fmt = 1;
+		apply_coef_bytes(s);
 	}
 	static_assert(sizeof(DevHuff) == sizeof(mjg_huff), "mjg_huff and DevHuff must match");
 	const size_t tab = e->n_tabs++;

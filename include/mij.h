@@ -240,8 +240,8 @@ int mij_batch_fallback_prepare(mij_batch *b, int slot);
 /* tests: the coefficient planes of a slot as they sit in HBM (tile layout), after entropy_run or upload */
 int mij_batch_fetch_coef(mij_batch *b, int slot, int16_t *dst, size_t dst_elems);
 /* 1 if the slot's coefficients sit in HBM as byte planes (experimental, environment MIJ_COEF_BYTES=1 when the entropy
- * arena is reserved): AC coefficients as biased bytes, DC in its own array -- half the bytes for the fused 4:2:0 kernel.
- * Chosen per image by mij_batch_add_stream (4:2:0 YCbCr, quantisers <= 128); an image with a coefficient outside
+ * arena is reserved): AC coefficients as signed bytes, DC in its own array -- half the bytes for the fused 4:2:0 kernel.
+ * Chosen per image by mij_batch_add_stream (4:2:0 YCbCr, any quantiser); an image with a coefficient outside
  * -128..127 is handed back by the GPU walk and ends up in int16 planes through the host walk. */
 int mij_batch_slot_coef_bytes(const mij_batch *b, int slot);
 /* tests / tuning: synchronisation rounds the last entropy_run needed for its slowest image */

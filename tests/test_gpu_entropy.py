@@ -236,7 +236,7 @@ def test_gpu_walk_restart_intervals_and_own_tables(ica, oracle, gpu_ctx, golden)
 
 
 def test_byte_coefficient_planes_opt_in(ica, oracle, gpu_ctx, monkeypatch):
-    """MIJ_COEF_BYTES=1 (experimental): the GPU walk leaves 4:2:0 images as byte-coefficient planes (AC biased
+    """MIJ_COEF_BYTES=1 (experimental): the GPU walk leaves 4:2:0 images as byte-coefficient planes (AC signed
     bytes, DC aside) and the fused kernel unpacks them; pixels unchanged.  Images with a coefficient outside
     -128..127 come back for the host walk and int16 planes; other layouts never use the format."""
     monkeypatch.setenv("MIJ_COEF_BYTES", "1")
@@ -244,7 +244,7 @@ def test_byte_coefficient_planes_opt_in(ica, oracle, gpu_ctx, monkeypatch):
     datas = [ica.synth_jpeg(w, h, i, q) for i, (w, h, q) in enumerate(((64, 48, 90), (200, 120, 90), (33, 17, 75), (640, 480, 90), (1920, 1080, 90), (250, 131, 50)))]
     datas.append(ica.synth_jpeg(320, 200, 7, 95))                                                         # 4:4:4: int16 planes
     datas.append(ica.stbi_write_jpg_to_memory(rng.integers(0, 256, (120, 160, 3)).astype(np.uint8), 90))   # noise: coefficients beyond a byte
-    datas.append(ica.synth_jpeg(96, 96, 9, 10))                                                            # quantisers above 128: int16 planes
+    datas.append(ica.synth_jpeg(96, 96, 9, 10))                                                            # quantisers up to 255: byte planes all the same
     for req in (3, 4):
         b = ica.Batch(gpu_ctx, len(datas) + 2, 64 << 20, 64 << 20, 64 << 20)
         b.entropy_reserve(8 << 20)
@@ -256,4 +256,6 @@ def test_byte_coefficient_planes_opt_in(ica, oracle, gpu_ctx, monkeypatch):
         for d, s_ in zip(datas, slots):
             assert np.array_equal(b.fetch(s_), oracle.load(d, req)[1]), (s_, req)
         assert np.array_equal(b.fetch(c1), oracle.load(datas[4], req)[1])
+        fmt = [b.slot_coef_bytes(s_) for s_ in slots]
+        assert fmt == [1, 1, 1, 1, 1, 1, 0, 0, 1], fmt
         b.close()
