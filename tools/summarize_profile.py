@@ -33,9 +33,19 @@ def timed(name):
 rows = [r for r in rows if timed(r["Kernel_Name"])]
 big = max(int(r["Grid_Size_X"]) for r in rows)
 durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows if int(r["Grid_Size_X"]) == big]
-lines += ["## 1. `rocprofv3 --kernel-trace --stats -- python3 bench.py --images 1024 --steps 5 --warmup 1 --no-cpu-baseline --no-e2e`",
+lines += ["## 1. `rocprofv3 --kernel-trace --stats -- python3 bench.py --images 1024 --steps 20 --warmup 3 --no-cpu-baseline --no-e2e`",
           "mij::%s: %d launches of %d threads, avg %.4f ms, min %.4f, max %.4f" % (rows[0]["Kernel_Name"].split("(")[0].replace("void ", "").replace("mij::", ""), len(durs), big, sum(durs) / len(durs) / 1e6, min(durs) / 1e6, max(durs) / 1e6),
-          "", "raw --stats table:", "```"]
+          ""]
+# bench.py's own HIP-event figure from the same (profiled) process, for the agreement check
+try:
+    bj = json.loads(open(os.path.join(src, "trace.stdout")).read().strip().splitlines()[-1])
+    steps = int(bj["steps"])
+    lines += ["bench.py's HIP-event figure inside this profiled run: %.4f ms per launch over its %d timed launches "
+              "(roofline.frac %.4f); the trace's last %d launches average %.4f ms." % (
+                  bj["roofline"]["kernel_ms_per_launch"], steps, bj["roofline"]["frac"], steps, sum(durs[-steps:]) / steps / 1e6), ""]
+except Exception as e:  # noqa: BLE001 - the summary is still useful without this line
+    lines += ["(no bench line in trace.stdout: %s)" % e, ""]
+lines += ["raw --stats table:", "```"]
 ks = one("trace/**/*kernel_stats.csv")
 lines += [l.rstrip() for l in open(ks)] + ["```", ""]
 shutil.copy(ks, os.path.join(ROOT, "profiles", tag + "_kernel_stats.csv"))
