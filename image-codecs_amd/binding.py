@@ -310,6 +310,14 @@ class Batch:
         self.descs.append(desc)
         return slot
 
+    def _desc(self, slot):
+        """Descriptor of a slot; slots added by the C-side front ends keep (data, req_comp) until first use, so that
+        a pipelined caller does not pay a Python-side header probe per image."""
+        d = self.descs[slot]
+        if isinstance(d, tuple):
+            d = self.descs[slot] = HostDecoder.probe(d[0], d[1])
+        return d
+
     def add_clone(self, src):
         slot = _check(lib().mij_batch_add_clone(self._h, int(src)), "mij_batch_add_clone")
         self.descs.append(self.descs[src])
@@ -317,7 +325,7 @@ class Batch:
 
     def staging(self, slot):
         """int16 numpy view over the slot's pinned planes (all components, back to back)."""
-        d = self.descs[slot]
+        d = self._desc(slot)
         p = lib().mij_batch_coef(self._h, int(slot), 0)
         if not p:
             raise MijError("mij_batch_coef: %s" % lib().mij_last_error().decode())
@@ -378,7 +386,7 @@ class Batch:
         _check(lib().mij_batch_fallback_prepare(self._h, int(slot)), "mij_batch_fallback_prepare")
 
     def fetch_coef(self, slot):
-        d = self.descs[slot]
+        d = self._desc(slot)
         out = np.empty(d.coef_elems(), dtype=np.int16)
         L = lib()
         L.mij_batch_fetch_coef.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
@@ -410,11 +418,11 @@ class Batch:
         if rc < 0:
             raise MijError("mjh_decode_batch: %s" % lib().mij_last_error().decode())
         out_slots = list(slots)
-        # mirror the descriptors of the slots the C side added (header probe is cheap)
+        # mirror the descriptors of the slots the C side added
         for i, sl in enumerate(out_slots):
             real = sl if sl >= 0 else (-1 - sl if sl < -1 else None)
             if real is not None and real >= first:
-                self.descs.append(HostDecoder.probe(datas[i], req_comp))
+                self.descs.append((datas[i], req_comp))  # header probed when somebody asks (fetch, staging)
         return rc, out_slots, [r.decode() if r else None for r in reasons]
 
     def decode_jpegs_gpu_begin(self, datas, req_comp=0, threads=1):
@@ -443,7 +451,7 @@ class Batch:
         for i, sl in enumerate(out_slots):
             real = sl if sl >= 0 else (-1 - sl if sl < -1 else None)
             if real is not None and real >= job["first"]:
-                self.descs.append(HostDecoder.probe(job["datas"][i], job["req"]))
+                self.descs.append((job["datas"][i], job["req"]))
         return rc, out_slots, [r.decode() if r else None for r in job["reasons"]]
 
     def set_flags(self, slot, flags):
@@ -465,7 +473,7 @@ class Batch:
         _check(lib().mij_batch_wait(self._h), "mij_batch_wait")
 
     def fetch(self, slot):
-        d = self.descs[slot]
+        d = self._desc(slot)
         out = np.empty((d.height, d.width, d.n_out), dtype=np.uint8)
         _check(lib().mij_batch_fetch(self._h, int(slot), out.ctypes.data_as(C.c_void_p), C.c_size_t(out.size)), "mij_batch_fetch")
         return out

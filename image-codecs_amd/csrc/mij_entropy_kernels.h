@@ -134,9 +134,19 @@ __device__ __forceinline__ int es_extend(uint64_t win, uint32_t len, uint32_t n)
 	return neg ? (int)bits - (int)((1u << n) - 1u) : (int)bits;
 }
 
+/* What the decode loop looks up per symbol or per block, copied into LDS once per workgroup: indexed by a per-lane
+ * block-in-MCU number these would otherwise be dependent global loads inside a divergent, serial loop. */
+struct EsLocal {
+	uint32_t tabs[12];  /* block-in-MCU -> component | DC table << 8 | AC table << 16 */
+	uint32_t geo[12];   /* h | v << 8 | dx << 16 | dy << 24 (write passes only) */
+	uint32_t bw[12];    /* the component's plane width in blocks */
+	uint64_t plane[12]; /* byte offset of the component's plane in the coefficient arena */
+	uint16_t qz[4][64]; /* DevScan.qz */
+};
+
 struct EsWriter { /* where the blocks of the write pass go */
 	const DevScan *sc;
-	const DevImage *im;
+	const EsLocal *loc;
 	int16_t *coef;       /* coefficient arena (tile layout) */
 	int16_t *dcdiff;     /* per block */
 	uint32_t *l1;        /* per block */
@@ -155,24 +165,26 @@ struct EsWriter { /* where the blocks of the write pass go */
 	uint32_t *pfinal;    /* where the bit position after the scan's last block is recorded */
 	__device__ __forceinline__ void locate(uint32_t c)
 	{
-		const uint32_t ci = sc->blk_comp[c];
-		const DevComp &cp = im->comp[ci];
-		const uint32_t bx = mx * (uint32_t)cp.h + sc->blk_dx[c], by = my * (uint32_t)cp.v + sc->blk_dy[c];
-		L = bx + by * (uint32_t)cp.bw;
-		uint8_t *plane = reinterpret_cast<uint8_t *>(coef) + cp.coef_off;
+		const uint32_t g = loc->geo[c];
+		const uint32_t bx = mx * (g & 255u) + ((g >> 16) & 255u), by = my * ((g >> 8) & 255u) + (g >> 24);
+		L = bx + by * loc->bw[c];
+		uint8_t *plane = reinterpret_cast<uint8_t *>(coef) + loc->plane[c];
 		blk = reinterpret_cast<int16_t *>(plane) + ((size_t)(L >> 6) << 12) + ((L & 63u) << 3);
 		blk8 = plane + ((size_t)(L >> 6) << 12) + ((L & 63u) << 3);
 	}
 	/* the staged block -> its eight chunks in the tile (complete, zeros included: the planes need no clearing) */
 	__device__ __forceinline__ void flush()
 	{
+		if (MIJ_VARIANT & 64) /* ablation: no staging reads, no stores */
+			return;
 		if (sc->fmt) {
 #pragma unroll
 			for (int c = 0; c < 8; ++c) {
 				uint2 *src = reinterpret_cast<uint2 *>(reinterpret_cast<uint8_t *>(buf) + 8 * c);
 				const uint2 v = *src;
 				*src = make_uint2(0, 0);
-				*reinterpret_cast<uint2 *>(blk8 + (c << 9)) = v;
+				if (!(MIJ_VARIANT & 32) || v.x == 0x12345678u) /* ablation bit 32: no global stores */
+					*reinterpret_cast<uint2 *>(blk8 + (c << 9)) = v;
 			}
 			return;
 		}
@@ -181,7 +193,8 @@ struct EsWriter { /* where the blocks of the write pass go */
 			uint4 *src = reinterpret_cast<uint4 *>(buf + 8 * c);
 			const uint4 v = *src;
 			*src = make_uint4(0, 0, 0, 0);
-			__builtin_nontemporal_store((u4v){v.x, v.y, v.z, v.w}, reinterpret_cast<u4v *>(blk + (c << 9)));
+			if (!(MIJ_VARIANT & 32) || v.x == 0x12345678u)
+				__builtin_nontemporal_store((u4v){v.x, v.y, v.z, v.w}, reinterpret_cast<u4v *>(blk + (c << 9)));
 		}
 	}
 	__device__ __forceinline__ void put(uint32_t k, int v)
@@ -207,8 +220,8 @@ struct EsWriter { /* where the blocks of the write pass go */
  * decoding stops at block ordinal sc.nblocks, malformed input sets *anom.
  */
 template <bool WRITE>
-__device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const DevHuff *__restrict__ tabs, const uint8_t *__restrict__ stream, EsState &s, uint32_t p_end,
-															 EsWriter *wr, uint32_t *anom)
+__device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &loc, const DevHuff *__restrict__ tabs, const uint8_t *__restrict__ stream, EsState &s,
+															 uint32_t p_end, EsWriter *wr, uint32_t *anom)
 {
 	uint32_t done = 0, guard = 0;
 	const uint32_t limit = sc.nbits + 64u; /* the arena is zero padded: never read far past the data */
@@ -222,10 +235,10 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const DevHuff *
 		if (WRITE && wr->ord >= sc.nblocks)
 			break;
 		const uint64_t win = br.win;
-		const uint32_t ci = sc.blk_comp[s.c];
+		const uint32_t tb = loc.tabs[s.c], ci = tb & 255u;
 		uint32_t len = 0;
 		if (s.z == 0) {
-			const int t = es_symbol(tabs[sc.dc_tab[ci]], win, len);
+			const int t = es_symbol(tabs[(tb >> 8) & 255u], win, len);
 			if (t < 0 || t > 11 || len == 0) { /* the reference takes categories up to 16; nothing a conforming stream uses */
 				if (!WRITE) { /* a guessed start ran into a non-code: slip one bit and keep looking for the true sequence */
 					s.p += 1;
@@ -243,7 +256,7 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const DevHuff *
 			br.take(len + (uint32_t)t);
 			s.z = 1;
 		} else {
-			const int rs = es_symbol(tabs[sc.ac_tab[ci]], win, len);
+			const int rs = es_symbol(tabs[tb >> 16], win, len);
 			if (rs < 0 || len == 0) {
 				if (!WRITE) {
 					s.p += 1;
@@ -277,7 +290,7 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const DevHuff *
 					const int v = es_extend(win, len, n);
 					if (WRITE && !wr->skip) {
 						wr->put(k, v);
-						const int dq = (int)(int16_t)((uint32_t)v * sc.qz[ci][k]);
+						const int dq = (int)(int16_t)((uint32_t)v * loc.qz[ci][k]);
 						wr->acc += (uint32_t)(dq < 0 ? -dq : dq);
 					}
 					s.p += len + n;
@@ -340,12 +353,24 @@ struct EsWork {
 	uint32_t scan, first;
 };
 
-__device__ __forceinline__ void es_load_tables(const DevHuff *__restrict__ g, DevHuff *l)
+/* the scan's eight Huffman tables and its EsLocal into LDS (im == nullptr: no block placement needed); ends in a barrier */
+__device__ __forceinline__ void es_load_tables(const DevScan &sc, const DevImage *im, const DevHuff *__restrict__ g, DevHuff *l, EsLocal *loc)
 {
 	const uint32_t *src = reinterpret_cast<const uint32_t *>(g);
 	uint32_t *dst = reinterpret_cast<uint32_t *>(l);
 	for (uint32_t i = threadIdx.x; i < 8u * sizeof(DevHuff) / 4u; i += blockDim.x)
 		dst[i] = src[i];
+	if (threadIdx.x < 12u) {
+		const uint32_t c = threadIdx.x, ci = sc.blk_comp[c] & 3u;
+		loc->tabs[c] = ci | (uint32_t)(sc.dc_tab[ci] & 7u) << 8 | (uint32_t)(sc.ac_tab[ci] & 7u) << 16;
+		if (im) {
+			const DevComp &cp = im->comp[ci];
+			loc->geo[c] = ((uint32_t)cp.h & 255u) | ((uint32_t)cp.v & 255u) << 8 | (uint32_t)sc.blk_dx[c] << 16 | (uint32_t)sc.blk_dy[c] << 24;
+			loc->bw[c] = (uint32_t)cp.bw;
+			loc->plane[c] = cp.coef_off;
+		}
+	}
+	loc->qz[threadIdx.x >> 6][threadIdx.x & 63u] = sc.qz[threadIdx.x >> 6][threadIdx.x & 63u];
 	__syncthreads();
 }
 
@@ -353,9 +378,10 @@ __global__ __launch_bounds__(256) void k_es_cold(const DevScan *__restrict__ sca
 																 const uint8_t *__restrict__ streams, uint64_t *__restrict__ start, uint64_t *__restrict__ end, uint32_t *__restrict__ cnt)
 {
 	__shared__ DevHuff tabs[8];
+	__shared__ EsLocal loc;
 	const EsWork wk = work[blockIdx.x];
 	const DevScan &sc = scans[wk.scan];
-	es_load_tables(huff + sc.tab_off, tabs);
+	es_load_tables(sc, nullptr, huff + sc.tab_off, tabs, &loc);
 	const uint32_t i = wk.first + threadIdx.x;
 	if (i >= sc.nsub)
 		return;
@@ -365,7 +391,7 @@ __global__ __launch_bounds__(256) void k_es_cold(const DevScan *__restrict__ sca
 	s.c = 0;
 	start[sc.sub_off + i] = es_pack(s);
 	const uint32_t pe = min((i + 1u) * MIJ_ES_BITS, sc.nbits);
-	cnt[sc.sub_off + i] = es_decode<false>(sc, tabs, streams + sc.stream_off, s, pe, nullptr, nullptr);
+	cnt[sc.sub_off + i] = es_decode<false>(sc, loc, tabs, streams + sc.stream_off, s, pe, nullptr, nullptr);
 	end[sc.sub_off + i] = es_pack(s);
 }
 
@@ -375,9 +401,10 @@ __global__ __launch_bounds__(256) void k_es_sync(const DevScan *__restrict__ sca
 																 uint64_t *__restrict__ end_out, uint32_t *__restrict__ cnt, uint32_t *__restrict__ changed)
 {
 	__shared__ DevHuff tabs[8];
+	__shared__ EsLocal loc;
 	const EsWork wk = work[blockIdx.x];
 	const DevScan &sc = scans[wk.scan];
-	es_load_tables(huff + sc.tab_off, tabs);
+	es_load_tables(sc, nullptr, huff + sc.tab_off, tabs, &loc);
 	const uint32_t i = wk.first + threadIdx.x;
 	if (i >= sc.nsub)
 		return;
@@ -394,7 +421,7 @@ __global__ __launch_bounds__(256) void k_es_sync(const DevScan *__restrict__ sca
 	start[slot] = want;
 	EsState s = es_unpack(want);
 	const uint32_t pe = min((i + 1u) * MIJ_ES_BITS, sc.nbits);
-	cnt[slot] = es_decode<false>(sc, tabs, streams + sc.stream_off, s, pe, nullptr, nullptr);
+	cnt[slot] = es_decode<false>(sc, loc, tabs, streams + sc.stream_off, s, pe, nullptr, nullptr);
 	end_out[slot] = es_pack(s);
 	atomicAdd(&changed[wk.scan], 1u);
 }
@@ -437,6 +464,7 @@ __global__ __launch_bounds__(256) void k_es_write(const DevScan *__restrict__ sc
 																  uint32_t *__restrict__ anom, uint32_t *__restrict__ pfinal)
 {
 	__shared__ DevHuff tabs[8];
+	__shared__ EsLocal loc;
 	__shared__ uint8_t zpos[64];
 	__shared__ __attribute__((aligned(16))) uint8_t stage[256 * MIJ_ES_BUFPITCH];
 	const EsWork wk = work[blockIdx.x];
@@ -447,7 +475,7 @@ __global__ __launch_bounds__(256) void k_es_write(const DevScan *__restrict__ sc
 		for (uint32_t i = threadIdx.x; i < 256u * MIJ_ES_BUFPITCH / 16u; i += 256)
 			reinterpret_cast<uint4 *>(stage)[i] = make_uint4(0, 0, 0, 0);
 	}
-	es_load_tables(huff + sc.tab_off, tabs);
+	es_load_tables(sc, &imgs[sc.img], huff + sc.tab_off, tabs, &loc);
 	const uint32_t i = wk.first + threadIdx.x;
 	if (i >= sc.nsub)
 		return;
@@ -455,7 +483,7 @@ __global__ __launch_bounds__(256) void k_es_write(const DevScan *__restrict__ sc
 	EsState s = es_unpack(start[slot]);
 	EsWriter wr;
 	wr.sc = &sc;
-	wr.im = &imgs[sc.img];
+	wr.loc = &loc;
 	wr.coef = coef;
 	wr.dcdiff = dcdiff + sc.blk_off;
 	wr.l1 = l1 + sc.blk_off;
@@ -479,7 +507,7 @@ __global__ __launch_bounds__(256) void k_es_write(const DevScan *__restrict__ sc
 	wr.mx = m - wr.my * sc.mcu_x;
 	wr.locate(s.c);
 	const uint32_t pe = min((i + 1u) * MIJ_ES_BITS, sc.nbits);
-	es_decode<true>(sc, tabs, streams + sc.stream_off, s, pe, &wr, &anom[wk.scan]);
+	es_decode<true>(sc, loc, tabs, streams + sc.stream_off, s, pe, &wr, &anom[wk.scan]);
 }
 
 /* the rest of every block that began in the previous subsequence: single coefficients into the block that the
@@ -490,6 +518,7 @@ __global__ __launch_bounds__(256) void k_es_tails(const DevScan *__restrict__ sc
 																  uint32_t *__restrict__ scratch)
 {
 	__shared__ DevHuff tabs[8];
+	__shared__ EsLocal loc;
 	__shared__ uint16_t toff[64];
 	const EsWork wk = work[blockIdx.x];
 	const DevScan &sc = scans[wk.scan];
@@ -497,7 +526,7 @@ __global__ __launch_bounds__(256) void k_es_tails(const DevScan *__restrict__ sc
 		const uint32_t P = mij_zigzag_pos[threadIdx.x];
 		toff[threadIdx.x] = (uint16_t)(((P >> 3) << 9) + (P & 7u));
 	}
-	es_load_tables(huff + sc.tab_off, tabs);
+	es_load_tables(sc, &imgs[sc.img], huff + sc.tab_off, tabs, &loc);
 	const uint32_t i = wk.first + threadIdx.x;
 	if (i >= sc.nsub)
 		return;
@@ -507,7 +536,7 @@ __global__ __launch_bounds__(256) void k_es_tails(const DevScan *__restrict__ sc
 		return;
 	EsWriter wr;
 	wr.sc = &sc;
-	wr.im = &imgs[sc.img];
+	wr.loc = &loc;
 	wr.coef = coef;
 	wr.dcdiff = dcdiff + sc.blk_off;
 	wr.l1 = l1 + sc.blk_off;
@@ -529,7 +558,7 @@ __global__ __launch_bounds__(256) void k_es_tails(const DevScan *__restrict__ sc
 	wr.mx = m - wr.my * sc.mcu_x;
 	wr.locate(s.c);
 	/* k_es_write walked the same symbols and reported what there was to report: verdict bits go to a scratch word */
-	es_decode<true>(sc, tabs, streams + sc.stream_off, s, sc.nbits, &wr, scratch + 1);
+	es_decode<true>(sc, loc, tabs, streams + sc.stream_off, s, sc.nbits, &wr, scratch + 1);
 }
 
 /* DC prediction (codec/jpeg.c:323-325), L1 bound and the completion checks; one workgroup per scan */
