@@ -84,7 +84,7 @@ __device__ __forceinline__ EsState es_unpack(uint64_t v)
 struct EsBits {
 	const uint32_t *w;
 	uint64_t win;
-	uint32_t avail, idx;
+	uint32_t avail, idx, nxt; /* nxt: the dword after the window, fetched one refill ahead so that its latency overlaps the symbols in between */
 	__device__ __forceinline__ void start(const uint8_t *__restrict__ stream, uint32_t p)
 	{
 		w = reinterpret_cast<const uint32_t *>(stream);
@@ -92,34 +92,59 @@ struct EsBits {
 		const uint32_t sh = p & 31u;
 		win = (((uint64_t)__builtin_bswap32(w[idx]) << 32) | __builtin_bswap32(w[idx + 1])) << sh;
 		avail = 64u - sh;
-		idx += 2;
+		nxt = w[idx + 2];
+		idx += 3;
 	}
 	__device__ __forceinline__ void take(uint32_t n)
 	{
 		win <<= n;
 		avail -= n;
 		if (avail < 32u) {
-			win |= (uint64_t)__builtin_bswap32(w[idx++]) << (32u - avail);
+			win |= (uint64_t)__builtin_bswap32(nxt) << (32u - avail);
 			avail += 32u;
+			nxt = w[idx++];
 		}
 	}
 };
 
+/* A table as the decode loop wants it in LDS: the reference's two-level fast path (fast[] -> size[], values[],
+ * codec/jpeg.c:201-210) folded into one 16-bit entry per 9-bit prefix, because every LDS round trip is on the
+ * serial chain from one symbol to the next. */
+struct EsTab {
+	uint16_t fast16[512]; /* code length << 8 | symbol; 0xffff = longer than 9 bits (or no such code) */
+	uint8_t values[256];
+	/* lengths 10..17 of stbi__huffman.maxcode / .delta (codec/jpeg.c:21-32), 16-byte aligned: the slow path fetches
+	 * all of them at once instead of walking them one LDS round trip at a time */
+	__attribute__((aligned(16))) uint32_t maxcode[8];
+	__attribute__((aligned(16))) int32_t delta[8];
+};
+
 /* codec/jpeg.c:193-243: returns the symbol and its code length, or -1 */
-__device__ __forceinline__ int es_symbol(const DevHuff &h, uint64_t win, uint32_t &len)
+__device__ __forceinline__ int es_symbol(const EsTab &h, uint64_t win, uint32_t &len)
 {
 	const uint32_t top16 = (uint32_t)(win >> 48);
-	const uint32_t k = h.fast[top16 >> 7];
-	if (k < 255u) {
-		len = h.size[k];
-		return h.values[k];
+	const uint32_t e = h.fast16[top16 >> 7];
+	if (e != 0xffffu) {
+		len = e >> 8;
+		return (int)(e & 255u);
 	}
-	uint32_t l = 10;
-	while (l < 17u && top16 >= h.maxcode[l])
-		++l; /* maxcode[17] = 0xffffffff ends the search in a table that was defined */
+	/* :219-221 "for (k = FAST_BITS+1;; ++k) if (temp < maxcode[k]) break": maxcode never decreases with the length
+	 * (each is (code + count) << 1 of the one before, left-aligned), so the first length that holds the prefix is
+	 * 10 + the number of shorter limits at or below it; maxcode[17] = 0xffffffff ends the count in a defined table */
+	const uint4 m0 = *reinterpret_cast<const uint4 *>(&h.maxcode[0]), m1 = *reinterpret_cast<const uint4 *>(&h.maxcode[4]);
+	const uint4 d0 = *reinterpret_cast<const uint4 *>(&h.delta[0]), d1 = *reinterpret_cast<const uint4 *>(&h.delta[4]);
+	const uint32_t ge[7] = {top16 >= m0.x, top16 >= m0.y, top16 >= m0.z, top16 >= m0.w, top16 >= m1.x, top16 >= m1.y, top16 >= m1.z};
+	const uint32_t l = 10u + ge[0] + ge[1] + ge[2] + ge[3] + ge[4] + ge[5] + ge[6];
 	if (l >= 17u)
 		return -1;
-	const int c = (int)((top16 >> (16u - l)) & ((1u << l) - 1u)) + h.delta[l];
+	uint32_t dl = d0.x;
+	dl = l == 11u ? d0.y : dl;
+	dl = l == 12u ? d0.z : dl;
+	dl = l == 13u ? d0.w : dl;
+	dl = l == 14u ? d1.x : dl;
+	dl = l == 15u ? d1.y : dl;
+	dl = l == 16u ? d1.z : dl;
+	const int c = (int)((top16 >> (16u - l)) & ((1u << l) - 1u)) + (int)dl;
 	if (c < 0 || c > 255)
 		return -1;
 	len = l;
@@ -220,13 +245,14 @@ struct EsWriter { /* where the blocks of the write pass go */
  * decoding stops at block ordinal sc.nblocks, malformed input sets *anom.
  */
 template <bool WRITE>
-__device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &loc, const DevHuff *__restrict__ tabs, const uint8_t *__restrict__ stream, EsState &s,
+__device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &loc, const EsTab *__restrict__ tabs, const uint8_t *__restrict__ stream, EsState &s,
 															 uint32_t p_end, EsWriter *wr, uint32_t *anom)
 {
 	uint32_t done = 0, guard = 0;
 	const uint32_t limit = sc.nbits + 64u; /* the arena is zero padded: never read far past the data */
 	EsBits br;
 	br.start(stream, s.p);
+	uint32_t tb = loc.tabs[s.c]; /* the current block's component and tables; changes with s.c only */
 	while (s.p < p_end && s.z != MIJ_ES_DEAD) {
 		if (++guard > MIJ_ES_BITS + 64u) { /* every symbol takes at least one bit: cannot happen, but a wave must always end */
 			s.z = MIJ_ES_DEAD;
@@ -235,7 +261,7 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &
 		if (WRITE && wr->ord >= sc.nblocks)
 			break;
 		const uint64_t win = br.win;
-		const uint32_t tb = loc.tabs[s.c], ci = tb & 255u;
+		const uint32_t ci = tb & 255u;
 		uint32_t len = 0;
 		if (s.z == 0) {
 			const int t = es_symbol(tabs[(tb >> 8) & 255u], win, len);
@@ -332,6 +358,7 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &
 					}
 				}
 			}
+			tb = loc.tabs[s.c];
 			if (WRITE && wr->ord < sc.nblocks)
 				wr->locate(s.c);
 		}
@@ -354,12 +381,20 @@ struct EsWork {
 };
 
 /* the scan's eight Huffman tables and its EsLocal into LDS (im == nullptr: no block placement needed); ends in a barrier */
-__device__ __forceinline__ void es_load_tables(const DevScan &sc, const DevImage *im, const DevHuff *__restrict__ g, DevHuff *l, EsLocal *loc)
+__device__ __forceinline__ void es_load_tables(const DevScan &sc, const DevImage *im, const DevHuff *__restrict__ g, EsTab *l, EsLocal *loc)
 {
-	const uint32_t *src = reinterpret_cast<const uint32_t *>(g);
-	uint32_t *dst = reinterpret_cast<uint32_t *>(l);
-	for (uint32_t i = threadIdx.x; i < 8u * sizeof(DevHuff) / 4u; i += blockDim.x)
-		dst[i] = src[i];
+	for (uint32_t i = threadIdx.x; i < 8u * 512u; i += blockDim.x) {
+		const DevHuff &h = g[i >> 9];
+		const uint32_t k = h.fast[i & 511u]; /* 255 = not in the fast table; entry 255 itself is never fast (:203) */
+		l[i >> 9].fast16[i & 511u] = (uint16_t)(k < 255u ? (uint32_t)h.size[k] << 8 | h.values[k] : 0xffffu);
+	}
+	for (uint32_t i = threadIdx.x; i < 8u * 256u; i += blockDim.x)
+		l[i >> 8].values[i & 255u] = g[i >> 8].values[i & 255u];
+	if (threadIdx.x < 64u) {
+		const uint32_t t = threadIdx.x >> 3, j = threadIdx.x & 7u;
+		l[t].maxcode[j] = g[t].maxcode[10u + j];
+		l[t].delta[j] = g[t].delta[10u + j];
+	}
 	if (threadIdx.x < 12u) {
 		const uint32_t c = threadIdx.x, ci = sc.blk_comp[c] & 3u;
 		loc->tabs[c] = ci | (uint32_t)(sc.dc_tab[ci] & 7u) << 8 | (uint32_t)(sc.ac_tab[ci] & 7u) << 16;
@@ -377,7 +412,7 @@ __device__ __forceinline__ void es_load_tables(const DevScan &sc, const DevImage
 __global__ __launch_bounds__(256) void k_es_cold(const DevScan *__restrict__ scans, const EsWork *__restrict__ work, const DevHuff *__restrict__ huff,
 																 const uint8_t *__restrict__ streams, uint64_t *__restrict__ start, uint64_t *__restrict__ end, uint32_t *__restrict__ cnt)
 {
-	__shared__ DevHuff tabs[8];
+	__shared__ EsTab tabs[8];
 	__shared__ EsLocal loc;
 	const EsWork wk = work[blockIdx.x];
 	const DevScan &sc = scans[wk.scan];
@@ -400,7 +435,7 @@ __global__ __launch_bounds__(256) void k_es_sync(const DevScan *__restrict__ sca
 																 const uint8_t *__restrict__ streams, uint64_t *__restrict__ start, const uint64_t *__restrict__ end_in,
 																 uint64_t *__restrict__ end_out, uint32_t *__restrict__ cnt, uint32_t *__restrict__ changed)
 {
-	__shared__ DevHuff tabs[8];
+	__shared__ EsTab tabs[8];
 	__shared__ EsLocal loc;
 	const EsWork wk = work[blockIdx.x];
 	const DevScan &sc = scans[wk.scan];
@@ -463,7 +498,7 @@ __global__ __launch_bounds__(256) void k_es_write(const DevScan *__restrict__ sc
 																  const uint32_t *__restrict__ base, int16_t *__restrict__ coef, int16_t *__restrict__ dcdiff, uint32_t *__restrict__ l1,
 																  uint32_t *__restrict__ anom, uint32_t *__restrict__ pfinal)
 {
-	__shared__ DevHuff tabs[8];
+	__shared__ EsTab tabs[8];
 	__shared__ EsLocal loc;
 	__shared__ uint8_t zpos[64];
 	__shared__ __attribute__((aligned(16))) uint8_t stage[256 * MIJ_ES_BUFPITCH];
@@ -517,7 +552,7 @@ __global__ __launch_bounds__(256) void k_es_tails(const DevScan *__restrict__ sc
 																  const uint32_t *__restrict__ base, int16_t *__restrict__ coef, int16_t *__restrict__ dcdiff, uint32_t *__restrict__ l1,
 																  uint32_t *__restrict__ scratch)
 {
-	__shared__ DevHuff tabs[8];
+	__shared__ EsTab tabs[8];
 	__shared__ EsLocal loc;
 	__shared__ uint16_t toff[64];
 	const EsWork wk = work[blockIdx.x];
