@@ -13,9 +13,10 @@
  *                    started from last time; the true chain from subsequence 0 wins; stops changing after a
  *                    few rounds because wrong starts re-synchronise inside one subsequence
  *   3. k_es_offsets  prefix sum of the blocks completed per subsequence -> the block ordinal each one starts at
- *   4. k_es_write    decode once more, now knowing where every coefficient goes: each block is staged in LDS in
- *                    tile order and stored whole into the tile-layout planes (mij.h) the IDCT kernels read,
- *                    DC differences aside; k_es_tails adds the rest of blocks that began in the previous subsequence
+ *   4. k_es_write    decode once more, now knowing where every coefficient goes: straight into the (cleared)
+ *                    tile-layout planes (mij.h) the IDCT kernels read, DC differences aside -- or, STAGED, each
+ *                    block through LDS and stored whole (no clearing, but 3 instead of 7 waves per SIMD: slower);
+ *                    k_es_tails adds the rest of blocks that began in the previous subsequence
  *   5. k_es_dc       per component running sum of the DC differences (codec/jpeg.c:323-325), per-block L1
  *                    bound (MIJ_FLAG_WIDE_IDCT), completion checks, the left-over-0xff rule
  * Symbol decoding is the reference's (codec/jpeg.c:193-265: 9-bit fast table, maxcode/delta slow path,
@@ -180,6 +181,7 @@ struct EsWriter { /* where the blocks of the write pass go */
 	int16_t *buf;         /* LDS: the current block in tile order, all zero between blocks; NULL = scatter mode */
 	bool skip;            /* the block in progress was begun by the previous subsequence: k_es_tails stores its rest */
 	bool stop_after_block;
+	bool owner;          /* scatter mode in k_es_write: this thread stores the L1 word of the blocks it begins (k_es_tails adds) */
 	uint32_t ord;        /* ordinal of the current block */
 	uint32_t mx, my;     /* its MCU */
 	int16_t *blk;        /* its tile slot (int16 planes) */
@@ -338,6 +340,9 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &
 						wr->flush();
 						wr->l1[wr->ord] = wr->acc;
 					}
+				} else if (wr->owner) {
+					if (!wr->skip)
+						wr->l1[wr->ord] = wr->acc;
 				} else
 					wr->l1[wr->ord] += wr->acc;
 				wr->acc = 0;
@@ -367,9 +372,10 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &
 			break;
 		}
 	}
-	if (WRITE && wr->buf && wr->ord < sc.nblocks && !wr->skip && s.z != 0 && s.z != MIJ_ES_DEAD) {
+	if (WRITE && (wr->buf || wr->owner) && wr->ord < sc.nblocks && !wr->skip && s.z != 0 && s.z != MIJ_ES_DEAD) {
 		/* a block that continues in the next subsequence: its head goes out now */
-		wr->flush();
+		if (wr->buf)
+			wr->flush();
 		wr->l1[wr->ord] = wr->acc;
 	}
 	return done;
@@ -493,6 +499,9 @@ __global__ __launch_bounds__(256) void k_es_offsets(const DevScan *__restrict__ 
 
 #define MIJ_ES_BUFPITCH 144 /* bytes per thread in the block staging area: 128 + 16 keeps 16-byte accesses of neighbours in different banks */
 
+/* STAGED: blocks go through LDS and are stored whole (planes need no clearing; 3 waves per SIMD).  Otherwise every
+ * coefficient is stored where it belongs in planes the host has cleared (no staging: 5 waves per SIMD). */
+template <bool STAGED>
 __global__ __launch_bounds__(256) void k_es_write(const DevScan *__restrict__ scans, const EsWork *__restrict__ work, const DevHuff *__restrict__ huff,
 																  const uint8_t *__restrict__ streams, const DevImage *__restrict__ imgs, const uint64_t *__restrict__ start,
 																  const uint32_t *__restrict__ base, int16_t *__restrict__ coef, int16_t *__restrict__ dcdiff, uint32_t *__restrict__ l1,
@@ -501,12 +510,16 @@ __global__ __launch_bounds__(256) void k_es_write(const DevScan *__restrict__ sc
 	__shared__ EsTab tabs[8];
 	__shared__ EsLocal loc;
 	__shared__ uint8_t zpos[64];
-	__shared__ __attribute__((aligned(16))) uint8_t stage[256 * MIJ_ES_BUFPITCH];
+	__shared__ uint16_t toff[64];
+	__shared__ __attribute__((aligned(16))) uint8_t stage[STAGED ? 256 * MIJ_ES_BUFPITCH : 16];
 	const EsWork wk = work[blockIdx.x];
 	const DevScan &sc = scans[wk.scan];
-	if (threadIdx.x < 64)
-		zpos[threadIdx.x] = mij_zigzag_pos[threadIdx.x];
-	{
+	if (threadIdx.x < 64) {
+		const uint32_t P = mij_zigzag_pos[threadIdx.x];
+		zpos[threadIdx.x] = (uint8_t)P;
+		toff[threadIdx.x] = (uint16_t)(((P >> 3) << 9) + (P & 7u));
+	}
+	if (STAGED) {
 		for (uint32_t i = threadIdx.x; i < 256u * MIJ_ES_BUFPITCH / 16u; i += 256)
 			reinterpret_cast<uint4 *>(stage)[i] = make_uint4(0, 0, 0, 0);
 	}
@@ -522,9 +535,10 @@ __global__ __launch_bounds__(256) void k_es_write(const DevScan *__restrict__ sc
 	wr.coef = coef;
 	wr.dcdiff = dcdiff + sc.blk_off;
 	wr.l1 = l1 + sc.blk_off;
-	wr.toff = nullptr;
+	wr.toff = STAGED ? nullptr : toff;
 	wr.zpos = zpos;
-	wr.buf = reinterpret_cast<int16_t *>(stage + threadIdx.x * MIJ_ES_BUFPITCH);
+	wr.buf = STAGED ? reinterpret_cast<int16_t *>(stage + threadIdx.x * MIJ_ES_BUFPITCH) : nullptr;
+	wr.owner = !STAGED;
 	wr.skip = s.z != 0; /* begun by the previous subsequence */
 	wr.stop_after_block = false;
 	wr.ord = base[slot];
@@ -578,6 +592,7 @@ __global__ __launch_bounds__(256) void k_es_tails(const DevScan *__restrict__ sc
 	wr.toff = toff;
 	wr.zpos = nullptr;
 	wr.buf = nullptr;
+	wr.owner = false;
 	wr.skip = false;
 	wr.stop_after_block = true;
 	wr.ord = base[slot];

@@ -1039,6 +1039,7 @@ struct EsArena {
 	size_t sub_used, blk_used, work_used, scan_cap, n_tabs;
 	int last_rounds, cur;
 	bool in_flight, coef_bytes_optin;
+	bool scatter; /* write pass without LDS staging, into cleared planes (default; MIJ_ES_SCATTER=0 selects the staged pass for A/B) */
 };
 
 static const int ES_MAX_ROUNDS = 96;
@@ -1120,6 +1121,7 @@ extern "C" int mij_batch_entropy_reserve(mij_batch *b, size_t stream_bytes)
 		return set_err(r == hipErrorOutOfMemory ? MIJ_E_NOMEM : MIJ_E_HIP, "mij_batch_entropy_reserve: %s", hipGetErrorString(r));
 	}
 	e->coef_bytes_optin = getenv("MIJ_COEF_BYTES") != nullptr && atoi(getenv("MIJ_COEF_BYTES")) != 0;
+	e->scatter = !(getenv("MIJ_ES_SCATTER") != nullptr && atoi(getenv("MIJ_ES_SCATTER")) == 0);
 	b->es = e;
 	return MIJ_OK;
 }
@@ -1230,8 +1232,29 @@ static int es_enqueue_tail(mij_batch *b)
 	const dim3 gw((unsigned)e->work_used), gs((unsigned)ns), blk(256);
 	hipLaunchKernelGGL(k_es_offsets, gs, blk, 0, st, e->d_scans, e->d_cnt, e->d_base, v_total);
 	HIP_TRY(hipGetLastError());
-	hipLaunchKernelGGL(k_es_write, gw, blk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, b->d_imgs, e->d_start, e->d_base,
-							 reinterpret_cast<int16_t *>(b->d_coef), e->d_dcdiff, e->d_l1, v_anom, v_pfinal);
+	if (e->scatter) {
+		/* clear the planes of the walked images (neighbours in the arena as one range) */
+		size_t lo = 0, hi = 0;
+		for (const Slot &sl : b->slots) {
+			if (!sl.dev_coef || sl.clone_of >= 0)
+				continue;
+			const size_t a = (size_t)sl.dev.comp[0].coef_off, z = a + sl.coef_bytes;
+			if (a == hi && hi > lo) {
+				hi = z;
+				continue;
+			}
+			if (hi > lo)
+				HIP_TRY(hipMemsetAsync(b->d_coef + lo, 0, hi - lo, st));
+			lo = a;
+			hi = z;
+		}
+		if (hi > lo)
+			HIP_TRY(hipMemsetAsync(b->d_coef + lo, 0, hi - lo, st));
+		hipLaunchKernelGGL(k_es_write<false>, gw, blk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, b->d_imgs, e->d_start, e->d_base,
+								 reinterpret_cast<int16_t *>(b->d_coef), e->d_dcdiff, e->d_l1, v_anom, v_pfinal);
+	} else
+		hipLaunchKernelGGL(k_es_write<true>, gw, blk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, b->d_imgs, e->d_start, e->d_base,
+								 reinterpret_cast<int16_t *>(b->d_coef), e->d_dcdiff, e->d_l1, v_anom, v_pfinal);
 	HIP_TRY(hipGetLastError());
 	hipLaunchKernelGGL(k_es_tails, gw, blk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, b->d_imgs, e->d_start, e->d_base,
 							 reinterpret_cast<int16_t *>(b->d_coef), e->d_dcdiff, e->d_l1, e->d_rounds_changed);
