@@ -9,7 +9,7 @@
 set -u
 TAG=${1:-r01}
 shift || true
-ARGS=${@:---images 1024 --steps 20 --warmup 3 --no-cpu-baseline --no-e2e}
+ARGS=${@:---images 1024 --steps 30 --warmup 10 --no-cpu-baseline --no-e2e}
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"

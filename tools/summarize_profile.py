@@ -33,7 +33,7 @@ def timed(name):
 rows = [r for r in rows if timed(r["Kernel_Name"])]
 big = max(int(r["Grid_Size_X"]) for r in rows)
 durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows if int(r["Grid_Size_X"]) == big]
-lines += ["## 1. `rocprofv3 --kernel-trace --stats -- python3 bench.py --images 1024 --steps 20 --warmup 3 --no-cpu-baseline --no-e2e`",
+lines += ["## 1. `rocprofv3 --kernel-trace --stats -- python3 bench.py --images 1024 --steps 30 --warmup 10 --no-cpu-baseline --no-e2e`",
           "mij::%s: %d launches of %d threads, avg %.4f ms, min %.4f, max %.4f" % (rows[0]["Kernel_Name"].split("(")[0].replace("void ", "").replace("mij::", ""), len(durs), big, sum(durs) / len(durs) / 1e6, min(durs) / 1e6, max(durs) / 1e6),
           ""]
 # bench.py's own HIP-event figure from the same (profiled) process, for the agreement check
