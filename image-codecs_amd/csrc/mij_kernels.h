@@ -346,19 +346,22 @@ __device__ __forceinline__ void load_block_b8(const uint8_t *__restrict__ plane,
 		h[k] = make_uint2(v.x, v.y);
 	}
 	const uint32_t dc = *reinterpret_cast<const uint16_t *>(dcarr + 2u * (size_t)L);
-#define MIJ_DQ2(dst, src, q, b0, b1)                                                                                                            \
-	"v_mul_i32_i24_sdwa " dst ", sext(" src "), " q " dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:" b0 " src1_sel:WORD_0\n\t"                   \
-	"v_mul_i32_i24_sdwa " dst ", sext(" src "), " q " dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:" b1 " src1_sel:WORD_1\n\t"
+	/* the low halves of the four pairs first, then the high halves: the instruction that preserves a register's
+	 * other half never directly follows the one that wrote it (dst_sel forwarding), and the s_nop covers the first
+	 * reader behind the block */
+#define MIJ_DQLO(dst, src, q, b) "v_mul_i32_i24_sdwa " dst ", sext(" src "), " q " dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:" b " src1_sel:WORD_0\n\t"
+#define MIJ_DQHI(dst, src, q, b) "v_mul_i32_i24_sdwa " dst ", sext(" src "), " q " dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:" b " src1_sel:WORD_1\n\t"
 #pragma unroll
 	for (int k = 0; k < 8; ++k) {
 		uint32_t x, y, z, w;
-		asm(MIJ_DQ2("%0", "%4", "%6", "BYTE_0", "BYTE_1") MIJ_DQ2("%1", "%4", "%7", "BYTE_2", "BYTE_3") MIJ_DQ2("%2", "%5", "%8", "BYTE_0", "BYTE_1")
-				 MIJ_DQ2("%3", "%5", "%9", "BYTE_2", "BYTE_3") "s_nop 0"
+		asm(MIJ_DQLO("%0", "%4", "%6", "BYTE_0") MIJ_DQLO("%1", "%4", "%7", "BYTE_2") MIJ_DQLO("%2", "%5", "%8", "BYTE_0") MIJ_DQLO("%3", "%5", "%9", "BYTE_2")
+				 MIJ_DQHI("%0", "%4", "%6", "BYTE_1") MIJ_DQHI("%1", "%4", "%7", "BYTE_3") MIJ_DQHI("%2", "%5", "%8", "BYTE_1") MIJ_DQHI("%3", "%5", "%9", "BYTE_3") "s_nop 0"
 			 : "=&v"(x), "=&v"(y), "=&v"(z), "=&v"(w)
 			 : "v"(h[k].x), "v"(h[k].y), "s"(dq[4 * k + 0]), "s"(dq[4 * k + 1]), "s"(dq[4 * k + 2]), "s"(dq[4 * k + 3]));
 		c[k] = make_uint4(x, y, z, w);
 	}
-#undef MIJ_DQ2
+#undef MIJ_DQLO
+#undef MIJ_DQHI
 	/* (short)(DC * dequant[0]) into the low half of the (r0, r4) pair of column 0 */
 	asm("v_mul_i32_i24_sdwa %0, sext(%1), %2 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0\n\ts_nop 0"
 		 : "+v"(c[0].x)
