@@ -11,7 +11,11 @@ def _host_planes(ica, data, req):
     return ica.HostDecoder.decode(data, req)
 
 
-def test_gpu_walk_equals_host_walk(ica, oracle, gpu_ctx, golden):
+@pytest.mark.parametrize("write_pass", ["scatter", "staged"])
+def test_gpu_walk_equals_host_walk(ica, oracle, gpu_ctx, golden, monkeypatch, write_pass):
+    """Both write passes: straight into cleared planes (the default) and block-wise through LDS (MIJ_ES_SCATTER=0)."""
+    if write_pass == "staged":
+        monkeypatch.setenv("MIJ_ES_SCATTER", "0")  # read by mij_batch_entropy_reserve
     datas = [ica.synth_jpeg(w, h, i, q) for i, (w, h, q) in enumerate(((64, 48, 90), (16, 16, 50), (200, 120, 90), (33, 17, 75), (640, 480, 90), (1920, 1080, 90),
                                                                         (8, 8, 95), (250, 131, 95), (1, 1, 90), (1024, 768, 30)))]
     rng = np.random.default_rng(3)

@@ -6,7 +6,7 @@ ROUNDS=${ROUNDS:-3}
 for r in $(seq 1 $ROUNDS); do
 	for lib in "$@"; do
 		echo -n "round $r $(basename $lib): "
-		MIJ_LIB=$(realpath $lib) python bench.py --images 1024 --steps 15 --warmup 3 --no-cpu-baseline --no-e2e 2>/dev/null |
+		MIJ_LIB=$(realpath $lib) python bench.py --images 1024 --steps 30 --warmup 10 --no-cpu-baseline --no-e2e 2>/dev/null |
 			python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['roofline']['kernel_ms_per_launch'], d['roofline']['frac'])"
 	done
 done
