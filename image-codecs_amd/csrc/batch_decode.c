@@ -92,7 +92,7 @@ int mjh_decode_batch(mij_batch *b, const uint8_t *const *bufs, const int *lens, 
 			reasons[i] = why;
 			continue;
 		}
-		slots[i] = mij_batch_add(b, &p.descs[i]);
+		slots[i] = mij_batch_add_uncleared(b, &p.descs[i]); /* the worker's mjh_decode_memory clears the planes */
 		if (slots[i] < 0) {
 			int rc = slots[i];
 			free(p.descs);
@@ -258,7 +258,7 @@ mjh_gpu_job *mjh_decode_batch_gpu_begin(mij_batch *b, const uint8_t *const *bufs
 				p->status[i] = 2;
 		}
 		if (p->status[i] != 1) {
-			slots[i] = mij_batch_add(b, &p->descs[i]);
+			slots[i] = mij_batch_add_uncleared(b, &p->descs[i]);
 			j->todo[i] = 1;
 		}
 		if (slots[i] < 0) {

@@ -391,7 +391,7 @@ static void apply_coef_bytes(Slot &s)
 
 /* lazy_stage: a slot of the GPU entropy stage -- its staging planes are only needed if the host walk has to
  * redo it, so they are neither required nor cleared here (mij_batch_fallback_prepare does that) */
-static int add_common(mij_batch *b, const mij_image_desc *d, int clone_of, bool lazy_stage = false)
+static int add_common(mij_batch *b, const mij_image_desc *d, int clone_of, bool lazy_stage = false, bool clear = true)
 {
 	if ((int)b->slots.size() >= b->max_images)
 		return set_err(MIJ_E_NOMEM, "batch is full (%d images)", b->max_images);
@@ -415,7 +415,7 @@ static int add_common(mij_batch *b, const mij_image_desc *d, int clone_of, bool 
 			s.stage_off = MIJ_NO_STAGE;
 		} else {
 			s.stage_off = b->stage_used;
-			if (!lazy_stage)
+			if (!lazy_stage && clear)
 				memset(b->stage + s.stage_off, 0, cbytes);
 			b->stage_used += cbytes;
 		}
@@ -440,6 +440,16 @@ extern "C" int mij_batch_add(mij_batch *b, const mij_image_desc *d)
 	if (rc != MIJ_OK)
 		return rc;
 	return add_common(b, d, -1);
+}
+
+extern "C" int mij_batch_add_uncleared(mij_batch *b, const mij_image_desc *d)
+{
+	if (!b)
+		return set_err(MIJ_E_ARG, "batch is NULL");
+	int rc = check_desc(d);
+	if (rc != MIJ_OK)
+		return rc;
+	return add_common(b, d, -1, false, false);
 }
 
 extern "C" int mij_batch_add_clone(mij_batch *b, int src_slot)

@@ -148,6 +148,9 @@ size_t mij_image_out_bytes(const mij_image_desc *d);  /* n_out*width*height, rou
 
 /* Adds an image; returns its slot (>= 0) or a negative error.  Its staging planes are zeroed. */
 int mij_batch_add(mij_batch *b, const mij_image_desc *d);
+/* The same without the clearing, for a caller that writes every element of the planes itself (mjh_decode_memory
+ * clears them on its own thread: the batch front ends add all images up front, in order, on one thread). */
+int mij_batch_add_uncleared(mij_batch *b, const mij_image_desc *d);
 /* Adds an image that shares descriptor and coefficients with slot src but gets its own device
  * coefficient and output buffers (filled device-to-device at upload).  For benchmarks that need
  * many resident images from a few distinct inputs. */
