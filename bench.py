@@ -198,7 +198,7 @@ def end_to_end(ica, ctx, datas, distinct, n_img, src_hash, cbytes, obytes, args)
     try:
         for eb in ebs:
             eb.close()
-        n_g = 8 * n_e  # this leg is fast: enough chunks for the pipeline to reach its steady state (the images cycle)
+        n_g = max(2048, 4 * n_e)  # this leg is fast: enough chunks for the pipeline to reach its steady state (the images cycle)
         jg = [datas[i % distinct] for i in range(n_g)]
         depth = max(2, int(os.environ.get("MIJ_BENCH_GPU_DEPTH", "4")))  # batches in the ring = walks in flight
         gchunk = max(1, min(int(os.environ.get("MIJ_BENCH_GPU_CHUNK", "128")), n_g // depth))
@@ -273,7 +273,7 @@ def main():
                          "(profiles/r01_clock_probe.txt)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the (untimed-region) end-to-end measurement")
-    ap.add_argument("--e2e-images", type=int, default=256)
+    ap.add_argument("--e2e-images", type=int, default=512)
     args = ap.parse_args()
 
     import torch  # device sync + launcher plumbing only
