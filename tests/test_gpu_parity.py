@@ -271,6 +271,29 @@ def test_batch_front_end_thread_pool(golden, ica, oracle, gpu_ctx):
     b.close()
 
 
+def test_batch_reuse_with_other_images(ica, oracle, gpu_ctx):
+    """A batch that is reset and filled again: the front ends add images without clearing the staging planes
+    (mij_batch_add_uncleared), so every worker must clear its own -- busy pictures first, flat ones of other sizes
+    second, through the host walk and through the GPU-walk front end (whose host-walk slots take the same route)."""
+    rng = np.random.default_rng(11)
+    busy = [ica.stbi_write_jpg_to_memory(rng.integers(0, 256, (96, 128, 3)).astype(np.uint8), 95) for _ in range(6)]
+    flat = [ica.stbi_write_jpg_to_memory(np.full((h, w, 3), 40 + 20 * i, np.uint8), 50) for i, (w, h) in enumerate(((128, 96), (64, 64), (200, 40), (16, 16), (96, 128), (33, 17)))]
+    prog = [helpers.progressive_from_du(*ica.host_transform(rng.integers(0, 256, (64, 80, 3)).astype(np.uint8), 92), 0)]
+    for gpu_entropy in (False, True):
+        b = ica.Batch(gpu_ctx, 8, 16 << 20, 16 << 20, 16 << 20)
+        if gpu_entropy:
+            b.entropy_reserve(4 << 20)
+        for datas in (busy + prog, flat + prog, busy[:3] + flat[:3]):
+            b.reset()
+            ok, slots, reasons = b.decode_jpegs(datas, 3, threads=3, gpu_entropy=gpu_entropy)
+            assert ok == len(datas), reasons
+            b.submit()
+            b.wait()
+            for d, s_ in zip(datas, slots):
+                assert np.array_equal(b.fetch(s_), oracle.load(d, 3)[1]), (gpu_entropy, s_)
+        b.close()
+
+
 def test_batch_api_errors(ica, gpu_ctx):
     d = ica.HostDecoder.probe(ica.synth_jpeg(32, 32, 0), 3)
     b = ica.Batch(gpu_ctx, 1, 1 << 20, 1 << 20, 1 << 20)
