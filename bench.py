@@ -267,10 +267,10 @@ def main():
                     help="untimed launches first: after an idle gap the first ~10 launches run 5-30 %% slower (power management ramp, profiles/r01h trace)")
     ap.add_argument("--images", type=int, default=1024, help="images per GPU (BASELINE configs[1]: 1024)")
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic images cycled to fill the batch")
-    ap.add_argument("--settle-ms", type=float, default=0.0,
-                    help="keep issuing untimed warm-up launches until this much wall time has passed; 0 = exactly --warmup "
-                         "launches.  Measured: no gain -- the kernel is power-limited, a hot chip is ~3 %% slower than a cool one "
-                         "(profiles/r01_clock_probe.txt)")
+    ap.add_argument("--settle-ms", type=float, default=25.0,
+                    help="the untimed warm-up lasts at least this long (more launches than --warmup if need be; the number "
+                         "issued is reported as config.warmup_launches_issued): after an idle gap launch durations take "
+                         "~25 ms to settle (power management), whatever W says.  0 = exactly --warmup launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the (untimed-region) end-to-end measurement")
     ap.add_argument("--e2e-images", type=int, default=512)
