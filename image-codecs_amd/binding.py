@@ -60,9 +60,25 @@ class GpuScan(C.Structure):
 _lib = None
 
 
+def _library_stale():
+    """True when the .so is missing or older than any source it is built from (csrc/, include/)."""
+    if not os.path.exists(LIB_PATH):
+        return True
+    built = os.path.getmtime(LIB_PATH)
+    for d in (os.path.join(_HERE, "csrc"), os.path.join(os.path.dirname(_HERE), "include")):
+        for name in os.listdir(d):
+            if name.endswith((".c", ".h", ".hip")) or name == "Makefile":
+                if os.path.getmtime(os.path.join(d, name)) > built:
+                    return True
+    return False
+
+
 def build_library(force=False):
-    """Compile the HIP/C sources in csrc/ for gfx950 (hipcc cross-compiles without a GPU)."""
-    if force or not os.path.exists(LIB_PATH):
+    """Compile the HIP/C sources in csrc/ for gfx950 (hipcc cross-compiles without a GPU).  Rebuilds when the
+    library is missing or any file under csrc/ or include/ is newer than it (make decides what to recompile)."""
+    if os.environ.get("MIJ_LIB"):
+        return LIB_PATH  # an A/B build chosen by the caller: never rebuilt behind its back
+    if force or _library_stale():
         subprocess.run(["make", "-C", os.path.join(_HERE, "csrc")] + (["-B"] if force else []), check=True)
     return LIB_PATH
 
@@ -104,6 +120,10 @@ def lib():
     L.mij_batch_coef.restype = C.c_void_p
     L.mij_batch_coef.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.mij_batch_set_flags.argtypes = [C.c_void_p, C.c_int, C.c_uint32]
+    L.mij_batch_set_color.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.mij_batch_set_coef_format.argtypes = [C.c_void_p, C.c_int]
+    L.mij_batch_slot_escapes.argtypes = [C.c_void_p, C.c_int]
+    L.mij_batch_slot_coef_bytes.argtypes = [C.c_void_p, C.c_int]
     for name in ("mij_batch_upload", "mij_batch_launch", "mij_batch_submit", "mij_batch_wait", "mij_batch_timer_begin",
                  "mij_batch_timer_end", "mij_batch_image_count"):
         getattr(L, name).argtypes = [C.c_void_p]
@@ -373,9 +393,16 @@ class Batch:
         return list(fb[:cnt.value])
 
     def slot_coef_bytes(self, slot):
-        L = lib()
-        L.mij_batch_slot_coef_bytes.argtypes = [C.c_void_p, C.c_int]
-        return L.mij_batch_slot_coef_bytes(self._h, int(slot))
+        """1 when the slot's coefficients sit in HBM as compact planes (the default), 0 for the int16 tile layout."""
+        return lib().mij_batch_slot_coef_bytes(self._h, int(slot))
+
+    def set_coef_format(self, fmt):
+        """'compact' (default) or 'int16': the format new coefficient planes of this batch get in HBM."""
+        _check(lib().mij_batch_set_coef_format(self._h, {"int16": 0, "compact": 1}[fmt]), "mij_batch_set_coef_format")
+
+    def slot_escapes(self, slot):
+        """Blocks of the slot that hold a coefficient outside -128..127 (compact planes only)."""
+        return _check(lib().mij_batch_slot_escapes(self._h, int(slot)), "mij_batch_slot_escapes")
 
     def entropy_rounds(self):
         L = lib()
@@ -400,6 +427,9 @@ class Batch:
         d2, _ = HostDecoder.decode(data, req_comp, out=self.staging(slot))
         if d2.flags:
             _check(lib().mij_batch_set_flags(self._h, slot, d2.flags), "mij_batch_set_flags")
+        if d2.color != d.color:  # a JFIF / Adobe marker behind SOF changed the colour branch (codec/jpeg.c:2244)
+            _check(lib().mij_batch_set_color(self._h, slot, d2.color), "mij_batch_set_color")
+            d.color = d2.color
         return slot
 
     def decode_jpegs(self, datas, req_comp=0, threads=1, gpu_entropy=False):

@@ -55,6 +55,8 @@ static void *worker(void *arg)
 			if (arena && mjh_decode_memory(p->bufs[i], p->lens[i], p->req_comp, &d, arena, elems, &why)) {
 				if (d.flags)
 					mij_batch_set_flags(p->b, slot, d.flags);
+				if (d.color != p->descs[i].color) /* a JFIF / Adobe marker behind SOF changed the colour branch */
+					mij_batch_set_color(p->b, slot, d.color);
 				++good;
 			} else {
 				mij_batch_set_flags(p->b, slot, MIJ_FLAG_SKIP);

@@ -192,6 +192,14 @@ static unsigned char *load_main(mjh_reader *r, int *x, int *y, int *comp, int re
 	}
 	if (mjh_needs_wide_idct(d))
 		mij_batch_set_flags(b, slot, MIJ_FLAG_WIDE_IDCT);
+	/* is_rgb / CMYK / YCCK are decided once every marker has been seen (codec/jpeg.c:2244): APP0 / APP14 may follow SOF */
+	if (mjh_color_mode(d, desc.n_out) != desc.color) {
+		desc.color = mjh_color_mode(d, desc.n_out);
+		if (mij_batch_set_color(b, slot, desc.color) != MIJ_OK) {
+			free(d);
+			return fail_ptr("gpu decode failed");
+		}
+	}
 
 	/* codec/jpeg.c:2293: n * x * y + 1 bytes */
 	nbytes = (size_t)desc.n_out * (size_t)desc.width * (size_t)desc.height;

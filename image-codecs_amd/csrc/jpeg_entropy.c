@@ -1074,24 +1074,32 @@ int mjh_decode_header(mjh_decoder *d, mjh_reader *r, int mode)
 }
 
 /* codec/jpeg.c:2241-2249 and the colour branches of :2320-2431 */
+/* The colour branch load_jpeg_image takes (codec/jpeg.c:2244, :2320-2431) from what the markers seen SO FAR say.
+ * The reference decides after stbi__decode_jpeg_image has processed every marker up to EOI, and APP0 / APP14 may
+ * follow SOF or sit between scans (:1432-1461 run from any stbi__process_marker call): callers ask again once the
+ * scans are done (or, for the GPU walk, once SOS is reached and EOI is known to follow the data). */
+int mjh_color_mode(const mjh_decoder *d, int n_out)
+{
+	const int is_rgb = d->img_n == 3 && (d->rgb == 3 || (d->app14 == 0 && !d->jfif));
+	if (d->img_n == 1)
+		return MIJ_COLOR_GREY;
+	if (d->img_n == 3)
+		return is_rgb ? MIJ_COLOR_RGB : (n_out >= 3 ? MIJ_COLOR_YCBCR : MIJ_COLOR_GREY);
+	return d->app14 == 0 ? MIJ_COLOR_CMYK : (d->app14 == 2 ? MIJ_COLOR_YCCK : MIJ_COLOR_YCBCRA);
+}
+
 int mjh_describe(const mjh_decoder *d, int req_comp, mij_image_desc *out)
 {
-	int n, is_rgb, i;
+	int n, i;
 	if (req_comp < 0 || req_comp > 4)
 		return 0;
 	memset(out, 0, sizeof(*out));
 	n = req_comp ? req_comp : (d->img_n >= 3 ? 3 : 1);
-	is_rgb = d->img_n == 3 && (d->rgb == 3 || (d->app14 == 0 && !d->jfif));
 	out->width = d->img_x;
 	out->height = d->img_y;
 	out->ncomp = d->img_n;
 	out->n_out = n;
-	if (d->img_n == 1)
-		out->color = MIJ_COLOR_GREY;
-	else if (d->img_n == 3)
-		out->color = is_rgb ? MIJ_COLOR_RGB : (n >= 3 ? MIJ_COLOR_YCBCR : MIJ_COLOR_GREY);
-	else
-		out->color = d->app14 == 0 ? MIJ_COLOR_CMYK : (d->app14 == 2 ? MIJ_COLOR_YCCK : MIJ_COLOR_YCBCRA);
+	out->color = mjh_color_mode(d, n);
 	out->flags = 0;
 	out->h_max = d->h_max;
 	out->v_max = d->v_max;
@@ -1265,6 +1273,7 @@ int mjh_decode_memory(const uint8_t *buf, int len, int req_comp, mij_image_desc 
 		}
 		if (mjh_needs_wide_idct(d))
 			desc->flags |= MIJ_FLAG_WIDE_IDCT;
+		desc->color = mjh_color_mode(d, desc->n_out); /* JFIF / Adobe markers behind SOF count too (codec/jpeg.c:2244) */
 		ok = 1;
 	}
 done:
@@ -1313,6 +1322,7 @@ int mjh_extract_scan(const uint8_t *buf, int len, int req_comp, mjg_scan *scan, 
 	}
 	if (!process_scan_header(d))
 		goto done;
+	scan->desc.color = mjh_color_mode(d, scan->desc.n_out); /* markers between SOF and SOS; EOI must follow the data (below) */
 	if (d->progressive || d->scan_n != d->img_n || (d->img_n != 1 && d->img_n != 3))
 		goto done;
 	for (ci = 0; ci < d->scan_n; ++ci)

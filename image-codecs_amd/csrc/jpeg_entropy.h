@@ -100,6 +100,10 @@ int mjh_decode_header(mjh_decoder *d, mjh_reader *r, int mode);
  * Returns 1, or 0 for "bad req_comp". */
 int mjh_describe(const mjh_decoder *d, int req_comp, mij_image_desc *out);
 
+/* The colour mode (MIJ_COLOR_*) as the markers seen so far decide it: ask again after mjh_decode_scans, because
+ * APP0 / APP14 segments may follow SOF (codec/jpeg.c:2244 is evaluated after the whole file has been parsed). */
+int mjh_color_mode(const mjh_decoder *d, int n_out);
+
 /* Everything after SOF until EOI (codec/jpeg.c:1713-1755): scans are entropy-decoded into
  * d->comp[i].plane (which the caller must have pointed at zero-filled tile-layout planes).
  * For progressive files every block's L1 is computed at the end.  Returns 1 / 0. */

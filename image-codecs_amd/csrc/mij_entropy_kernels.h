@@ -14,8 +14,9 @@
  *                    few rounds because wrong starts re-synchronise inside one subsequence
  *   3. k_es_offsets  prefix sum of the blocks completed per subsequence -> the block ordinal each one starts at
  *   4. k_es_write    decode once more, now knowing where every coefficient goes: straight into the (cleared)
- *                    tile-layout planes (mij.h) the IDCT kernels read, DC differences aside -- or, STAGED, each
- *                    block through LDS and stored whole (no clearing, but 3 instead of 7 waves per SIMD: slower);
+ *                    planes the IDCT kernels read -- compact planes by default (low byte into the tile, and for a
+ *                    value outside -128..127 its escape byte and the block's flag: nothing is handed back for
+ *                    size), int16 tile layout on request -- DC differences aside;
  *                    k_es_tails adds the rest of blocks that began in the previous subsequence
  *   5. k_es_dc       per component running sum of the DC differences (codec/jpeg.c:323-325), per-block L1
  *                    bound (MIJ_FLAG_WIDE_IDCT), completion checks, the left-over-0xff rule
@@ -58,7 +59,7 @@ struct DevScan {
 	uint32_t bpm, mcu_x;
 	uint32_t first_mcu;  /* restart intervals: the MCU this segment starts at (0 without restart markers) */
 	uint32_t last_seg;   /* the segment that ends at EOI */
-	uint32_t fmt;        /* 1: byte-coefficient planes (MIJ_DEV_COEF_BYTES): AC as signed bytes, DC in its own int16 array */
+	uint32_t fmt;        /* 1: compact planes (MIJ_DEV_COEF_BYTES): AC low bytes + escape bytes, DC in its own int16 array */
 	uint8_t blk_comp[12], blk_dx[12], blk_dy[12]; /* block-in-MCU -> component and position inside the MCU */
 	uint8_t dc_tab[4], ac_tab[4];                 /* component -> table index (0..3 DC, 4..7 AC) of this scan's eight tables */
 	uint32_t tab_off;    /* first of the eight DevHuff of this scan */
@@ -167,27 +168,27 @@ struct EsLocal {
 	uint32_t geo[12];   /* h | v << 8 | dx << 16 | dy << 24 (write passes only) */
 	uint32_t bw[12];    /* the component's plane width in blocks */
 	uint64_t plane[12]; /* byte offset of the component's plane in the coefficient arena */
+	uint64_t hi[12];    /* compact planes: byte offset of the component's escape bytes */
 	uint16_t qz[4][64]; /* DevScan.qz */
 };
 
 struct EsWriter { /* where the blocks of the write pass go */
 	const DevScan *sc;
 	const EsLocal *loc;
-	int16_t *coef;       /* coefficient arena (tile layout) */
+	int16_t *coef;       /* coefficient arena */
 	int16_t *dcdiff;     /* per block */
 	uint32_t *l1;        /* per block */
-	const uint16_t *toff; /* zigzag index -> element offset inside the block's tile slot (scatter mode) */
-	const uint8_t *zpos;  /* zigzag index -> position in the block's 64-element tile-order image (staged mode) */
-	int16_t *buf;         /* LDS: the current block in tile order, all zero between blocks; NULL = scatter mode */
+	const uint16_t *toff; /* zigzag index -> element offset inside the block's tile slot */
+	const uint8_t *zpos;  /* zigzag index -> in-block position P (the order of a block's escape bytes) */
 	bool skip;            /* the block in progress was begun by the previous subsequence: k_es_tails stores its rest */
 	bool stop_after_block;
-	bool owner;          /* scatter mode in k_es_write: this thread stores the L1 word of the blocks it begins (k_es_tails adds) */
+	bool owner;          /* k_es_write: this thread stores the L1 word of the blocks it begins (k_es_tails adds) */
 	uint32_t ord;        /* ordinal of the current block */
 	uint32_t mx, my;     /* its MCU */
 	int16_t *blk;        /* its tile slot (int16 planes) */
-	uint8_t *blk8;       /* its tile slot (byte planes) */
+	uint8_t *blk8;       /* its tile slot (compact planes) */
+	uint8_t *hi8;        /* its 64 escape bytes (compact planes) */
 	uint32_t L;          /* its index in the component's block grid */
-	uint32_t *anom8;     /* verdict word: a coefficient that does not fit a byte sends the image back */
 	uint32_t acc;        /* L1 of the AC coefficients written by this thread into it */
 	uint32_t *pfinal;    /* where the bit position after the scan's last block is recorded */
 	__device__ __forceinline__ void locate(uint32_t c)
@@ -198,45 +199,17 @@ struct EsWriter { /* where the blocks of the write pass go */
 		uint8_t *plane = reinterpret_cast<uint8_t *>(coef) + loc->plane[c];
 		blk = reinterpret_cast<int16_t *>(plane) + ((size_t)(L >> 6) << 12) + ((L & 63u) << 3);
 		blk8 = plane + ((size_t)(L >> 6) << 12) + ((L & 63u) << 3);
-	}
-	/* the staged block -> its eight chunks in the tile (complete, zeros included: the planes need no clearing) */
-	__device__ __forceinline__ void flush()
-	{
-		if (MIJ_VARIANT & 64) /* ablation: no staging reads, no stores */
-			return;
-		if (sc->fmt) {
-#pragma unroll
-			for (int c = 0; c < 8; ++c) {
-				uint2 *src = reinterpret_cast<uint2 *>(reinterpret_cast<uint8_t *>(buf) + 8 * c);
-				const uint2 v = *src;
-				*src = make_uint2(0, 0);
-				if (!(MIJ_VARIANT & 32) || v.x == 0x12345678u) /* ablation bit 32: no global stores */
-					*reinterpret_cast<uint2 *>(blk8 + (c << 9)) = v;
-			}
-			return;
-		}
-#pragma unroll
-		for (int c = 0; c < 8; ++c) {
-			uint4 *src = reinterpret_cast<uint4 *>(buf + 8 * c);
-			const uint4 v = *src;
-			*src = make_uint4(0, 0, 0, 0);
-			if (!(MIJ_VARIANT & 32) || v.x == 0x12345678u)
-				__builtin_nontemporal_store((u4v){v.x, v.y, v.z, v.w}, reinterpret_cast<u4v *>(blk + (c << 9)));
-		}
+		hi8 = reinterpret_cast<uint8_t *>(coef) + loc->hi[c] + ((size_t)L << 6);
 	}
 	__device__ __forceinline__ void put(uint32_t k, int v)
 	{
 		if (sc->fmt) {
-			if ((uint32_t)(v + 128) > 255u)
-				atomicOr(anom8, 128u);
-			const uint8_t u = (uint8_t)v; /* two's complement byte */
-			if (buf)
-				reinterpret_cast<uint8_t *>(buf)[zpos[k]] = u;
-			else
-				blk8[toff[k]] = u;
-		} else if (buf)
-			buf[zpos[k]] = (int16_t)v;
-		else
+			blk8[toff[k]] = (uint8_t)v; /* low byte */
+			if ((uint32_t)(v + 128) > 255u) { /* escape: v == sext8(low) + 256 * h (mij_kernels.h, load_block_b8) */
+				hi8[zpos[k]] = (uint8_t)((v + 128) >> 8);
+				blk8[0] = 1; /* the block's flags byte sits in the DC's place; every writer stores the same value */
+			}
+		} else
 			blk[toff[k]] = (int16_t)v;
 	}
 };
@@ -335,12 +308,7 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &
 					atomicOr(anom, 16u); /* the data ran out inside this block: the reference decodes on with zero bits */
 				/* per-block L1 of the AC coefficients without atomics: whoever holds the block's start stores, the
 				 * thread that finishes a block begun elsewhere (k_es_tails, a later launch) adds */
-				if (wr->buf) {
-					if (!wr->skip) {
-						wr->flush();
-						wr->l1[wr->ord] = wr->acc;
-					}
-				} else if (wr->owner) {
+				if (wr->owner) {
 					if (!wr->skip)
 						wr->l1[wr->ord] = wr->acc;
 				} else
@@ -372,12 +340,8 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &
 			break;
 		}
 	}
-	if (WRITE && (wr->buf || wr->owner) && wr->ord < sc.nblocks && !wr->skip && s.z != 0 && s.z != MIJ_ES_DEAD) {
-		/* a block that continues in the next subsequence: its head goes out now */
-		if (wr->buf)
-			wr->flush();
-		wr->l1[wr->ord] = wr->acc;
-	}
+	if (WRITE && wr->owner && wr->ord < sc.nblocks && !wr->skip && s.z != 0 && s.z != MIJ_ES_DEAD)
+		wr->l1[wr->ord] = wr->acc; /* a block that continues in the next subsequence: the L1 of its head */
 	return done;
 }
 
@@ -409,6 +373,7 @@ __device__ __forceinline__ void es_load_tables(const DevScan &sc, const DevImage
 			loc->geo[c] = ((uint32_t)cp.h & 255u) | ((uint32_t)cp.v & 255u) << 8 | (uint32_t)sc.blk_dx[c] << 16 | (uint32_t)sc.blk_dy[c] << 24;
 			loc->bw[c] = (uint32_t)cp.bw;
 			loc->plane[c] = cp.coef_off;
+			loc->hi[c] = cp.hi_off;
 		}
 	}
 	loc->qz[threadIdx.x >> 6][threadIdx.x & 63u] = sc.qz[threadIdx.x >> 6][threadIdx.x & 63u];
@@ -497,11 +462,9 @@ __global__ __launch_bounds__(256) void k_es_offsets(const DevScan *__restrict__ 
 	}
 }
 
-#define MIJ_ES_BUFPITCH 144 /* bytes per thread in the block staging area: 128 + 16 keeps 16-byte accesses of neighbours in different banks */
-
-/* STAGED: blocks go through LDS and are stored whole (planes need no clearing; 3 waves per SIMD).  Otherwise every
- * coefficient is stored where it belongs in planes the host has cleared (no staging: 5 waves per SIMD). */
-template <bool STAGED>
+/* Every coefficient is stored where it belongs in planes cleared beforehand (hipMemsetAsync): no staging, so the
+ * pass runs at the occupancy of the cold pass.  (Round 1 also had a variant that staged each block in LDS and stored
+ * it whole: 37 KiB of LDS per workgroup, 3 waves per SIMD, 5.4 ms against 3.4 ms per 256 images -- removed.) */
 __global__ __launch_bounds__(256) void k_es_write(const DevScan *__restrict__ scans, const EsWork *__restrict__ work, const DevHuff *__restrict__ huff,
 																  const uint8_t *__restrict__ streams, const DevImage *__restrict__ imgs, const uint64_t *__restrict__ start,
 																  const uint32_t *__restrict__ base, int16_t *__restrict__ coef, int16_t *__restrict__ dcdiff, uint32_t *__restrict__ l1,
@@ -511,17 +474,12 @@ __global__ __launch_bounds__(256) void k_es_write(const DevScan *__restrict__ sc
 	__shared__ EsLocal loc;
 	__shared__ uint8_t zpos[64];
 	__shared__ uint16_t toff[64];
-	__shared__ __attribute__((aligned(16))) uint8_t stage[STAGED ? 256 * MIJ_ES_BUFPITCH : 16];
 	const EsWork wk = work[blockIdx.x];
 	const DevScan &sc = scans[wk.scan];
 	if (threadIdx.x < 64) {
 		const uint32_t P = mij_zigzag_pos[threadIdx.x];
 		zpos[threadIdx.x] = (uint8_t)P;
 		toff[threadIdx.x] = (uint16_t)(((P >> 3) << 9) + (P & 7u));
-	}
-	if (STAGED) {
-		for (uint32_t i = threadIdx.x; i < 256u * MIJ_ES_BUFPITCH / 16u; i += 256)
-			reinterpret_cast<uint4 *>(stage)[i] = make_uint4(0, 0, 0, 0);
 	}
 	es_load_tables(sc, &imgs[sc.img], huff + sc.tab_off, tabs, &loc);
 	const uint32_t i = wk.first + threadIdx.x;
@@ -535,16 +493,14 @@ __global__ __launch_bounds__(256) void k_es_write(const DevScan *__restrict__ sc
 	wr.coef = coef;
 	wr.dcdiff = dcdiff + sc.blk_off;
 	wr.l1 = l1 + sc.blk_off;
-	wr.toff = STAGED ? nullptr : toff;
+	wr.toff = toff;
 	wr.zpos = zpos;
-	wr.buf = STAGED ? reinterpret_cast<int16_t *>(stage + threadIdx.x * MIJ_ES_BUFPITCH) : nullptr;
-	wr.owner = !STAGED;
+	wr.owner = true;
 	wr.skip = s.z != 0; /* begun by the previous subsequence */
 	wr.stop_after_block = false;
 	wr.ord = base[slot];
 	wr.acc = 0;
 	wr.pfinal = &pfinal[wk.scan];
-	wr.anom8 = &anom[wk.scan];
 	if (wr.ord >= sc.nblocks)
 		return;
 	const uint32_t ml = wr.ord / sc.bpm, m = sc.first_mcu + ml;
@@ -568,11 +524,13 @@ __global__ __launch_bounds__(256) void k_es_tails(const DevScan *__restrict__ sc
 {
 	__shared__ EsTab tabs[8];
 	__shared__ EsLocal loc;
+	__shared__ uint8_t zpos[64];
 	__shared__ uint16_t toff[64];
 	const EsWork wk = work[blockIdx.x];
 	const DevScan &sc = scans[wk.scan];
 	if (threadIdx.x < 64) {
 		const uint32_t P = mij_zigzag_pos[threadIdx.x];
+		zpos[threadIdx.x] = (uint8_t)P;
 		toff[threadIdx.x] = (uint16_t)(((P >> 3) << 9) + (P & 7u));
 	}
 	es_load_tables(sc, &imgs[sc.img], huff + sc.tab_off, tabs, &loc);
@@ -590,15 +548,13 @@ __global__ __launch_bounds__(256) void k_es_tails(const DevScan *__restrict__ sc
 	wr.dcdiff = dcdiff + sc.blk_off;
 	wr.l1 = l1 + sc.blk_off;
 	wr.toff = toff;
-	wr.zpos = nullptr;
-	wr.buf = nullptr;
+	wr.zpos = zpos;
 	wr.owner = false;
 	wr.skip = false;
 	wr.stop_after_block = true;
 	wr.ord = base[slot];
 	wr.acc = 0;
 	wr.pfinal = scratch; /* never reached: the walk stops at the end of this block */
-	wr.anom8 = scratch + 1;
 	if (wr.ord >= sc.nblocks)
 		return;
 	const uint32_t ml = wr.ord / sc.bpm, m = sc.first_mcu + ml;

@@ -42,15 +42,21 @@ struct DevComp {
 	int32_t hs, vs;       /* h_max / h, v_max / v (integer division, codec/jpeg.c:2273-2274) */
 	uint64_t coef_off;    /* byte offset of the component's tile-layout plane in the coefficient arena */
 	uint64_t plane_off;   /* byte offset of its u8 sample plane in the scratch arena (two-pass path) */
-	uint64_t dc_off;      /* byte-coefficient planes (MIJ_DEV_COEF_BYTES): offset of the int16 DC array, one per block */
+	uint64_t dc_off;      /* compact planes (MIJ_DEV_COEF_BYTES): offset of the int16 DC array, one entry per block */
+	uint64_t hi_off;      /* compact planes: offset of the escape bytes, 64 per block in in-block position order P */
 };
 
-#define MIJ_DEV_COEF_BYTES 0x100 /* DevImage.flags: AC coefficients are signed bytes, DC separate (GPU entropy stage only) */
+/* DevImage.flags: the image's coefficients sit in HBM as COMPACT planes (mij.h, "compact coefficient planes"):
+ * per 64-block tile 4 KiB of low bytes in the chunk order of the int16 tile layout, the DC terms in an int16
+ * array, and for blocks holding a coefficient outside -128..127 ("escaped", bit 0 of the block's byte at
+ * in-block position 0) 64 high bytes h with  coefficient == sext8(low) + 256*h  (mod 2^16). */
+#define MIJ_DEV_COEF_BYTES 0x100
 
 struct DevImage {
 	int32_t width, height, n_out, color;
 	int32_t ncomp, flags, mcu_x, mcu_y;
 	uint64_t out_off; /* byte offset of the pixels in the output arena */
+	uint64_t src16_off; /* k_pack_c8 only: byte offset of the image's int16 tile-layout planes (back to back) in the upload scratch */
 	uint64_t plane_bytes_total;
 	DevComp comp[4];
 	uint32_t dq[4][32]; /* per component: quantisation table as u16 pairs in in-block position order P */
@@ -328,16 +334,34 @@ __device__ __forceinline__ void load_block(const uint8_t *__restrict__ plane, ui
 	}
 }
 
-/* The same block from a byte-coefficient plane (experimental; written by the GPU entropy stage): tiles of 4 KiB,
- * chunk k = column k as eight signed bytes in the row order of the int16 layout, DC (row 0 of column 0) in its own
- * int16 array.  Unpacking and de-quantising are one step: v_mul_i32_i24 with an SDWA byte select (sign-extended)
- * times the 16-bit quantiser, its low half written into one half of the destination -- two instructions per pair,
- * the pair comes out as (short)(coef * dequant) (codec/jpeg.c:325-365).  dq = the component's table in the
- * in-block pair order (wave-uniform).  Half the bytes of the int16 plane. */
-__device__ __forceinline__ void load_block_b8(const uint8_t *__restrict__ plane, const uint8_t *__restrict__ dcarr, uint32_t L, const uint32_t *__restrict__ dq,
-															 uint4 (&c)[8])
+/* where one component's coefficients are, for either format */
+struct CoefView {
+	const uint8_t *plane, *dc, *hi;
+};
+__device__ __forceinline__ CoefView coef_view(const uint8_t *__restrict__ coef, const DevComp &cp)
 {
-	const uint8_t *base = plane + ((size_t)(L >> 6) << 12) + ((size_t)(L & 63u) << 3);
+	CoefView v;
+	v.plane = coef + cp.coef_off;
+	v.dc = coef + cp.dc_off;
+	v.hi = coef + cp.hi_off;
+	return v;
+}
+
+/* The same block from COMPACT planes (the default format in HBM; written by the GPU entropy stage and by
+ * k_pack_c8): tiles of 4 KiB, chunk k = column k as eight low bytes in the row order of the int16 layout, DC
+ * (row 0 of column 0) in its own int16 array, the byte in its place holds the block's flags.  Unpacking and
+ * de-quantising are one step: v_mul_i32_i24 with an SDWA byte select (sign-extended) times the 16-bit quantiser,
+ * its low half written into one half of the destination -- two instructions per pair, the pair comes out as
+ * (short)(coef * dequant) (codec/jpeg.c:325-365).  dq = the component's table in the in-block pair order
+ * (wave-uniform).  Half the bytes of the int16 plane.
+ * Escapes: the reference's coefficients are 16-bit (codec/jpeg.c:250-265: up to 15 magnitude bits), so a block
+ * may hold values a byte cannot.  Such a block has bit 0 of its flags byte set and 64 bytes h[P] at hi + 64*L
+ * with coef == sext8(low) + 256*h (mod 2^16); (short)(coef*q) == (short)(sext8(low)*q) + ((h*q & 255) << 8), so
+ * the fix is, per pair, two SDWA byte multiplies into bytes 1 and 3 of a zeroed register and one v_pk_add_u16.
+ * The branch is wave-uniform (any lane escaped); lanes without escapes add zero. */
+__device__ __forceinline__ void load_block_b8(const CoefView &cv, uint32_t L, const uint32_t *__restrict__ dq, uint4 (&c)[8])
+{
+	const uint8_t *base = cv.plane + ((size_t)(L >> 6) << 12) + ((size_t)(L & 63u) << 3);
 	uint2 h[8];
 #pragma unroll
 	for (int k = 0; k < 8; ++k) {
@@ -345,7 +369,8 @@ __device__ __forceinline__ void load_block_b8(const uint8_t *__restrict__ plane,
 		const u2v v = __builtin_nontemporal_load(reinterpret_cast<const u2v *>(base + (k << 9)));
 		h[k] = make_uint2(v.x, v.y);
 	}
-	const uint32_t dc = *reinterpret_cast<const uint16_t *>(dcarr + 2u * (size_t)L);
+	const uint32_t dc = *reinterpret_cast<const uint16_t *>(cv.dc + 2u * (size_t)L);
+	const bool esc = (h[0].x & 1u) != 0;
 	/* the low halves of the four pairs first, then the high halves: the instruction that preserves a register's
 	 * other half never directly follows the one that wrote it (dst_sel forwarding), and the s_nop covers the first
 	 * reader behind the block */
@@ -362,10 +387,48 @@ __device__ __forceinline__ void load_block_b8(const uint8_t *__restrict__ plane,
 	}
 #undef MIJ_DQLO
 #undef MIJ_DQHI
-	/* (short)(DC * dequant[0]) into the low half of the (r0, r4) pair of column 0 */
+	if (__builtin_amdgcn_ballot_w64(esc) != 0ull) { /* wave-uniform */
+		uint4 e[4] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+		if (esc) {
+			const uint4 *hp = reinterpret_cast<const uint4 *>(cv.hi + ((size_t)L << 6));
+			e[0] = hp[0];
+			e[1] = hp[1];
+			e[2] = hp[2];
+			e[3] = hp[3];
+		}
+		/* byte 1 <- low byte of h_a * q_lo (rest zero), byte 3 <- low byte of h_b * q_hi, then the packed add */
+#define MIJ_EX1(dst, src, q, b) "v_mul_u32_u24_sdwa " dst ", " src ", " q " dst_sel:BYTE_1 dst_unused:UNUSED_PAD src0_sel:" b " src1_sel:WORD_0\n\t"
+#define MIJ_EX3(dst, src, q, b) "v_mul_u32_u24_sdwa " dst ", " src ", " q " dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:" b " src1_sel:WORD_1\n\t"
+#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+			const uint32_t ex = (k & 1) ? e[k >> 1].z : e[k >> 1].x, ey = (k & 1) ? e[k >> 1].w : e[k >> 1].y;
+			uint32_t fx, fy, fz, fw;
+			asm(MIJ_EX1("%0", "%4", "%6", "BYTE_0") MIJ_EX1("%1", "%4", "%7", "BYTE_2") MIJ_EX1("%2", "%5", "%8", "BYTE_0") MIJ_EX1("%3", "%5", "%9", "BYTE_2")
+					 MIJ_EX3("%0", "%4", "%6", "BYTE_1") MIJ_EX3("%1", "%4", "%7", "BYTE_3") MIJ_EX3("%2", "%5", "%8", "BYTE_1") MIJ_EX3("%3", "%5", "%9", "BYTE_3") "s_nop 0"
+				 : "=&v"(fx), "=&v"(fy), "=&v"(fz), "=&v"(fw)
+				 : "v"(ex), "v"(ey), "s"(dq[4 * k + 0]), "s"(dq[4 * k + 1]), "s"(dq[4 * k + 2]), "s"(dq[4 * k + 3]));
+			c[k].x = __builtin_bit_cast(uint32_t, (v2u)(__builtin_bit_cast(v2u, c[k].x) + __builtin_bit_cast(v2u, fx)));
+			c[k].y = __builtin_bit_cast(uint32_t, (v2u)(__builtin_bit_cast(v2u, c[k].y) + __builtin_bit_cast(v2u, fy)));
+			c[k].z = __builtin_bit_cast(uint32_t, (v2u)(__builtin_bit_cast(v2u, c[k].z) + __builtin_bit_cast(v2u, fz)));
+			c[k].w = __builtin_bit_cast(uint32_t, (v2u)(__builtin_bit_cast(v2u, c[k].w) + __builtin_bit_cast(v2u, fw)));
+		}
+#undef MIJ_EX1
+#undef MIJ_EX3
+	}
+	/* (short)(DC * dequant[0]) into the low half of the (r0, r4) pair of column 0 (whose low byte held the flags) */
 	asm("v_mul_i32_i24_sdwa %0, sext(%1), %2 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0\n\ts_nop 0"
 		 : "+v"(c[0].x)
 		 : "v"(dc), "s"(dq[0]));
+}
+
+/* one block in either format: the coefficients of c[] come out de-quantised for B8, quantised otherwise */
+template <bool B8>
+__device__ __forceinline__ void load_block_fmt(const CoefView &cv, uint32_t L, const uint32_t *__restrict__ dq, uint4 (&c)[8])
+{
+	if constexpr (B8)
+		load_block_b8(cv, L, dq, c);
+	else
+		load_block(cv.plane, L, c);
 }
 
 /* ------------------------------------------------------------------ colour (codec/jpeg.c:1976-2018)
@@ -481,7 +544,7 @@ __device__ __forceinline__ int comps_needed(int color, int n, int ncomp)
 
 /* ------------------------------------------------------------------ two-pass path, pass 1 */
 
-template <bool WIDE>
+template <bool WIDE, bool B8 = false>
 __global__ __launch_bounds__(256) void k_idct_planes(const DevImage *__restrict__ imgs, const WorkIdct *__restrict__ work, const uint8_t *__restrict__ coef,
 																	  uint8_t *__restrict__ planes)
 {
@@ -495,9 +558,9 @@ __global__ __launch_bounds__(256) void k_idct_planes(const DevImage *__restrict_
 	IdctK K;
 	K.init();
 	uint4 c[8];
-	load_block(coef + cp.coef_off, L, c);
+	load_block_fmt<B8>(coef_view(coef, cp), L, im.dq[wk.comp], c);
 	uint2 rows[8];
-	idct_block<WIDE>(K, c, im.dq[wk.comp], rows);
+	idct_block<WIDE, B8>(K, c, im.dq[wk.comp], rows);
 	const uint32_t by = L / (uint32_t)cp.bw, bx = L - by * (uint32_t)cp.bw;
 	const size_t w2 = (size_t)cp.bw * 8;
 	uint8_t *dst = planes + cp.plane_off + (size_t)by * 8 * w2 + (size_t)bx * 8;
@@ -506,12 +569,67 @@ __global__ __launch_bounds__(256) void k_idct_planes(const DevImage *__restrict_
 		*reinterpret_cast<uint2 *>(dst + (size_t)i * w2) = rows[i];
 }
 
+/* ------------------------------------------------------------------ int16 planes -> compact planes
+ * Every producer that stages int16 coefficients on the host (the host Huffman walk; the progressive scans, which
+ * read-modify-write their planes, codec/jpeg.c:372-558) uploads them into a scratch buffer and this kernel packs
+ * them into the compact format the decode kernels read (MIJ_DEV_COEF_BYTES above), so an image with coefficients
+ * beyond a byte never leaves the GPU path: its blocks get escape bytes.  One block per lane, whole tiles (the
+ * padding blocks of the last tile are zero in the source and come out as zero).
+ * work.first = first block, work.comp = component. */
+__global__ __launch_bounds__(256) void k_pack_c8(const DevImage *__restrict__ imgs, const WorkIdct *__restrict__ work, const uint8_t *__restrict__ src16,
+																 uint8_t *__restrict__ coef)
+{
+	const WorkIdct wk = work[blockIdx.x];
+	const DevImage &im = imgs[wk.img];
+	const DevComp &cp = im.comp[wk.comp];
+	const uint32_t ntile = ((uint32_t)(cp.bw * cp.bh) + 63u) >> 6;
+	const uint32_t L = wk.first + threadIdx.x;
+	if (L >= ntile * 64u)
+		return;
+	size_t soff = im.src16_off;
+	for (uint32_t k = 0; k < wk.comp; ++k)
+		soff += (size_t)(((uint32_t)(im.comp[k].bw * im.comp[k].bh) + 63u) >> 6) << 13;
+	uint4 c[8];
+	load_block(src16 + soff, L, c);
+	uint32_t lo[16], hi[16], any = 0;
+	const uint32_t bias = 0x00800080u;
+#pragma unroll
+	for (int k = 0; k < 8; ++k) {
+		const uint32_t w[4] = {c[k].x, c[k].y, c[k].z, c[k].w};
+		uint32_t t[4];
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			/* x + 128 per 16-bit half: the high byte is h = (x + 128) >> 8, non-zero exactly when x is outside -128..127 */
+			t[j] = __builtin_bit_cast(uint32_t, (v2u)(__builtin_bit_cast(v2u, w[j]) + __builtin_bit_cast(v2u, bias)));
+			any |= t[j] & ((k == 0 && j == 0) ? 0xff000000u : 0xff00ff00u); /* the DC term has its own array */
+		}
+		lo[2 * k] = __builtin_amdgcn_perm(w[1], w[0], 0x06040200u);
+		lo[2 * k + 1] = __builtin_amdgcn_perm(w[3], w[2], 0x06040200u);
+		hi[2 * k] = __builtin_amdgcn_perm(t[1], t[0], 0x07050301u);
+		hi[2 * k + 1] = __builtin_amdgcn_perm(t[3], t[2], 0x07050301u);
+	}
+	const uint32_t dc = c[0].x & 0xffffu;
+	lo[0] = (lo[0] & 0xffffff00u) | (any ? 1u : 0u); /* flags byte in the DC's place */
+	hi[0] &= 0xffffff00u;
+	uint8_t *dst = coef + cp.coef_off + ((size_t)(L >> 6) << 12) + ((size_t)(L & 63u) << 3);
+#pragma unroll
+	for (int k = 0; k < 8; ++k)
+		*reinterpret_cast<uint2 *>(dst + (k << 9)) = make_uint2(lo[2 * k], lo[2 * k + 1]);
+	*reinterpret_cast<uint16_t *>(coef + cp.dc_off + 2u * (size_t)L) = (uint16_t)dc;
+	if (any) {
+		uint4 *hp = reinterpret_cast<uint4 *>(coef + cp.hi_off + ((size_t)L << 6));
+#pragma unroll
+		for (int k = 0; k < 4; ++k)
+			hp[k] = make_uint4(hi[4 * k], hi[4 * k + 1], hi[4 * k + 2], hi[4 * k + 3]);
+	}
+}
+
 /* ------------------------------------------------------------------ two-pass path, pass 2 */
 
 /* ------------------------------------------------------------------ fused single-component (grey) kernel
  * One block per lane: IDCT, then the 8x8 samples go straight to the pixel buffer, replicated to n_out
  * channels (codec/jpeg.c:2373-2378, :2380-2430: grey -> y | y,255 | y,y,y | y,y,y,255).  No sample plane. */
-template <bool WIDE>
+template <bool WIDE, bool B8 = false>
 __global__ __launch_bounds__(256) void k_fused_grey(const DevImage *__restrict__ imgs, const WorkIdct *__restrict__ work, const uint8_t *__restrict__ coef,
 																	 uint8_t *__restrict__ outbase)
 {
@@ -525,9 +643,9 @@ __global__ __launch_bounds__(256) void k_fused_grey(const DevImage *__restrict__
 	IdctK K;
 	K.init();
 	uint4 c[8];
-	load_block(coef + cp.coef_off, L, c);
+	load_block_fmt<B8>(coef_view(coef, cp), L, im.dq[0], c);
 	uint2 rows[8];
-	idct_block<WIDE>(K, c, im.dq[0], rows);
+	idct_block<WIDE, B8>(K, c, im.dq[0], rows);
 	const int by = (int)(L / (uint32_t)cp.bw), bx = (int)(L - (uint32_t)by * (uint32_t)cp.bw);
 	const int W = im.width, H = im.height, n = im.n_out;
 	const int x0 = 8 * bx, y0 = 8 * by;
@@ -871,10 +989,7 @@ __global__ __launch_bounds__(256) void k_fused420(const DevImage *__restrict__ i
 	uint8_t *const saveCb = saveY + 2 * YP; /* [2][CP] */
 	uint8_t *const saveCr = saveCb + 2 * CP;
 
-	const uint8_t *const coefY = coef + im.comp[0].coef_off;
-	const uint8_t *const coefCb = coef + im.comp[1].coef_off;
-	const uint8_t *const coefCr = coef + im.comp[2].coef_off;
-	const uint8_t *const dcY = coef + im.comp[0].dc_off, *const dcCb = coef + im.comp[1].dc_off, *const dcCr = coef + im.comp[2].dc_off;
+	const CoefView cvY = coef_view(coef, im.comp[0]), cvCb = coef_view(coef, im.comp[1]), cvCr = coef_view(coef, im.comp[2]);
 	uint8_t *const out = outbase + im.out_off;
 	const uint32_t opitch = (uint32_t)W * NOUT;
 
@@ -899,10 +1014,7 @@ __global__ __launch_bounds__(256) void k_fused420(const DevImage *__restrict__ i
 			if (bx < bwC) {
 				uint4 c[8];
 				uint2 rows[8];
-				if (B8)
-					load_block_b8(comp == 1 ? coefCb : coefCr, comp == 1 ? dcCb : dcCr, (uint32_t)(mc * bwC + bx), im.dq[comp], c);
-				else
-					load_block(comp == 1 ? coefCb : coefCr, (uint32_t)(mc * bwC + bx), c);
+				load_block_fmt<B8>(comp == 1 ? cvCb : cvCr, (uint32_t)(mc * bwC + bx), im.dq[comp], c);
 				idct_block<WIDE, B8>(KI, c, im.dq[comp], rows);
 				*reinterpret_cast<uint2 *>((comp == 1 ? dstCb : dstCr) + 8 * bx) = keep ? rows[7] : rows[0];
 			}
@@ -1002,10 +1114,7 @@ __global__ __launch_bounds__(256) void k_fused420(const DevImage *__restrict__ i
 			if (ww < nYw) {
 				const int i = ww * 64 + lane; /* block of the two luma block rows 2m, 2m+1 (contiguous in L) */
 				if (i < 2 * bwY) {
-					if (B8)
-						load_block_b8(coefY, dcY, (uint32_t)(2 * m * bwY + i), im.dq[0], c);
-					else
-						load_block(coefY, (uint32_t)(2 * m * bwY + i), c);
+					load_block_fmt<B8>(cvY, (uint32_t)(2 * m * bwY + i), im.dq[0], c);
 					idct_block<WIDE, B8>(KI, c, im.dq[0], rows);
 					const int by = i >= bwY ? 1 : 0, bx = i - by * bwY;
 					uint8_t *dst = sY + (8 * by) * YP + 8 * bx;
@@ -1017,10 +1126,7 @@ __global__ __launch_bounds__(256) void k_fused420(const DevImage *__restrict__ i
 				const int comp = (ww - nYw) < nCw ? 1 : 2;
 				const int bx = ((ww - nYw) - (comp == 2 ? nCw : 0)) * 64 + lane;
 				if (bx < bwC) {
-					if (B8)
-						load_block_b8(comp == 1 ? coefCb : coefCr, comp == 1 ? dcCb : dcCr, (uint32_t)(m * bwC + bx), im.dq[comp], c);
-					else
-						load_block(comp == 1 ? coefCb : coefCr, (uint32_t)(m * bwC + bx), c);
+					load_block_fmt<B8>(comp == 1 ? cvCb : cvCr, (uint32_t)(m * bwC + bx), im.dq[comp], c);
 					idct_block<WIDE, B8>(KI, c, im.dq[comp], rows);
 					uint8_t *dst = (comp == 1 ? sCb : sCr) + 8 * bx;
 #pragma unroll
@@ -1123,7 +1229,7 @@ __device__ __forceinline__ void fused422_pixel(const uint8_t *yrow, const uint8_
 	store_rgb_px<NOUT>(dst + (size_t)x * NOUT, r, g, b);
 }
 
-template <int NOUT, bool WIDE>
+template <int NOUT, bool WIDE, bool B8 = false>
 __global__ __launch_bounds__(256) void k_fused422(const DevImage *__restrict__ imgs, const WorkBand *__restrict__ work, const uint8_t *__restrict__ coef,
 																  uint8_t *__restrict__ outbase)
 {
@@ -1138,9 +1244,7 @@ __global__ __launch_bounds__(256) void k_fused422(const DevImage *__restrict__ i
 	uint8_t *const sY = lds;
 	uint8_t *const sCb = sY + 8 * YP;
 	uint8_t *const sCr = sCb + 8 * CP;
-	const uint8_t *const coefY = coef + im.comp[0].coef_off;
-	const uint8_t *const coefCb = coef + im.comp[1].coef_off;
-	const uint8_t *const coefCr = coef + im.comp[2].coef_off;
+	const CoefView cvY = coef_view(coef, im.comp[0]), cvCb = coef_view(coef, im.comp[1]), cvCr = coef_view(coef, im.comp[2]);
 	uint8_t *const out = outbase + im.out_off;
 	const uint32_t opitch = (uint32_t)W * NOUT;
 	const int bwY = 2 * mcu_x, bwC = mcu_x;
@@ -1167,8 +1271,8 @@ __global__ __launch_bounds__(256) void k_fused422(const DevImage *__restrict__ i
 			if (ww < nYw) {
 				const int bx = ww * 64 + lane;
 				if (bx < bwY) {
-					load_block(coefY, (uint32_t)(m * bwY + bx), c);
-					idct_block<WIDE>(KI, c, im.dq[0], rows);
+					load_block_fmt<B8>(cvY, (uint32_t)(m * bwY + bx), im.dq[0], c);
+					idct_block<WIDE, B8>(KI, c, im.dq[0], rows);
 					uint8_t *dst = sY + 8 * bx;
 #pragma unroll
 					for (int r = 0; r < 8; ++r)
@@ -1178,8 +1282,8 @@ __global__ __launch_bounds__(256) void k_fused422(const DevImage *__restrict__ i
 				const int comp = (ww - nYw) < nCw ? 1 : 2;
 				const int bx = ((ww - nYw) - (comp == 2 ? nCw : 0)) * 64 + lane;
 				if (bx < bwC) {
-					load_block(comp == 1 ? coefCb : coefCr, (uint32_t)(m * bwC + bx), c);
-					idct_block<WIDE>(KI, c, im.dq[comp], rows);
+					load_block_fmt<B8>(comp == 1 ? cvCb : cvCr, (uint32_t)(m * bwC + bx), im.dq[comp], c);
+					idct_block<WIDE, B8>(KI, c, im.dq[comp], rows);
 					uint8_t *dst = (comp == 1 ? sCb : sCr) + 8 * bx;
 #pragma unroll
 					for (int r = 0; r < 8; ++r)
@@ -1241,7 +1345,7 @@ __global__ __launch_bounds__(256) void k_fused422(const DevImage *__restrict__ i
  * (RGBA) contiguous bytes per lane.  Algorithmic bytes: 384 B read + 64*NOUT written per MCU
  * (9 B/px for RGB: BASELINE config 4's shape).
  */
-template <int NOUT, bool WIDE>
+template <int NOUT, bool WIDE, bool B8 = false>
 __global__ __launch_bounds__(256) void k_fused444(const DevImage *__restrict__ imgs, const WorkIdct *__restrict__ work, const uint8_t *__restrict__ coef,
 																  uint8_t *__restrict__ outbase)
 {
@@ -1258,18 +1362,18 @@ __global__ __launch_bounds__(256) void k_fused444(const DevImage *__restrict__ i
 	uint2 ry[8], rb[8], rr[8];
 	{
 		uint4 c[8];
-		load_block(coef + im.comp[0].coef_off, L, c);
-		idct_block<WIDE>(KI, c, im.dq[0], ry);
+		load_block_fmt<B8>(coef_view(coef, im.comp[0]), L, im.dq[0], c);
+		idct_block<WIDE, B8>(KI, c, im.dq[0], ry);
 	}
 	{
 		uint4 c[8];
-		load_block(coef + im.comp[1].coef_off, L, c);
-		idct_block<WIDE>(KI, c, im.dq[1], rb);
+		load_block_fmt<B8>(coef_view(coef, im.comp[1]), L, im.dq[1], c);
+		idct_block<WIDE, B8>(KI, c, im.dq[1], rb);
 	}
 	{
 		uint4 c[8];
-		load_block(coef + im.comp[2].coef_off, L, c);
-		idct_block<WIDE>(KI, c, im.dq[2], rr);
+		load_block_fmt<B8>(coef_view(coef, im.comp[2]), L, im.dq[2], c);
+		idct_block<WIDE, B8>(KI, c, im.dq[2], rr);
 	}
 	const uint32_t by = L / (uint32_t)bw, bx = L - by * (uint32_t)bw;
 	const int x0 = (int)bx * 8, y0 = (int)by * 8;

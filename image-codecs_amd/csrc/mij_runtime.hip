@@ -86,20 +86,16 @@ extern "C" int mij_ctx_create(int device, mij_ctx **out)
 		return MIJ_E_NODEVICE;
 	}
 	c->max_dyn_lds = 160 * 1024;
-	/* allow the fused kernel to use the whole 160 KiB of LDS for wide images */
-	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused420<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
-	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused420<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
-	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused420<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
-	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused420<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
-	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused420<3, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
-	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused420<3, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
-	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused420<4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
-	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused420<4, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+	/* allow the fused band kernels to use the whole 160 KiB of LDS for wide images */
+#define MIJ_LDS_ATTR(K) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds)
+#define MIJ_LDS_ATTR8(K)                                                                                                           \
+	MIJ_LDS_ATTR((K<3, false, false>)); MIJ_LDS_ATTR((K<3, true, false>)); MIJ_LDS_ATTR((K<4, false, false>)); MIJ_LDS_ATTR((K<4, true, false>)); \
+	MIJ_LDS_ATTR((K<3, false, true>)); MIJ_LDS_ATTR((K<3, true, true>)); MIJ_LDS_ATTR((K<4, false, true>)); MIJ_LDS_ATTR((K<4, true, true>))
+	MIJ_LDS_ATTR8(k_fused420);
+	MIJ_LDS_ATTR8(k_fused422);
+#undef MIJ_LDS_ATTR8
+#undef MIJ_LDS_ATTR
 	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_encode420), hipFuncAttributeMaxDynamicSharedMemorySize, MIJ_ENC_LDS);
-	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused422<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
-	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused422<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
-	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused422<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
-	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused422<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
 	(void)hipGetLastError();
 	*out = c;
 	return MIJ_OK;
@@ -129,12 +125,19 @@ struct Slot {
 	mij_image_desc desc;
 	DevImage dev;
 	size_t stage_off;  /* byte offset in the staging arena (clones: the source's) */
-	size_t coef_bytes; /* bytes of this image's coefficient planes */
+	size_t coef_base;  /* byte offset of this image's region in the coefficient arena */
+	size_t coef_bytes; /* bytes of that region (mij_image_coef_bytes: room for either format) */
 	int clone_of;      /* -1: own staging */
 	int dev_coef;      /* 1: the GPU entropy stage wrote the coefficient planes in HBM; nothing to upload */
 	int es_index;      /* index into the entropy arena's scan list, or -1 */
-	int coef_bytes_fmt; /* 1: byte-coefficient planes (experimental, MIJ_COEF_BYTES=1): AC as signed bytes, DC array aside */
-	int path;          /* 0 none, 1 fused 4:2:0, 2 two-pass, 3 fused 4:4:4 */
+	int coef_bytes_fmt; /* 1: compact planes in HBM (low bytes + escapes + DC array), 0: int16 tile layout */
+	int path;          /* 0 none, 1 fused 4:2:0, 2 two-pass, 3 fused 4:4:4, 4 fused 4:2:2, 5 fused grey */
+};
+
+/* kernel families of a launch plan, in launch order */
+enum { MK_PLANES = 0, MK_RESAMPLE, MK_420, MK_422, MK_444, MK_GREY, MK_KINDS };
+struct Work4 { /* WorkBand and WorkIdct are both four u32 */
+	uint32_t a, b, c, d;
 };
 
 struct mij_batch {
@@ -151,30 +154,20 @@ struct mij_batch {
 	size_t out_cap, out_used;
 	uint8_t *d_planes;
 	size_t planes_cap;
+	uint8_t *d_up16; /* upload scratch: int16 planes on their way into compact planes (k_pack_c8), stage_cap bytes */
 	/* descriptors + work lists (pinned host mirror + device copy) */
 	DevImage *h_imgs, *d_imgs;
-	WorkBand *h_bands, *d_bands;
-	size_t bands_cap;
-	WorkIdct *h_idct, *d_idct;
-	size_t idct_cap;
+	Work4 *h_work, *d_work;
+	size_t work_cap;
 	std::vector<Slot> slots;
 	/* launch plan built by upload */
-	struct BandLaunch {
-		int nout, wide;
-		bool b8;
-		size_t first, count;
-		size_t lds;
-	};
-	std::vector<BandLaunch> band_launches;
-	struct IdctLaunch {
-		int kind; /* 0 two-pass pass 1, 1 fused 4:4:4, 2 two-pass pass 2, 3 fused 4:2:2, 4 fused grey */
-		int nout;
-		int wide;
+	struct Launch {
+		int kind, nout, wide, b8;
 		size_t first, count, lds;
 	};
-	std::vector<IdctLaunch> idct_launches;
-	std::vector<int> twopass_slots;
+	std::vector<Launch> launches;
 	bool uploaded, launched, force_generic;
+	int coef_fmt;  /* format new coefficient planes get in HBM: 1 compact (default), 0 int16 (MIJ_COEF_FORMAT=int16, mij_batch_set_coef_format) */
 	int band_rows; /* MCU rows per fused workgroup; 0 = automatic */
 	struct EsArena *es; /* GPU entropy stage, allocated by mij_batch_entropy_reserve */
 };
@@ -183,11 +176,15 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 static void es_free_fwd(struct EsArena *e);
 static void es_reset_fwd(struct EsArena *e);
 
+static inline size_t comp_tiles(const mij_comp_desc &cp) { return ((size_t)(cp.bw * cp.bh) + 63) >> 6; }
+
+/* room for either format: int16 tile layout needs 8192 B per 64-block tile, compact planes 4096 (low bytes) + 128 (DC)
+ * + 4096 (escape bytes) = MIJ_TILE_COMPACT_BYTES */
 extern "C" size_t mij_image_coef_bytes(const mij_image_desc *d)
 {
 	size_t total = 0;
 	for (int c = 0; c < d->ncomp; ++c)
-		total += mij_plane_elems((uint32_t)(d->comp[c].bw * d->comp[c].bh)) * sizeof(int16_t);
+		total += comp_tiles(d->comp[c]) * MIJ_TILE_COMPACT_BYTES;
 	return total;
 }
 
@@ -207,16 +204,20 @@ extern "C" int mij_batch_create(mij_ctx *ctx, int max_images, size_t stage_bytes
 	b->stage = nullptr;
 	b->d_coef = b->d_out = b->d_planes = nullptr;
 	b->h_imgs = b->d_imgs = nullptr;
-	b->h_bands = b->d_bands = nullptr;
-	b->h_idct = b->d_idct = nullptr;
+	b->h_work = b->d_work = nullptr;
+	b->d_up16 = nullptr;
 	b->stage_cap = stage_bytes;
 	b->coef_cap = coef_bytes;
 	b->out_cap = out_bytes;
 	b->stage_used = b->coef_used = b->out_used = 0;
 	b->planes_cap = 0;
-	b->bands_cap = b->idct_cap = 0;
+	b->work_cap = 0;
 	b->uploaded = b->launched = b->force_generic = false;
 	b->band_rows = 0;
+	{
+		const char *fmt = getenv("MIJ_COEF_FORMAT");
+		b->coef_fmt = (fmt && (!strcmp(fmt, "int16") || !strcmp(fmt, "0"))) ? 0 : 1;
+	}
 	b->es = nullptr;
 	b->stream = nullptr;
 	b->ev_begin = b->ev_end = nullptr;
@@ -269,14 +270,12 @@ extern "C" void mij_batch_destroy(mij_batch *b)
 		(void)hipHostFree(b->h_imgs);
 	if (b->d_imgs)
 		(void)hipFree(b->d_imgs);
-	if (b->h_bands)
-		(void)hipHostFree(b->h_bands);
-	if (b->d_bands)
-		(void)hipFree(b->d_bands);
-	if (b->h_idct)
-		(void)hipHostFree(b->h_idct);
-	if (b->d_idct)
-		(void)hipFree(b->d_idct);
+	if (b->h_work)
+		(void)hipHostFree(b->h_work);
+	if (b->d_work)
+		(void)hipFree(b->d_work);
+	if (b->d_up16)
+		(void)hipFree(b->d_up16);
 	if (b->es)
 		es_free_fwd(b->es);
 	if (b->ev_begin)
@@ -297,9 +296,7 @@ extern "C" int mij_batch_reset(mij_batch *b)
 	b->slots.clear();
 	b->stage_used = b->coef_used = b->out_used = 0;
 	b->uploaded = b->launched = false;
-	b->band_launches.clear();
-	b->idct_launches.clear();
-	b->twopass_slots.clear();
+	b->launches.clear();
 	es_reset_fwd(b->es);
 	return MIJ_OK;
 }
@@ -333,10 +330,36 @@ static int check_desc(const mij_image_desc *d)
 		if (cp.x <= 0 || cp.y <= 0 || cp.x > cp.bw * 8 || cp.y > cp.bh * 8)
 			return set_err(MIJ_E_ARG, "component %d effective size out of range", c);
 	}
+	/* the MCU grid covers the picture (codec/jpeg.c:1618-1622): the kernels address pixels from MCU coordinates */
+	if ((int64_t)d->width > (int64_t)d->mcu_x * 8 * d->h_max || (int64_t)d->height > (int64_t)d->mcu_y * 8 * d->v_max)
+		return set_err(MIJ_E_ARG, "image larger than its MCU grid");
 	return MIJ_OK;
 }
 
-static void fill_dev_image(Slot &s, size_t coef_off, size_t out_off)
+/* where the component planes of a slot lie inside its region of the coefficient arena, for its format */
+static void layout_coef(Slot &s)
+{
+	size_t off = s.coef_base;
+	if (s.coef_bytes_fmt)
+		s.dev.flags |= MIJ_DEV_COEF_BYTES;
+	else
+		s.dev.flags &= ~(int32_t)MIJ_DEV_COEF_BYTES;
+	for (int c = 0; c < s.desc.ncomp; ++c) {
+		const size_t nt = comp_tiles(s.desc.comp[c]);
+		DevComp &dc = s.dev.comp[c];
+		dc.coef_off = off;
+		if (s.coef_bytes_fmt) {
+			dc.dc_off = off + (nt << 12);
+			dc.hi_off = off + (nt << 12) + (nt << 7);
+			off += nt * MIJ_TILE_COMPACT_BYTES;
+		} else {
+			dc.dc_off = dc.hi_off = 0;
+			off += nt << 13;
+		}
+	}
+}
+
+static void fill_dev_image(Slot &s, size_t out_off)
 {
 	const mij_image_desc &d = s.desc;
 	DevImage &v = s.dev;
@@ -362,8 +385,6 @@ static void fill_dev_image(Slot &s, size_t coef_off, size_t out_off)
 		dc.bh = cp.bh;
 		dc.hs = d.h_max / cp.h;
 		dc.vs = d.v_max / cp.v;
-		dc.coef_off = coef_off;
-		coef_off += mij_plane_elems((uint32_t)(cp.bw * cp.bh)) * sizeof(int16_t);
 		dc.plane_off = plane_off; /* relative; rebased at launch */
 		plane_off += align_up((size_t)cp.bw * 8 * cp.bh * 8, 256);
 		/* quantisation table, natural order -> in-block position order P = 8*col + rowslot[row] */
@@ -378,16 +399,6 @@ static void fill_dev_image(Slot &s, size_t coef_off, size_t out_off)
 }
 
 #define MIJ_NO_STAGE ((size_t)-1)
-
-/* byte-coefficient planes: flag and DC arrays (behind each component's 4 KiB tiles, inside the same plane region) */
-static void apply_coef_bytes(Slot &s)
-{
-	s.dev.flags |= MIJ_DEV_COEF_BYTES;
-	for (int c = 0; c < s.desc.ncomp; ++c) {
-		const size_t ntile = ((size_t)(s.desc.comp[c].bw * s.desc.comp[c].bh) + 63) >> 6;
-		s.dev.comp[c].dc_off = s.dev.comp[c].coef_off + (ntile << 12);
-	}
-}
 
 /* lazy_stage: a slot of the GPU entropy stage -- its staging planes are only needed if the host walk has to
  * redo it, so they are neither required nor cleared here (mij_batch_fallback_prepare does that) */
@@ -422,9 +433,9 @@ static int add_common(mij_batch *b, const mij_image_desc *d, int clone_of, bool 
 	} else {
 		s.stage_off = b->slots[(size_t)clone_of].stage_off;
 	}
-	fill_dev_image(s, b->coef_used, b->out_used);
-	if (s.coef_bytes_fmt)
-		apply_coef_bytes(s); /* a clone of a byte-plane slot */
+	s.coef_base = b->coef_used;
+	fill_dev_image(s, b->out_used);
+	layout_coef(s); /* host-staged slots: int16 until upload decides; clones: their source's format */
 	b->coef_used += cbytes;
 	b->out_used += obytes;
 	b->slots.push_back(s);
@@ -484,6 +495,22 @@ extern "C" int mij_batch_set_flags(mij_batch *b, int slot, uint32_t flags)
 		return set_err(MIJ_E_ARG, "bad slot");
 	b->slots[(size_t)slot].desc.flags = flags;
 	b->slots[(size_t)slot].dev.flags = (int32_t)flags | (b->slots[(size_t)slot].coef_bytes_fmt ? MIJ_DEV_COEF_BYTES : 0);
+	b->uploaded = b->launched = false;
+	return MIJ_OK;
+}
+
+extern "C" int mij_batch_set_color(mij_batch *b, int slot, int color)
+{
+	if (!b || slot < 0 || slot >= (int)b->slots.size())
+		return set_err(MIJ_E_ARG, "bad slot");
+	Slot &s = b->slots[(size_t)slot];
+	mij_image_desc d = s.desc;
+	d.color = color;
+	int rc = check_desc(&d);
+	if (rc != MIJ_OK)
+		return rc;
+	s.desc.color = color;
+	s.dev.color = color;
 	b->uploaded = b->launched = false;
 	return MIJ_OK;
 }
@@ -600,6 +627,8 @@ static int grow_pair(T *&h, T *&d, size_t &cap, size_t need)
 	return MIJ_OK;
 }
 
+static size_t fused420_lds(const mij_image_desc &d) { return (size_t)d.mcu_x * (16 * 16 + 2 * 8 * 8 + 2 * 16 + 4 * 8); }
+
 extern "C" int mij_batch_upload(mij_batch *b)
 {
 	if (!b)
@@ -609,14 +638,31 @@ extern "C" int mij_batch_upload(mij_batch *b)
 	if (n == 0)
 		return set_err(MIJ_E_STATE, "batch is empty");
 
-	/* ---- plan: group fused images by (n_out, wide); everything else goes two-pass */
-	std::vector<WorkBand> bands[8]; /* (n_out 3/4) x (narrow, wide) x (int16, byte planes) */
-	std::vector<WorkIdct> idct[13]; /* 0,1: two-pass (narrow, wide); 2..5: fused 4:4:4 (n_out 3/4 x narrow/wide); 6: two-pass pass 2 (row groups);
-	                                  7..10: fused 4:2:2 bands (n_out 3/4 x narrow/wide; comp = first MCU row, first = end MCU row);
-	                                  11,12: fused grey (narrow, wide) */
-	size_t lds422[4] = {0, 0, 0, 0};
-	size_t band_lds[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-	b->twopass_slots.clear();
+	/* ---- format of the planes in HBM.  Slots the GPU entropy stage wrote keep theirs; host-staged slots get the
+	 * batch's format (compact by default: uploaded as int16 into the scratch, packed by k_pack_c8); clones follow
+	 * their source (which precedes them). */
+	bool need_pack = false;
+	for (size_t i = 0; i < n; ++i) {
+		Slot &s = b->slots[i];
+		if (s.clone_of >= 0)
+			s.coef_bytes_fmt = b->slots[(size_t)s.clone_of].coef_bytes_fmt;
+		else if (!s.dev_coef)
+			s.coef_bytes_fmt = (b->coef_fmt && !(s.desc.flags & MIJ_FLAG_SKIP)) ? 1 : 0;
+		layout_coef(s);
+		if (s.clone_of < 0 && !s.dev_coef && s.coef_bytes_fmt)
+			need_pack = true;
+	}
+	if (need_pack && !b->d_up16) {
+		hipError_t e = hipMalloc(reinterpret_cast<void **>(&b->d_up16), b->stage_cap ? b->stage_cap : 16);
+		if (e != hipSuccess)
+			return set_err(e == hipErrorOutOfMemory ? MIJ_E_NOMEM : MIJ_E_HIP, "upload scratch: %s", hipGetErrorString(e));
+	}
+
+	/* ---- plan: one work list per (kernel family, n_out, wide IDCT, plane format) */
+	std::vector<Work4> lists[MK_KINDS][2][2][2];
+	size_t lds_need[MK_KINDS][2][2][2];
+	memset(lds_need, 0, sizeof(lds_need));
+	std::vector<Work4> pack;
 	size_t planes_need = 0, planes_off = 0;
 	const int cu = b->ctx->prop.multiProcessorCount > 0 ? b->ctx->prop.multiProcessorCount : 256;
 	/* Automatic band count per image.  The grid runs in "rounds" of (CUs x workgroups per CU by LDS)
@@ -630,9 +676,8 @@ extern "C" int mij_batch_upload(mij_batch *b)
 			const mij_image_desc &d = b->slots[i].desc;
 			++n_fused;
 			mcu_rows_sum += (size_t)d.mcu_y;
-			size_t lds = (size_t)d.mcu_x * (16 * 16 + 2 * 8 * 8 + 2 * 16 + 4 * 8);
-			if (lds > lds_max)
-				lds_max = lds;
+			if (fused420_lds(d) > lds_max)
+				lds_max = fused420_lds(d);
 		}
 	int auto_nb = 1;
 	if (n_fused) {
@@ -655,92 +700,52 @@ extern "C" int mij_batch_upload(mij_batch *b)
 	for (size_t i = 0; i < n; ++i) {
 		Slot &s = b->slots[i];
 		const mij_image_desc &d = s.desc;
-		const int wide = (d.flags & MIJ_FLAG_WIDE_IDCT) ? 1 : 0;
+		const int wide = (d.flags & MIJ_FLAG_WIDE_IDCT) ? 1 : 0, b8 = s.coef_bytes_fmt ? 1 : 0, o4 = d.n_out == 4 ? 1 : 0;
 		if (d.flags & MIJ_FLAG_SKIP) { /* rejected by the host stage after it got a slot */
 			s.path = 0;
 			continue;
 		}
+		if (s.clone_of < 0 && !s.dev_coef && b8) /* int16 planes in the scratch -> compact planes */
+			for (int c = 0; c < d.ncomp; ++c)
+				for (uint32_t f = 0, nb = (uint32_t)comp_tiles(d.comp[c]) * 64u; f < nb; f += 256)
+					pack.push_back(Work4{(uint32_t)i, (uint32_t)c, f, 0u});
+		auto per_blocks = [&](std::vector<Work4> &L, int comp) {
+			const uint32_t nblk = (uint32_t)(d.comp[comp].bw * d.comp[comp].bh);
+			for (uint32_t f = 0; f < nblk; f += 256)
+				L.push_back(Work4{(uint32_t)i, (uint32_t)comp, f, 0u});
+		};
 		if (fused420_ok(b, d)) {
 			s.path = 1;
-			const int g = (d.n_out == 4 ? 2 : 0) + wide + (s.coef_bytes_fmt ? 4 : 0);
 			/* split mcu_y into nb equal-ish bands */
 			int nb = b->band_rows > 0 ? (d.mcu_y + b->band_rows - 1) / b->band_rows : auto_nb;
 			if (nb > d.mcu_y)
 				nb = d.mcu_y;
 			if (nb < 1)
 				nb = 1;
-			for (int k = 0; k < nb; ++k) {
-				WorkBand w;
-				w.img = (uint32_t)i;
-				w.m0 = (uint32_t)((long)d.mcu_y * k / nb);
-				w.m1 = (uint32_t)((long)d.mcu_y * (k + 1) / nb);
-				w.pad = 0;
-				bands[g].push_back(w);
-			}
-			size_t lds = (size_t)d.mcu_x * (16 * 16 + 2 * 8 * 8 + 2 * 16 + 4 * 8);
-			if (lds > band_lds[g])
-				band_lds[g] = lds;
+			for (int k = 0; k < nb; ++k)
+				lists[MK_420][o4][wide][b8].push_back(Work4{(uint32_t)i, (uint32_t)((long)d.mcu_y * k / nb), (uint32_t)((long)d.mcu_y * (k + 1) / nb), 0u});
+			size_t &l = lds_need[MK_420][o4][wide][b8];
+			l = fused420_lds(d) > l ? fused420_lds(d) : l;
 		} else if (fused_grey_ok(b, d)) {
 			s.path = 5;
-			const uint32_t nblk = (uint32_t)(d.comp[0].bw * d.comp[0].bh);
-			for (uint32_t f = 0; f < nblk; f += 256) {
-				WorkIdct w;
-				w.img = (uint32_t)i;
-				w.comp = 0;
-				w.first = f;
-				w.pad = 0;
-				idct[11 + wide].push_back(w);
-			}
+			per_blocks(lists[MK_GREY][0][wide][b8], 0);
 		} else if (fused422_ok(b, d)) {
 			s.path = 4;
-			const int g = (d.n_out == 4 ? 2 : 0) + wide;
-			const size_t lds = (size_t)d.mcu_x * 256 + 16;
-			if (lds > lds422[g])
-				lds422[g] = lds;
+			size_t &l = lds_need[MK_422][o4][wide][b8];
+			l = (size_t)d.mcu_x * 256 + 16 > l ? (size_t)d.mcu_x * 256 + 16 : l;
 			/* no halo: bands of about eight MCU rows keep the grid deep without making workgroups short */
 			const int nb = (d.mcu_y + 7) / 8;
-			for (int k = 0; k < nb; ++k) {
-				WorkIdct w;
-				w.img = (uint32_t)i;
-				w.comp = (uint32_t)((long)d.mcu_y * k / nb);
-				w.first = (uint32_t)((long)d.mcu_y * (k + 1) / nb);
-				w.pad = 0;
-				idct[7 + g].push_back(w);
-			}
+			for (int k = 0; k < nb; ++k)
+				lists[MK_422][o4][wide][b8].push_back(Work4{(uint32_t)i, (uint32_t)((long)d.mcu_y * k / nb), (uint32_t)((long)d.mcu_y * (k + 1) / nb), 0u});
 		} else if (fused444_ok(b, d)) {
 			s.path = 3;
-			const int g = 2 + (d.n_out == 4 ? 2 : 0) + wide;
-			const uint32_t nblk = (uint32_t)(d.comp[0].bw * d.comp[0].bh);
-			for (uint32_t f = 0; f < nblk; f += 256) {
-				WorkIdct w;
-				w.img = (uint32_t)i;
-				w.comp = 0;
-				w.first = f;
-				w.pad = 0;
-				idct[g].push_back(w);
-			}
+			per_blocks(lists[MK_444][o4][wide][b8], 0);
 		} else {
 			s.path = 2;
-			b->twopass_slots.push_back((int)i);
-			for (uint32_t r = 0; r < (uint32_t)d.height; r += MIJ_RESAMPLE_ROWS) {
-				WorkIdct w;
-				w.img = (uint32_t)i;
-				w.comp = 0;
-				w.first = r;
-				w.pad = 0;
-				idct[6].push_back(w);
-			}
-			for (int c = 0; c < d.ncomp; ++c) {
-				const uint32_t nblk = (uint32_t)(d.comp[c].bw * d.comp[c].bh);
-				for (uint32_t f = 0; f < nblk; f += 256) {
-					WorkIdct w;
-					w.img = (uint32_t)i;
-					w.comp = (uint32_t)c;
-					w.first = f;
-					w.pad = 0;
-					idct[wide].push_back(w);
-				}
-			}
+			for (uint32_t r = 0; r < (uint32_t)d.height; r += MIJ_RESAMPLE_ROWS)
+				lists[MK_RESAMPLE][0][0][0].push_back(Work4{(uint32_t)i, 0u, r, 0u});
+			for (int c = 0; c < d.ncomp; ++c)
+				per_blocks(lists[MK_PLANES][0][wide][b8], c);
 			/* rebase this image's sample planes into the scratch arena */
 			size_t rel0 = 0;
 			for (int c = 0; c < d.ncomp; ++c) {
@@ -750,6 +755,7 @@ extern "C" int mij_batch_upload(mij_batch *b)
 			planes_off += rel0;
 			planes_need = planes_off;
 		}
+		s.dev.src16_off = s.stage_off == MIJ_NO_STAGE ? 0 : s.stage_off;
 	}
 
 	/* ---- scratch planes for the two-pass path */
@@ -765,92 +771,112 @@ extern "C" int mij_batch_upload(mij_batch *b)
 		b->planes_cap = planes_need;
 	}
 
-	/* ---- work lists */
-	size_t nb_total = 0, ni_total = 0;
-	for (int g = 0; g < 8; ++g)
-		nb_total += bands[g].size();
-	for (int g = 0; g < 13; ++g)
-		ni_total += idct[g].size();
-	int rc;
-	if ((nb_total > b->bands_cap || ni_total > b->idct_cap))
+	/* ---- work lists: the pack list first, then one range per launch */
+	size_t total = pack.size();
+	for (int k = 0; k < MK_KINDS; ++k)
+		for (int v = 0; v < 8; ++v)
+			total += lists[k][v >> 2][(v >> 1) & 1][v & 1].size();
+	if (total > b->work_cap)
 		HIP_TRY(hipStreamSynchronize(b->stream));
-	if ((rc = grow_pair(b->h_bands, b->d_bands, b->bands_cap, nb_total)) != MIJ_OK)
+	int rc;
+	if ((rc = grow_pair(b->h_work, b->d_work, b->work_cap, total)) != MIJ_OK)
 		return rc;
-	if ((rc = grow_pair(b->h_idct, b->d_idct, b->idct_cap, ni_total)) != MIJ_OK)
-		return rc;
-	b->band_launches.clear();
-	b->idct_launches.clear();
+	b->launches.clear();
 	size_t pos = 0;
-	for (int g = 0; g < 8; ++g) {
-		if (bands[g].empty())
-			continue;
-		memcpy(b->h_bands + pos, bands[g].data(), bands[g].size() * sizeof(WorkBand));
-		mij_batch::BandLaunch L;
-		L.nout = (g & 2) ? 4 : 3;
-		L.wide = g & 1;
-		L.b8 = (g & 4) != 0;
-		L.first = pos;
-		L.count = bands[g].size();
-		L.lds = band_lds[g];
-		if (const char *pad = getenv("MIJ_LDS_PAD")) { /* experiment knob: lower the occupancy on purpose */
-			size_t want = L.lds + (size_t)atol(pad);
-			L.lds = want > (size_t)b->ctx->max_dyn_lds ? (size_t)b->ctx->max_dyn_lds : want;
+	if (!pack.empty())
+		memcpy(b->h_work, pack.data(), pack.size() * sizeof(Work4));
+	pos = pack.size();
+	for (int k = 0; k < MK_KINDS; ++k)
+		for (int v = 0; v < 8; ++v) {
+			const std::vector<Work4> &L = lists[k][v >> 2][(v >> 1) & 1][v & 1];
+			if (L.empty())
+				continue;
+			memcpy(b->h_work + pos, L.data(), L.size() * sizeof(Work4));
+			mij_batch::Launch q;
+			q.kind = k;
+			q.nout = (v >> 2) ? 4 : 3;
+			q.wide = (v >> 1) & 1;
+			q.b8 = v & 1;
+			q.first = pos;
+			q.count = L.size();
+			q.lds = lds_need[k][v >> 2][(v >> 1) & 1][v & 1];
+			if (k == MK_420)
+				if (const char *pad = getenv("MIJ_LDS_PAD")) { /* experiment knob: lower the occupancy on purpose */
+					size_t want = q.lds + (size_t)atol(pad);
+					q.lds = want > (size_t)b->ctx->max_dyn_lds ? (size_t)b->ctx->max_dyn_lds : want;
+				}
+			b->launches.push_back(q);
+			pos += L.size();
 		}
-		b->band_launches.push_back(L);
-		pos += bands[g].size();
-	}
-	pos = 0;
-	for (int g = 0; g < 13; ++g) {
-		if (idct[g].empty())
-			continue;
-		memcpy(b->h_idct + pos, idct[g].data(), idct[g].size() * sizeof(WorkIdct));
-		mij_batch::IdctLaunch L;
-		L.kind = g >= 11 ? 4 : (g >= 7 ? 3 : (g == 6 ? 2 : (g >= 2 ? 1 : 0)));
-		L.nout = (g >= 7 && g < 11) ? ((g - 7) & 2 ? 4 : 3) : ((g >= 4) ? 4 : 3);
-		L.lds = (g >= 7 && g < 11) ? lds422[g - 7] : 0;
-		L.wide = g >= 7 ? ((g - 7) & 1) : (g & 1);
-		L.first = pos;
-		L.count = idct[g].size();
-		b->idct_launches.push_back(L);
-		pos += idct[g].size();
-	}
 	for (size_t i = 0; i < n; ++i)
 		b->h_imgs[i] = b->slots[i].dev;
 
 	/* ---- copies, all on the batch stream */
 	HIP_TRY(copy_table(b->d_imgs, b->h_imgs, sizeof(DevImage) * n, b->stream));
-	if (nb_total)
-		HIP_TRY(copy_table(b->d_bands, b->h_bands, sizeof(WorkBand) * nb_total, b->stream));
-	if (ni_total)
-		HIP_TRY(copy_table(b->d_idct, b->h_idct, sizeof(WorkIdct) * ni_total, b->stream));
-	/* staged coefficients: own-staging slots are contiguous in both arenas in add order, so runs of
-	 * them go up in one copy each */
+	if (total)
+		HIP_TRY(copy_table(b->d_work, b->h_work, sizeof(Work4) * total, b->stream));
+	/* staged coefficients: own-staging slots are contiguous in the staging arena, the upload scratch and the
+	 * coefficient arena in add order, so runs of them with one destination go up in one copy each */
 	size_t i = 0;
 	while (i < n) {
-		if (b->slots[i].clone_of >= 0 || b->slots[i].dev_coef) {
+		if (b->slots[i].clone_of >= 0 || b->slots[i].dev_coef || (b->slots[i].desc.flags & MIJ_FLAG_SKIP)) {
 			++i;
 			continue;
 		}
 		size_t j = i, bytes = 0;
-		const size_t s0 = b->slots[i].stage_off, c0 = b->slots[i].dev.comp[0].coef_off;
-		while (j < n && b->slots[j].clone_of < 0 && !b->slots[j].dev_coef && b->slots[j].stage_off == s0 + bytes && b->slots[j].dev.comp[0].coef_off == c0 + bytes) {
+		const int fmt = b->slots[i].coef_bytes_fmt;
+		const size_t s0 = b->slots[i].stage_off, c0 = b->slots[i].coef_base;
+		while (j < n && b->slots[j].clone_of < 0 && !b->slots[j].dev_coef && !(b->slots[j].desc.flags & MIJ_FLAG_SKIP) && b->slots[j].coef_bytes_fmt == fmt &&
+				 b->slots[j].stage_off == s0 + bytes && b->slots[j].coef_base == c0 + bytes) {
 			bytes += b->slots[j].coef_bytes;
 			++j;
 		}
-		HIP_TRY(hipMemcpyAsync(b->d_coef + c0, b->stage + s0, bytes, hipMemcpyHostToDevice, b->stream));
+		HIP_TRY(hipMemcpyAsync(fmt ? b->d_up16 + s0 : b->d_coef + c0, b->stage + s0, bytes, hipMemcpyHostToDevice, b->stream));
 		i = j;
+	}
+	if (!pack.empty()) {
+		hipLaunchKernelGGL(k_pack_c8, dim3((unsigned)pack.size()), dim3(256), 0, b->stream, b->d_imgs, reinterpret_cast<const WorkIdct *>(b->d_work), b->d_up16, b->d_coef);
+		HIP_TRY(hipGetLastError());
 	}
 	for (size_t k = 0; k < n; ++k) {
 		const Slot &s = b->slots[k];
 		if (s.clone_of < 0)
 			continue;
 		const Slot &src = b->slots[(size_t)s.clone_of];
-		HIP_TRY(hipMemcpyAsync(b->d_coef + s.dev.comp[0].coef_off, b->d_coef + src.dev.comp[0].coef_off, s.coef_bytes, hipMemcpyDeviceToDevice, b->stream));
+		HIP_TRY(hipMemcpyAsync(b->d_coef + s.coef_base, b->d_coef + src.coef_base, s.coef_bytes, hipMemcpyDeviceToDevice, b->stream));
 	}
 	b->uploaded = true;
 	b->launched = false;
 	return MIJ_OK;
 }
+
+/* one kernel template over (n_out 3/4, wide IDCT, compact planes) */
+#define MIJ_LAUNCH_NWB(K, WT, ARGS)                                                                                                \
+	do {                                                                                                                            \
+		const int v_ = (L.nout == 4 ? 4 : 0) | (L.wide ? 2 : 0) | (L.b8 ? 1 : 0);                                                    \
+		switch (v_) {                                                                                                                \
+		case 0: hipLaunchKernelGGL((K<3, false, false>), grid, block, L.lds, b->stream, b->d_imgs, reinterpret_cast<const WT *>(wk), ARGS); break; \
+		case 1: hipLaunchKernelGGL((K<3, false, true>), grid, block, L.lds, b->stream, b->d_imgs, reinterpret_cast<const WT *>(wk), ARGS); break;  \
+		case 2: hipLaunchKernelGGL((K<3, true, false>), grid, block, L.lds, b->stream, b->d_imgs, reinterpret_cast<const WT *>(wk), ARGS); break;  \
+		case 3: hipLaunchKernelGGL((K<3, true, true>), grid, block, L.lds, b->stream, b->d_imgs, reinterpret_cast<const WT *>(wk), ARGS); break;   \
+		case 4: hipLaunchKernelGGL((K<4, false, false>), grid, block, L.lds, b->stream, b->d_imgs, reinterpret_cast<const WT *>(wk), ARGS); break; \
+		case 5: hipLaunchKernelGGL((K<4, false, true>), grid, block, L.lds, b->stream, b->d_imgs, reinterpret_cast<const WT *>(wk), ARGS); break;  \
+		case 6: hipLaunchKernelGGL((K<4, true, false>), grid, block, L.lds, b->stream, b->d_imgs, reinterpret_cast<const WT *>(wk), ARGS); break;  \
+		default: hipLaunchKernelGGL((K<4, true, true>), grid, block, L.lds, b->stream, b->d_imgs, reinterpret_cast<const WT *>(wk), ARGS); break;  \
+		}                                                                                                                            \
+	} while (0)
+#define MIJ_LAUNCH_WB(K, ARGS)                                                                                                     \
+	do {                                                                                                                            \
+		const int v_ = (L.wide ? 2 : 0) | (L.b8 ? 1 : 0);                                                                            \
+		switch (v_) {                                                                                                                \
+		case 0: hipLaunchKernelGGL((K<false, false>), grid, block, 0, b->stream, b->d_imgs, reinterpret_cast<const WorkIdct *>(wk), ARGS); break; \
+		case 1: hipLaunchKernelGGL((K<false, true>), grid, block, 0, b->stream, b->d_imgs, reinterpret_cast<const WorkIdct *>(wk), ARGS); break;  \
+		case 2: hipLaunchKernelGGL((K<true, false>), grid, block, 0, b->stream, b->d_imgs, reinterpret_cast<const WorkIdct *>(wk), ARGS); break;  \
+		default: hipLaunchKernelGGL((K<true, true>), grid, block, 0, b->stream, b->d_imgs, reinterpret_cast<const WorkIdct *>(wk), ARGS); break;  \
+		}                                                                                                                            \
+	} while (0)
+#define MIJ_COEF_OUT b->d_coef, b->d_out
+#define MIJ_COEF_OUT_PLANES b->d_coef, b->d_planes
 
 extern "C" int mij_batch_launch(mij_batch *b)
 {
@@ -859,61 +885,29 @@ extern "C" int mij_batch_launch(mij_batch *b)
 	if (!b->uploaded)
 		return set_err(MIJ_E_STATE, "mij_batch_launch before mij_batch_upload");
 	HIP_TRY(hipSetDevice(b->ctx->device));
-	for (const auto &L : b->band_launches) {
+	for (const auto &L : b->launches) { /* in family order: pass 2 of the two-pass family runs behind every pass-1 launch */
 		const dim3 grid((unsigned)L.count), block(256);
-		const WorkBand *wk = b->d_bands + L.first;
-		if (L.b8) {
-			if (L.nout == 3 && !L.wide)
-				hipLaunchKernelGGL((k_fused420<3, false, true>), grid, block, L.lds, b->stream, b->d_imgs, wk, b->d_coef, b->d_out);
-			else if (L.nout == 3)
-				hipLaunchKernelGGL((k_fused420<3, true, true>), grid, block, L.lds, b->stream, b->d_imgs, wk, b->d_coef, b->d_out);
-			else if (!L.wide)
-				hipLaunchKernelGGL((k_fused420<4, false, true>), grid, block, L.lds, b->stream, b->d_imgs, wk, b->d_coef, b->d_out);
-			else
-				hipLaunchKernelGGL((k_fused420<4, true, true>), grid, block, L.lds, b->stream, b->d_imgs, wk, b->d_coef, b->d_out);
-		} else if (L.nout == 3 && !L.wide)
-			hipLaunchKernelGGL((k_fused420<3, false>), grid, block, L.lds, b->stream, b->d_imgs, wk, b->d_coef, b->d_out);
-		else if (L.nout == 3)
-			hipLaunchKernelGGL((k_fused420<3, true>), grid, block, L.lds, b->stream, b->d_imgs, wk, b->d_coef, b->d_out);
-		else if (!L.wide)
-			hipLaunchKernelGGL((k_fused420<4, false>), grid, block, L.lds, b->stream, b->d_imgs, wk, b->d_coef, b->d_out);
-		else
-			hipLaunchKernelGGL((k_fused420<4, true>), grid, block, L.lds, b->stream, b->d_imgs, wk, b->d_coef, b->d_out);
-		HIP_TRY(hipGetLastError());
-	}
-	for (const auto &L : b->idct_launches) {
-		const dim3 grid((unsigned)L.count), block(256);
-		const WorkIdct *wk = b->d_idct + L.first;
-		if (L.kind == 4) {
-			if (L.wide)
-				hipLaunchKernelGGL((k_fused_grey<true>), grid, block, 0, b->stream, b->d_imgs, wk, b->d_coef, b->d_out);
-			else
-				hipLaunchKernelGGL((k_fused_grey<false>), grid, block, 0, b->stream, b->d_imgs, wk, b->d_coef, b->d_out);
-		} else if (L.kind == 3) {
-			const WorkBand *wb = reinterpret_cast<const WorkBand *>(wk); /* same four-u32 layout */
-			if (L.nout == 3 && !L.wide)
-				hipLaunchKernelGGL((k_fused422<3, false>), grid, block, L.lds, b->stream, b->d_imgs, wb, b->d_coef, b->d_out);
-			else if (L.nout == 3)
-				hipLaunchKernelGGL((k_fused422<3, true>), grid, block, L.lds, b->stream, b->d_imgs, wb, b->d_coef, b->d_out);
-			else if (!L.wide)
-				hipLaunchKernelGGL((k_fused422<4, false>), grid, block, L.lds, b->stream, b->d_imgs, wb, b->d_coef, b->d_out);
-			else
-				hipLaunchKernelGGL((k_fused422<4, true>), grid, block, L.lds, b->stream, b->d_imgs, wb, b->d_coef, b->d_out);
-		} else if (L.kind == 2) /* pass 2 of the two-pass family: after every k_idct_planes launch (stream order) */
-			hipLaunchKernelGGL(k_resample_color, grid, block, 0, b->stream, b->d_imgs, wk, b->d_planes, b->d_out);
-		else if (L.kind == 1) {
-			if (L.nout == 3 && !L.wide)
-				hipLaunchKernelGGL((k_fused444<3, false>), grid, block, 0, b->stream, b->d_imgs, wk, b->d_coef, b->d_out);
-			else if (L.nout == 3)
-				hipLaunchKernelGGL((k_fused444<3, true>), grid, block, 0, b->stream, b->d_imgs, wk, b->d_coef, b->d_out);
-			else if (!L.wide)
-				hipLaunchKernelGGL((k_fused444<4, false>), grid, block, 0, b->stream, b->d_imgs, wk, b->d_coef, b->d_out);
-			else
-				hipLaunchKernelGGL((k_fused444<4, true>), grid, block, 0, b->stream, b->d_imgs, wk, b->d_coef, b->d_out);
-		} else if (L.wide)
-			hipLaunchKernelGGL((k_idct_planes<true>), grid, block, 0, b->stream, b->d_imgs, wk, b->d_coef, b->d_planes);
-		else
-			hipLaunchKernelGGL((k_idct_planes<false>), grid, block, 0, b->stream, b->d_imgs, wk, b->d_coef, b->d_planes);
+		const Work4 *wk = b->d_work + L.first;
+		switch (L.kind) {
+		case MK_420:
+			MIJ_LAUNCH_NWB(k_fused420, WorkBand, MIJ_COEF_OUT);
+			break;
+		case MK_422:
+			MIJ_LAUNCH_NWB(k_fused422, WorkBand, MIJ_COEF_OUT);
+			break;
+		case MK_444:
+			MIJ_LAUNCH_NWB(k_fused444, WorkIdct, MIJ_COEF_OUT);
+			break;
+		case MK_GREY:
+			MIJ_LAUNCH_WB(k_fused_grey, MIJ_COEF_OUT);
+			break;
+		case MK_PLANES:
+			MIJ_LAUNCH_WB(k_idct_planes, MIJ_COEF_OUT_PLANES);
+			break;
+		default:
+			hipLaunchKernelGGL(k_resample_color, grid, block, 0, b->stream, b->d_imgs, reinterpret_cast<const WorkIdct *>(wk), b->d_planes, b->d_out);
+			break;
+		}
 		HIP_TRY(hipGetLastError());
 	}
 	b->launched = true;
@@ -1073,8 +1067,7 @@ struct EsArena {
 	std::vector<int> scan_slot; /* scan index -> batch slot */
 	size_t sub_used, blk_used, work_used, scan_cap, n_tabs;
 	int last_rounds, cur;
-	bool in_flight, coef_bytes_optin;
-	bool scatter; /* write pass without LDS staging, into cleared planes (default; MIJ_ES_SCATTER=0 selects the staged pass for A/B) */
+	bool in_flight;
 };
 
 static const int ES_MAX_ROUNDS = 96;
@@ -1155,8 +1148,6 @@ extern "C" int mij_batch_entropy_reserve(mij_batch *b, size_t stream_bytes)
 		es_free(e);
 		return set_err(r == hipErrorOutOfMemory ? MIJ_E_NOMEM : MIJ_E_HIP, "mij_batch_entropy_reserve: %s", hipGetErrorString(r));
 	}
-	e->coef_bytes_optin = getenv("MIJ_COEF_BYTES") != nullptr && atoi(getenv("MIJ_COEF_BYTES")) != 0;
-	e->scatter = !(getenv("MIJ_ES_SCATTER") != nullptr && atoi(getenv("MIJ_ES_SCATTER")) == 0);
 	b->es = e;
 	return MIJ_OK;
 }
@@ -1179,6 +1170,26 @@ extern "C" int mij_batch_add_stream(mij_batch *b, const mjg_scan *scan, uint8_t 
 		return set_err(MIJ_E_ARG, "the stream must lie 4-byte aligned inside the pinned entropy region with 32 spare bytes behind it");
 	if (scan->blocks_per_mcu < 1 || scan->blocks_per_mcu > 10 || scan->nblocks == 0 || stream_len >= (1u << 28))
 		return set_err(MIJ_E_ARG, "bad scan description");
+	/* the walk kernels compute plane addresses straight from these fields: they must describe the image's own MCU */
+	{
+		int rc = check_desc(&scan->desc);
+		if (rc != MIJ_OK)
+			return rc;
+		const mij_image_desc &sd = scan->desc;
+		uint32_t want = 0;
+		for (int c = 0; c < sd.ncomp; ++c)
+			want += (uint32_t)(sd.comp[c].h * sd.comp[c].v);
+		if (want != scan->blocks_per_mcu || (uint64_t)scan->nblocks != (uint64_t)want * (uint32_t)sd.mcu_x * (uint32_t)sd.mcu_y)
+			return set_err(MIJ_E_ARG, "scan block counts do not match the descriptor");
+		for (uint32_t k = 0; k < scan->blocks_per_mcu; ++k) {
+			const uint32_t ci = scan->blk_comp[k];
+			if (ci >= (uint32_t)sd.ncomp || scan->blk_dx[k] >= (uint32_t)sd.comp[ci].h || scan->blk_dy[k] >= (uint32_t)sd.comp[ci].v)
+				return set_err(MIJ_E_ARG, "scan block %u lies outside its component's MCU", k);
+		}
+		for (int c = 0; c < sd.ncomp; ++c)
+			if (scan->dc_tab[c] > 3 || scan->ac_tab[c] < 4 || scan->ac_tab[c] > 7)
+				return set_err(MIJ_E_ARG, "bad Huffman table index for component %d", c);
+	}
 	/* one DevScan per restart interval (one for the whole stream without restart markers) */
 	const uint32_t nseg = scan->n_seg ? scan->n_seg : 1u;
 	if ((size_t)scan->seg_table_off + 8u * (size_t)nseg > stream_len || (scan->seg_table_off & 3u))
@@ -1205,15 +1216,11 @@ extern "C" int mij_batch_add_stream(mij_batch *b, const mjg_scan *scan, uint8_t 
 	Slot &s = b->slots[(size_t)slot];
 	s.dev_coef = 1;
 	s.es_index = (int)e->scan_slot.size();
-	/* Byte-coefficient planes (opt-in, MIJ_COEF_BYTES=1): only where the fused 4:2:0 kernel reads them.  Any
-	 * quantiser will do: the unpack multiplies the sign-extended byte by the 16-bit quantiser and keeps the low
-	 * half, which is the reference's (short)(v * dequant).  A coefficient outside -128..127 raises the verdict
-	 * and the image goes to the host walk and int16 planes. */
-	s.coef_bytes_fmt = 0;
-	if (e->coef_bytes_optin && fused420_ok(b, scan->desc)) {
-		s.coef_bytes_fmt = 1;
-		apply_coef_bytes(s);
-	}
+	/* The walk writes the batch's plane format straight into HBM: compact planes by default (every decode kernel
+	 * reads them; a coefficient outside -128..127 becomes an escape byte, nothing is handed back for its size),
+	 * int16 tile layout on request (mij_batch_set_coef_format). */
+	s.coef_bytes_fmt = b->coef_fmt ? 1 : 0;
+	layout_coef(s);
 	static_assert(sizeof(DevHuff) == sizeof(mjg_huff), "mjg_huff and DevHuff must match");
 	const size_t tab = e->n_tabs++;
 	memcpy(&e->h_huff[8 * tab], scan->huff, sizeof(mjg_huff) * 8);
@@ -1267,13 +1274,14 @@ static int es_enqueue_tail(mij_batch *b)
 	const dim3 gw((unsigned)e->work_used), gs((unsigned)ns), blk(256);
 	hipLaunchKernelGGL(k_es_offsets, gs, blk, 0, st, e->d_scans, e->d_cnt, e->d_base, v_total);
 	HIP_TRY(hipGetLastError());
-	if (e->scatter) {
-		/* clear the planes of the walked images (neighbours in the arena as one range) */
+	{
+		/* clear the planes of the walked images (neighbours in the arena as one range): the write pass only stores
+		 * non-zero coefficients, and escape bytes only where a value needs one */
 		size_t lo = 0, hi = 0;
 		for (const Slot &sl : b->slots) {
 			if (!sl.dev_coef || sl.clone_of >= 0)
 				continue;
-			const size_t a = (size_t)sl.dev.comp[0].coef_off, z = a + sl.coef_bytes;
+			const size_t a = sl.coef_base, z = a + sl.coef_bytes;
 			if (a == hi && hi > lo) {
 				hi = z;
 				continue;
@@ -1285,11 +1293,9 @@ static int es_enqueue_tail(mij_batch *b)
 		}
 		if (hi > lo)
 			HIP_TRY(hipMemsetAsync(b->d_coef + lo, 0, hi - lo, st));
-		hipLaunchKernelGGL(k_es_write<false>, gw, blk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, b->d_imgs, e->d_start, e->d_base,
+		hipLaunchKernelGGL(k_es_write, gw, blk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, b->d_imgs, e->d_start, e->d_base,
 								 reinterpret_cast<int16_t *>(b->d_coef), e->d_dcdiff, e->d_l1, v_anom, v_pfinal);
-	} else
-		hipLaunchKernelGGL(k_es_write<true>, gw, blk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, b->d_imgs, e->d_start, e->d_base,
-								 reinterpret_cast<int16_t *>(b->d_coef), e->d_dcdiff, e->d_l1, v_anom, v_pfinal);
+	}
 	HIP_TRY(hipGetLastError());
 	hipLaunchKernelGGL(k_es_tails, gw, blk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, b->d_imgs, e->d_start, e->d_base,
 							 reinterpret_cast<int16_t *>(b->d_coef), e->d_dcdiff, e->d_l1, e->d_rounds_changed);
@@ -1458,8 +1464,8 @@ extern "C" int mij_batch_fallback_prepare(mij_batch *b, int slot)
 	if (s.stage_off == MIJ_NO_STAGE)
 		return set_err(MIJ_E_NOMEM, "slot %d has no staging planes (the staging arena was too small when it was added)", slot);
 	s.dev_coef = 0;
-	s.coef_bytes_fmt = 0;
-	s.dev.flags &= ~(int32_t)MIJ_DEV_COEF_BYTES;
+	s.coef_bytes_fmt = 0; /* staged as int16 by the host walk; upload decides the format in HBM */
+	layout_coef(s);
 	s.desc.flags &= ~(uint32_t)MIJ_FLAG_WIDE_IDCT;
 	memset(b->stage + s.stage_off, 0, s.coef_bytes);
 	b->uploaded = b->launched = false;
@@ -1471,12 +1477,73 @@ extern "C" int mij_batch_fetch_coef(mij_batch *b, int slot, int16_t *dst, size_t
 	if (!b || slot < 0 || slot >= (int)b->slots.size() || !dst)
 		return set_err(MIJ_E_ARG, "bad slot or destination");
 	const Slot &s = b->slots[(size_t)slot];
-	if (dst_elems * sizeof(int16_t) < s.coef_bytes)
+	size_t elems = 0;
+	for (int c = 0; c < s.desc.ncomp; ++c)
+		elems += comp_tiles(s.desc.comp[c]) << 12;
+	if (dst_elems < elems)
 		return set_err(MIJ_E_ARG, "destination too small");
 	HIP_TRY(hipSetDevice(b->ctx->device));
-	HIP_TRY(hipMemcpyAsync(dst, b->d_coef + s.dev.comp[0].coef_off, s.coef_bytes, hipMemcpyDeviceToHost, b->stream));
+	if (!s.coef_bytes_fmt) {
+		HIP_TRY(hipMemcpyAsync(dst, b->d_coef + s.coef_base, elems * sizeof(int16_t), hipMemcpyDeviceToHost, b->stream));
+		HIP_TRY(hipStreamSynchronize(b->stream));
+		return MIJ_OK;
+	}
+	/* compact planes: bring the region over and expand it on the host into the int16 tile layout */
+	std::vector<uint8_t> raw(s.coef_bytes);
+	HIP_TRY(hipMemcpyAsync(raw.data(), b->d_coef + s.coef_base, s.coef_bytes, hipMemcpyDeviceToHost, b->stream));
 	HIP_TRY(hipStreamSynchronize(b->stream));
+	size_t roff = 0, eoff = 0;
+	for (int c = 0; c < s.desc.ncomp; ++c) {
+		const size_t nt = comp_tiles(s.desc.comp[c]);
+		const uint8_t *lo = raw.data() + roff, *dcp = lo + (nt << 12), *hi = dcp + (nt << 7);
+		int16_t *out = dst + eoff;
+		for (size_t L = 0; L < nt * 64; ++L) {
+			const uint8_t *blo = lo + ((L >> 6) << 12) + ((L & 63) << 3);
+			int16_t *bo = out + ((L >> 6) << 12) + ((L & 63) << 3);
+			const bool esc = (blo[0] & 1u) != 0;
+			for (int P = 0; P < 64; ++P) {
+				int v = (int8_t)blo[((size_t)(P >> 3) << 9) + (P & 7)];
+				if (esc)
+					v += 256 * (int)hi[(L << 6) + P];
+				bo[((size_t)(P >> 3) << 9) + (P & 7)] = (int16_t)v;
+			}
+			uint16_t dcv;
+			memcpy(&dcv, dcp + 2 * L, 2);
+			bo[0] = (int16_t)dcv;
+		}
+		roff += nt * MIJ_TILE_COMPACT_BYTES;
+		eoff += nt << 12;
+	}
 	return MIJ_OK;
+}
+
+extern "C" int mij_batch_set_coef_format(mij_batch *b, int fmt)
+{
+	if (!b || (fmt != MIJ_COEF_INT16 && fmt != MIJ_COEF_COMPACT))
+		return set_err(MIJ_E_ARG, "bad coefficient format");
+	b->coef_fmt = fmt;
+	b->uploaded = b->launched = false;
+	return MIJ_OK;
+}
+
+extern "C" int mij_batch_slot_escapes(mij_batch *b, int slot)
+{
+	if (!b || slot < 0 || slot >= (int)b->slots.size())
+		return set_err(MIJ_E_ARG, "bad slot");
+	const Slot &s = b->slots[(size_t)slot];
+	if (!s.coef_bytes_fmt)
+		return 0;
+	HIP_TRY(hipSetDevice(b->ctx->device));
+	int total = 0;
+	for (int c = 0; c < s.desc.ncomp; ++c) {
+		const size_t nt = comp_tiles(s.desc.comp[c]);
+		std::vector<uint8_t> lo(nt << 12);
+		HIP_TRY(hipMemcpyAsync(lo.data(), b->d_coef + s.dev.comp[c].coef_off, nt << 12, hipMemcpyDeviceToHost, b->stream));
+		HIP_TRY(hipStreamSynchronize(b->stream));
+		for (size_t L = 0; L < (size_t)(s.desc.comp[c].bw * s.desc.comp[c].bh); ++L)
+			total += lo[((L >> 6) << 12) + ((L & 63) << 3)] & 1;
+	}
+	return total;
 }
 
 extern "C" int mij_batch_slot_coef_bytes(const mij_batch *b, int slot)

@@ -103,6 +103,21 @@ static const uint8_t mij_zigzag_pos[64] = {
 	23, 31, 35, 46, 49, 61, 57, 54,
 	43, 39, 47, 51, 62, 59, 55, 63};
 
+/*
+ * Compact coefficient planes: the DEFAULT format of the coefficients in HBM (the staging above stays int16: the
+ * host walk and the progressive scans read-modify-write it, and mij_batch_upload packs it on the device).  Per
+ * component and 64-block tile: 4 KiB of low bytes in the same chunk order (chunk c of block lane l at byte
+ * (c*64 + l)*8, eight bytes = column c in mij_rowslot order), then behind all tiles an int16 DC array (one entry
+ * per block; the byte at in-block position 0 holds the block's flags instead) and 64 "escape" bytes per block in
+ * position order P.  coefficient == sext8(low byte) + 256 * (int8)escape byte  (mod 2^16 -- all that
+ * (short)(coef * dequant), codec/jpeg.c:325-365, depends on); the escape bytes of a block are only defined (and
+ * only read) when bit 0 of its flags byte is set, i.e. when one of its coefficients lies outside -128..127.  The
+ * reference's coefficients have up to 15 magnitude bits (codec/jpeg.c:250-265), so this is exact for every stream;
+ * a typical q=90 photograph reads 4.1 KiB per tile instead of 8.
+ */
+#define MIJ_TILE_COMPACT_BYTES (4096 + 128 + 4096)
+enum { MIJ_COEF_INT16 = 0, MIJ_COEF_COMPACT = 1 };
+
 static inline size_t mij_coef_index(uint32_t L, uint32_t P)
 {
 	return ((size_t)(L >> 6) << 12) + ((size_t)(P >> 3) << 9) + ((size_t)(L & 63u) << 3) + (P & 7u);
@@ -143,7 +158,7 @@ int mij_batch_create(mij_ctx *ctx, int max_images, size_t stage_bytes, size_t co
 void mij_batch_destroy(mij_batch *b);
 int mij_batch_reset(mij_batch *b); /* forget all images; arenas are reused */
 
-size_t mij_image_coef_bytes(const mij_image_desc *d); /* sum over components of whole tiles */
+size_t mij_image_coef_bytes(const mij_image_desc *d); /* sum over components of whole tiles, MIJ_TILE_COMPACT_BYTES each: room for either format */
 size_t mij_image_out_bytes(const mij_image_desc *d);  /* n_out*width*height, rounded up to 256 */
 
 /* Adds an image; returns its slot (>= 0) or a negative error.  Its staging planes are zeroed. */
@@ -159,6 +174,10 @@ int mij_batch_add_clone(mij_batch *b, int src_slot);
 int16_t *mij_batch_coef(mij_batch *b, int slot, int comp);
 /* May be called after the entropy stage to raise flags it only knows late (e.g. WIDE_IDCT). */
 int mij_batch_set_flags(mij_batch *b, int slot, uint32_t flags);
+
+/* May be called after the entropy stage when a marker behind SOF changed the colour branch (the reference decides
+ * is_rgb / CMYK / YCCK after the last marker, codec/jpeg.c:2244); the new mode must fit the slot's component count. */
+int mij_batch_set_color(mij_batch *b, int slot, int color);
 
 /* submit = upload + launch.  All asynchronous on the batch's stream; wait blocks. */
 int mij_batch_upload(mij_batch *b); /* H2D of staged coefficients (+ D2D for clones) + descriptors */
@@ -240,13 +259,16 @@ int mij_batch_entropy_run(mij_batch *b, int *fallback, int cap, int *n_fallback)
 int mij_batch_entropy_launch(mij_batch *b);
 int mij_batch_entropy_finish(mij_batch *b, int *fallback, int cap, int *n_fallback);
 int mij_batch_fallback_prepare(mij_batch *b, int slot);
-/* tests: the coefficient planes of a slot as they sit in HBM (tile layout), after entropy_run or upload */
+/* tests: the coefficient planes of a slot as they sit in HBM, after entropy_run or upload, always returned in the
+ * int16 tile layout (compact planes are expanded on the host); dst_elems >= sum of mij_plane_elems */
 int mij_batch_fetch_coef(mij_batch *b, int slot, int16_t *dst, size_t dst_elems);
-/* 1 if the slot's coefficients sit in HBM as byte planes (experimental, environment MIJ_COEF_BYTES=1 when the entropy
- * arena is reserved): AC coefficients as signed bytes, DC in its own array -- half the bytes for the fused 4:2:0 kernel.
- * Chosen per image by mij_batch_add_stream (4:2:0 YCbCr, any quantiser); an image with a coefficient outside
- * -128..127 is handed back by the GPU walk and ends up in int16 planes through the host walk. */
+/* The format new coefficient planes of this batch get in HBM: MIJ_COEF_COMPACT (default; environment
+ * MIJ_COEF_FORMAT=int16 flips the default) or MIJ_COEF_INT16.  Applies to slots added or uploaded afterwards. */
+int mij_batch_set_coef_format(mij_batch *b, int fmt);
+/* 1 if the slot's coefficients sit in HBM as compact planes (after upload or the GPU walk) */
 int mij_batch_slot_coef_bytes(const mij_batch *b, int slot);
+/* number of escaped blocks of a slot (blocks holding a coefficient outside -128..127), read back from HBM; tests */
+int mij_batch_slot_escapes(mij_batch *b, int slot);
 /* tests / tuning: synchronisation rounds the last entropy_run needed for its slowest image */
 int mij_batch_entropy_rounds(const mij_batch *b);
 

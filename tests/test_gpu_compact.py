@@ -1,0 +1,108 @@
+"""Compact coefficient planes (include/mij.h, "compact coefficient planes"): the default format of the
+coefficients in HBM.  The reference's coefficients are 16-bit (codec/jpeg.c:250-265, :325-365), the planes hold
+low bytes plus escape bytes for blocks that need them: these tests put blocks on both sides of the escape -- and
+at the extremes of int16 -- through every decode kernel family, through both producers (the GPU Huffman walk,
+which writes the format itself, and the host walk, whose int16 staging k_pack_c8 packs on the device), and compare
+with the oracle.  No stream may fall back to the host for the size of its coefficients."""
+import numpy as np
+import pytest
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+EDGE = [127, -128, 128, -129, 255, -256, 256, 1000, -1000, 32767, -32767, 32511, -32640, 383, -384]
+
+
+def _streams(ica, seed, extreme):
+    """Baseline streams (4:2:0, 4:4:4, 4:2:2, grey) whose quantised coefficients were replaced by values around
+    and far beyond the byte range; DC stays small enough for its 11-bit category."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for (w, h, q, layout) in ((96, 64, 90, "native"), (72, 40, 95, "native"), (80, 48, 95, "422"), (64, 56, 95, "grey"), (200, 120, 50, "native")):
+        img = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+        plan, du = ica.host_transform(img, q)
+        du = du.copy()
+        nblk = du.shape[0]
+        hit = rng.random(nblk) < 0.3  # most blocks stay inside a byte: escaped and plain blocks share tiles and waves
+        for b in np.nonzero(hit)[0]:
+            for _ in range(int(rng.integers(1, 6))):
+                k = int(rng.integers(1, 64))
+                if extreme:
+                    du[b, k] = EDGE[int(rng.integers(0, len(EDGE)))]
+                else:
+                    du[b, k] = int(rng.integers(128, 400)) * (1 if rng.random() < 0.5 else -1)
+        du[:, 0] = np.clip(du[:, 0], -900, 900)
+        out.append(helpers.baseline_from_du(plan, du, restart_mcus=(5 if layout == "native" and w == 96 else 0), layout=layout))
+    return out
+
+
+@pytest.mark.parametrize("extreme", [False, True])
+def test_escaped_blocks_decode_exactly_through_both_producers(ica, oracle, gpu_ctx, extreme):
+    datas = _streams(ica, 21 + extreme, extreme)
+    for req in (3, 4, 1):
+        want = []
+        for d in datas:
+            kind, px, _ = oracle.load(d, req)
+            assert kind == "ok", px
+            want.append(px)
+        # producer 1: the GPU Huffman walk writes compact planes straight into HBM
+        b = ica.Batch(gpu_ctx, len(datas), 64 << 20, 64 << 20, 64 << 20)
+        b.entropy_reserve(8 << 20)
+        ok, slots, reasons = b.decode_jpegs(datas, req, threads=2, gpu_entropy=True)
+        assert ok == len(datas), reasons
+        b.submit()
+        b.wait()
+        for i, s in enumerate(slots):
+            assert b.slot_coef_bytes(s) == 1
+            assert b.slot_escapes(s) > 0, i
+            assert np.array_equal(b.fetch(s), want[i]), ("gpu walk", i, req)
+        planes_gpu = [b.fetch_coef(s) for s in slots]
+        b.close()
+        # producer 2: host walk -> int16 staging -> k_pack_c8 on the device
+        b = ica.Batch(gpu_ctx, len(datas), 64 << 20, 64 << 20, 64 << 20)
+        ok, slots, reasons = b.decode_jpegs(datas, req, threads=2)
+        assert ok == len(datas), reasons
+        b.submit()
+        b.wait()
+        for i, s in enumerate(slots):
+            assert b.slot_coef_bytes(s) == 1
+            assert b.slot_escapes(s) > 0, i
+            assert np.array_equal(b.fetch(s), want[i]), ("host walk + pack", i, req)
+            # the packed planes, expanded again, are the staged int16 planes -- and what the GPU walk wrote
+            desc, staged = ica.HostDecoder.decode(datas[i], req)
+            for pa, pb, pc in zip(ica.detile_coefficients(desc, b.fetch_coef(s)), ica.detile_coefficients(desc, staged), ica.detile_coefficients(desc, planes_gpu[i])):
+                assert np.array_equal(pa, pb) and np.array_equal(pa, pc), i
+        # the same batch through the general two-pass kernels, and once more as int16 planes
+        b.force_generic(True)
+        b.submit()
+        b.wait()
+        for i, s in enumerate(slots):
+            assert b.slot_path(s) == 2 and np.array_equal(b.fetch(s), want[i]), ("two-pass", i, req)
+        b.force_generic(False)
+        b.set_coef_format("int16")
+        b.submit()
+        b.wait()
+        for i, s in enumerate(slots):
+            assert b.slot_coef_bytes(s) == 0 and np.array_equal(b.fetch(s), want[i]), ("int16", i, req)
+        b.close()
+
+
+def test_escapes_through_stbi_load_and_progressive(ica, oracle, gpu_ctx):
+    """stbi_load_from_memory (one-image batch, host walk, pack) and a progressive stream (planes re-staged over ten
+    scans, then packed) with coefficients far beyond a byte."""
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (88, 120, 3)).astype(np.uint8)
+    for q in (92, 100):
+        plan, du = ica.host_transform(img, q)
+        du = du.copy()
+        du[::3, 1] = 300
+        du[1::5, 2] = -700
+        du[:, 0] = np.clip(du[:, 0], -900, 900)
+        for data in (helpers.baseline_from_du(plan, du), helpers.progressive_from_du(plan, du)):
+            for req in (0, 3, 4):
+                kind, want, _ = oracle.load(data, req)
+                assert kind == "ok"
+                got = ica.stbi_load_from_memory(data, req)
+                assert got is not None, ica.stbi_failure_reason()
+                assert np.array_equal(got[0], want), (q, req)

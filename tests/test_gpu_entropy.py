@@ -11,17 +11,17 @@ def _host_planes(ica, data, req):
     return ica.HostDecoder.decode(data, req)
 
 
-@pytest.mark.parametrize("write_pass", ["scatter", "staged"])
-def test_gpu_walk_equals_host_walk(ica, oracle, gpu_ctx, golden, monkeypatch, write_pass):
-    """Both write passes: straight into cleared planes (the default) and block-wise through LDS (MIJ_ES_SCATTER=0)."""
-    if write_pass == "staged":
-        monkeypatch.setenv("MIJ_ES_SCATTER", "0")  # read by mij_batch_entropy_reserve
+@pytest.mark.parametrize("fmt", ["compact", "int16"])
+def test_gpu_walk_equals_host_walk(ica, oracle, gpu_ctx, golden, fmt):
+    """Both plane formats the write pass knows: compact planes (the default: low bytes + escape bytes + DC array)
+    and the int16 tile layout.  fetch_coef expands compact planes, so both compare with the host walk's staging."""
     datas = [ica.synth_jpeg(w, h, i, q) for i, (w, h, q) in enumerate(((64, 48, 90), (16, 16, 50), (200, 120, 90), (33, 17, 75), (640, 480, 90), (1920, 1080, 90),
                                                                         (8, 8, 95), (250, 131, 95), (1, 1, 90), (1024, 768, 30)))]
     rng = np.random.default_rng(3)
     datas.append(ica.stbi_write_jpg_to_memory(rng.integers(0, 256, (211, 307, 3)).astype(np.uint8), 92))   # noise: long codes, big coefficients
     datas.append(ica.stbi_write_jpg_to_memory(rng.integers(0, 256, (120, 160, 3)).astype(np.uint8), 100))  # q=100: WIDE candidates
     b = ica.Batch(gpu_ctx, len(datas), 64 << 20, 64 << 20, 64 << 20)
+    b.set_coef_format(fmt)
     b.entropy_reserve(16 << 20)
     slots = []
     for d in datas:
@@ -31,6 +31,9 @@ def test_gpu_walk_equals_host_walk(ica, oracle, gpu_ctx, golden, monkeypatch, wr
     fallback = b.entropy_run()
     assert fallback == [], fallback
     assert 1 <= b.entropy_rounds() <= 24
+    assert {b.slot_coef_bytes(s) for s in slots} == {1 if fmt == "compact" else 0}
+    if fmt == "compact":  # the two noise images hold coefficients beyond a byte: escaped blocks, not fallbacks
+        assert b.slot_escapes(slots[-1]) > 0 and b.slot_escapes(slots[-2]) > 0
     for d, s in zip(datas, slots):
         desc, want = _host_planes(ica, d, 3)
         got = b.fetch_coef(s)
@@ -239,27 +242,30 @@ def test_gpu_walk_restart_intervals_and_own_tables(ica, oracle, gpu_ctx, golden)
     b.close()
 
 
-def test_byte_coefficient_planes_opt_in(ica, oracle, gpu_ctx, monkeypatch):
-    """MIJ_COEF_BYTES=1 (experimental): the GPU walk leaves 4:2:0 images as byte-coefficient planes (AC signed
-    bytes, DC aside) and the fused kernel unpacks them; pixels unchanged.  Images with a coefficient outside
-    -128..127 come back for the host walk and int16 planes; other layouts never use the format."""
-    monkeypatch.setenv("MIJ_COEF_BYTES", "1")
+def test_compact_planes_are_the_default(ica, oracle, gpu_ctx):
+    """Without any knob the GPU walk leaves every image it takes as compact planes -- whatever the sampling, the
+    quantiser or the size of the coefficients -- and every decode kernel family reads them; an image with
+    coefficients outside -128..127 gets escape bytes instead of a trip through the host walk."""
     rng = np.random.default_rng(8)
     datas = [ica.synth_jpeg(w, h, i, q) for i, (w, h, q) in enumerate(((64, 48, 90), (200, 120, 90), (33, 17, 75), (640, 480, 90), (1920, 1080, 90), (250, 131, 50)))]
-    datas.append(ica.synth_jpeg(320, 200, 7, 95))                                                         # 4:4:4: int16 planes
+    datas.append(ica.synth_jpeg(320, 200, 7, 95))                                                         # 4:4:4
     datas.append(ica.stbi_write_jpg_to_memory(rng.integers(0, 256, (120, 160, 3)).astype(np.uint8), 90))   # noise: coefficients beyond a byte
-    datas.append(ica.synth_jpeg(96, 96, 9, 10))                                                            # quantisers up to 255: byte planes all the same
+    datas.append(ica.synth_jpeg(96, 96, 9, 10))                                                            # quantisers up to 255
+    datas.append(ica.stbi_write_jpg_to_memory(rng.integers(0, 256, (64, 80)).astype(np.uint8), 95))        # grey
     for req in (3, 4):
         b = ica.Batch(gpu_ctx, len(datas) + 2, 64 << 20, 64 << 20, 64 << 20)
         b.entropy_reserve(8 << 20)
         ok, slots, reasons = b.decode_jpegs(datas, req, threads=2, gpu_entropy=True)
         assert ok == len(datas), reasons
         c1 = b.add_clone(slots[4])
+        c2 = b.add_clone(slots[7])
         b.submit()
         b.wait()
         for d, s_ in zip(datas, slots):
             assert np.array_equal(b.fetch(s_), oracle.load(d, req)[1]), (s_, req)
         assert np.array_equal(b.fetch(c1), oracle.load(datas[4], req)[1])
-        fmt = [b.slot_coef_bytes(s_) for s_ in slots]
-        assert fmt == [1, 1, 1, 1, 1, 1, 0, 0, 1], fmt
+        assert np.array_equal(b.fetch(c2), oracle.load(datas[7], req)[1])
+        assert [b.slot_coef_bytes(s_) for s_ in slots] == [1] * len(datas)
+        assert b.slot_escapes(slots[7]) > 0
+        assert {b.slot_path(s_) for s_ in slots} == {1, 3, 5}
         b.close()
