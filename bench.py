@@ -314,6 +314,7 @@ def main():
     def int16_batch(count):
         """North-star pipeline: host Huffman walk -> int16 tile planes -> H2D; `count` images (clones beyond `distinct`)."""
         bt = ica.Batch(ctx, count, cbytes * distinct, cbytes * count, obytes * count)
+        bt.set_coef_format("int16")
         t0 = time.time()
         for d in datas:
             bt.add_jpeg(d, 3)  # host Huffman walk straight into pinned staging
@@ -338,7 +339,6 @@ def main():
     if not os.environ.get("MIJ_BENCH_INT16"):
         bb = None
         try:
-            os.environ["MIJ_COEF_BYTES"] = "1"
             bb = ica.Batch(ctx, n_img, cbytes * 2, cbytes * n_img, obytes * n_img)
             bb.entropy_reserve(sum(len(x) * 9 // 8 + 4352 for x in datas))
             ok, slots, reasons = bb.decode_jpegs(datas, 3, threads=usable_cores(), gpu_entropy=True)
@@ -354,7 +354,6 @@ def main():
         except Exception as exc:  # noqa: BLE001 -- the experimental format must never cost the benchmark its line
             planes_note = "%s: %s" % (type(exc).__name__, exc)
         finally:
-            os.environ.pop("MIJ_COEF_BYTES", None)
             if bb is not None:
                 bb.close()
     if batch is None:

@@ -32,10 +32,17 @@ from .binding import (  # noqa: F401
     stbi_info_from_memory,
     stbi_load,
     stbi_load_from_memory,
+    stbi_load_from_callbacks,
+    stbi_load_from_file,
+    stbi_info,
+    stbi_info_from_file,
+    stbi_info_from_callbacks,
+    stbi_write_jpg,
     stbi_load_16_from_memory,
     stbi_set_flip_vertically_on_load,
     stbi_write_jpg_to_memory,
     detile_coefficients,
+    decode_jpegs_multi,
     gpu_available,
 )
 from .synth import synth_rgb, synth_jpeg  # noqa: F401

@@ -207,6 +207,140 @@ def stbi_info_from_memory(data):
     return ok, x.value, y.value, c.value
 
 
+# ---- the callback / FILE* / file-name variants of the loaders (convert.c:188-211,261-266; image_api.c:74-131)
+
+_READ_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_char), C.c_int)
+_SKIP_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int)
+_EOF_CB = C.CFUNCTYPE(C.c_int, C.c_void_p)
+
+
+class IoCallbacks(C.Structure):
+    """stbi_io_callbacks (include/image_api.h)."""
+    _fields_ = [("read", _READ_CB), ("skip", _SKIP_CB), ("eof", _EOF_CB)]
+
+
+class _CallbackSource:
+    """A byte string behind stbi_io_callbacks whose read() hands out at most `chunk(k)` bytes on its k-th call
+    (short reads are legal: the reference refills its 128-byte buffer with whatever comes, common.c:10-26)."""
+
+    def __init__(self, data, chunk=None):
+        self.data, self.pos, self.calls = bytes(data), 0, 0
+        self.chunk = chunk
+
+        def read(_u, buf, size):
+            n = min(size, len(self.data) - self.pos)
+            if self.chunk is not None:
+                n = min(n, max(1, int(self.chunk(self.calls))))
+            self.calls += 1
+            C.memmove(buf, self.data[self.pos:self.pos + n], n)
+            self.pos += n
+            return n
+
+        def skip(_u, n):
+            self.pos = min(len(self.data), max(0, self.pos + n))
+
+        def eof(_u):
+            return 1 if self.pos >= len(self.data) else 0
+
+        self.cb = IoCallbacks(_READ_CB(read), _SKIP_CB(skip), _EOF_CB(eof))
+
+
+def stbi_load_from_callbacks(data, req_comp=0, chunk=None):
+    """stbi_load_from_callbacks over an in-memory source with (optionally) short reads; result as stbi_load_from_memory."""
+    L = lib()
+    L.stbi_load_from_callbacks.restype = C.POINTER(C.c_ubyte)
+    L.stbi_load_from_callbacks.argtypes = [C.POINTER(IoCallbacks), C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
+    src = _CallbackSource(data, chunk)
+    x, y, c = C.c_int(), C.c_int(), C.c_int()
+    p = L.stbi_load_from_callbacks(C.byref(src.cb), None, C.byref(x), C.byref(y), C.byref(c), int(req_comp))
+    if not p:
+        return None
+    n = req_comp if req_comp else c.value
+    return _take(p, (y.value, x.value, n), np.uint8), x.value, y.value, c.value
+
+
+def stbi_info_from_callbacks(data, chunk=None):
+    L = lib()
+    L.stbi_info_from_callbacks.argtypes = [C.POINTER(IoCallbacks), C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    src = _CallbackSource(data, chunk)
+    x, y, c = C.c_int(), C.c_int(), C.c_int()
+    ok = L.stbi_info_from_callbacks(C.byref(src.cb), None, C.byref(x), C.byref(y), C.byref(c))
+    return ok, x.value, y.value, c.value
+
+
+_libc = None
+
+
+def _c_stdio():
+    global _libc
+    if _libc is None:
+        _libc = C.CDLL(None)
+        _libc.fopen.restype = C.c_void_p
+        _libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+        _libc.fclose.argtypes = [C.c_void_p]
+        _libc.ftell.restype = C.c_long
+        _libc.ftell.argtypes = [C.c_void_p]
+        _libc.fseek.argtypes = [C.c_void_p, C.c_long, C.c_int]
+    return _libc
+
+
+def stbi_load_from_file(filename, req_comp=0, offset=0):
+    """fopen + fseek(offset) + stbi_load_from_file + ftell: -> (result as stbi_load_from_memory or None, position the
+    FILE* was left at) -- the reference seeks back over what it buffered but did not consume (convert.c:208)."""
+    L, libc = lib(), _c_stdio()
+    L.stbi_load_from_file.restype = C.POINTER(C.c_ubyte)
+    L.stbi_load_from_file.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
+    f = libc.fopen(os.fsencode(filename), b"rb")
+    if not f:
+        raise OSError("fopen failed: %s" % filename)
+    try:
+        libc.fseek(f, offset, 0)
+        x, y, c = C.c_int(), C.c_int(), C.c_int()
+        p = L.stbi_load_from_file(f, C.byref(x), C.byref(y), C.byref(c), int(req_comp))
+        pos = libc.ftell(f)
+        if not p:
+            return None, pos
+        n = req_comp if req_comp else c.value
+        return (_take(p, (y.value, x.value, n), np.uint8), x.value, y.value, c.value), pos
+    finally:
+        libc.fclose(f)
+
+
+def stbi_info_from_file(filename, offset=0):
+    """-> ((ok, w, h, comp), position afterwards): stbi_info_from_file restores the position (image_api.c:85-94)."""
+    L, libc = lib(), _c_stdio()
+    L.stbi_info_from_file.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    f = libc.fopen(os.fsencode(filename), b"rb")
+    if not f:
+        raise OSError("fopen failed: %s" % filename)
+    try:
+        libc.fseek(f, offset, 0)
+        x, y, c = C.c_int(), C.c_int(), C.c_int()
+        ok = L.stbi_info_from_file(f, C.byref(x), C.byref(y), C.byref(c))
+        return (ok, x.value, y.value, c.value), libc.ftell(f)
+    finally:
+        libc.fclose(f)
+
+
+def stbi_info(filename):
+    L = lib()
+    L.stbi_info.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    x, y, c = C.c_int(), C.c_int(), C.c_int()
+    ok = L.stbi_info(os.fsencode(filename), C.byref(x), C.byref(y), C.byref(c))
+    return ok, x.value, y.value, c.value
+
+
+def stbi_write_jpg(filename, pixels, quality=90):
+    """stbi_write_jpg(filename, ...) (codec/jpeg_write.c:376-388); returns its int result."""
+    a = np.ascontiguousarray(pixels, dtype=np.uint8)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    h, w, comp = a.shape
+    L = lib()
+    L.stbi_write_jpg.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    return L.stbi_write_jpg(os.fsencode(filename), w, h, comp, a.ctypes.data_as(C.c_void_p), int(quality))
+
+
 _WRITE_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int)
 
 
@@ -554,6 +688,31 @@ class Batch:
         if self._h:
             lib().mij_batch_destroy(self._h)
             self._h = C.c_void_p()
+
+
+def decode_jpegs_multi(batches, datas, req_comp=0, threads=1):
+    """mjh_decode_batch_multi: one logical batch sliced over several mij batches (one per device context), host
+    walk on a shared pool, every batch submitted as soon as its slice is walked.  -> (n_ok, owner, slots, reasons)."""
+    L = lib()
+    n, nb = len(datas), len(batches)
+    L.mjh_decode_batch_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int,
+                                         C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_char_p)]
+    hs = (C.c_void_p * nb)(*[b._h for b in batches])
+    bufs = (C.c_char_p * n)(*[bytes(d) for d in datas])
+    lens = (C.c_int * n)(*[len(d) for d in datas])
+    owner, slots, reasons = (C.c_int * n)(), (C.c_int * n)(), (C.c_char_p * n)()
+    rc = L.mjh_decode_batch_multi(hs, nb, bufs, lens, n, int(req_comp), int(threads), owner, slots, reasons)
+    if rc < 0:
+        raise MijError("mjh_decode_batch_multi: %d %s" % (rc, L.mij_last_error().decode()))
+    for i in range(n):
+        sl = slots[i]
+        real = sl if sl >= 0 else (-1 - sl if sl < -1 else None)
+        if real is not None:
+            b = batches[owner[i]]
+            while len(b.descs) <= real:
+                b.descs.append(None)
+            b.descs[real] = (datas[i], req_comp)
+    return rc, list(owner), list(slots), [r.decode() if r else None for r in reasons]
 
 
 class PinnedBuffer:

@@ -301,9 +301,16 @@ int mjh_decode_batch_gpu_end(mjh_gpu_job *j)
 			if (p->slots[i] >= 0)
 				img_of_slot[p->slots[i]] = i;
 		for (i = 0; i < n_fb; ++i) {
-			if ((rc = mij_batch_fallback_prepare(p->b, j->fb[i])) != MIJ_OK) /* no staging planes left for the host walk */
-				goto out;
-			j->todo[img_of_slot[j->fb[i]]] = 1;
+			const int img = img_of_slot[j->fb[i]];
+			if (mij_batch_fallback_prepare(p->b, j->fb[i]) != MIJ_OK) {
+				/* no staging planes left for the host walk of this one image: it alone fails, the batch goes on */
+				mij_batch_set_flags(p->b, j->fb[i], MIJ_FLAG_SKIP);
+				p->reasons[img] = "outofmem";
+				p->slots[img] = -1 - j->fb[i];
+				p->status[img] = 0;
+				continue;
+			}
+			j->todo[img] = 1;
 		}
 	}
 	for (i = 0; i < p->n; ++i)
@@ -332,4 +339,141 @@ int mjh_decode_batch_gpu(mij_batch *b, const uint8_t *const *bufs, const int *le
 		return rc;
 	}
 	return mjh_decode_batch_gpu_end(j);
+}
+
+/* ------------------------------------------------------------------ one logical batch over several devices
+ *
+ * BASELINE config 3 / north_star: "a batch of independent images is sharded across the 8 GPUs of one node on
+ * separate HIP streams (embarrassingly parallel, so no RCCL)".  Decoder state is per call in the reference
+ * (stbi__jpeg is malloc'd per image, codec/jpeg.c:2445), so image i simply goes to batch
+ * owner(i) = the contiguous slice it falls into; every batch has its own context (device), stream and arenas, the
+ * host threads are one shared pool.  Slices are walked in order, and the thread that finishes the last image of a
+ * slice submits that batch at once: device k uploads and decodes while the pool walks slice k+1.
+ */
+typedef struct {
+	pool_t p;            /* b unused: per image batches below */
+	mij_batch *const *batches;
+	const int *owner;
+	int n_batches;
+	int *remaining;      /* per batch: images not yet walked */
+	int *submit_rc;      /* per batch: result of its submit */
+} multi_t;
+
+static void *multi_worker(void *arg)
+{
+	multi_t *m = (multi_t *)arg;
+	pool_t *p = &m->p;
+	int good = 0;
+	for (;;) {
+		int i, slot, k, last;
+		const char *why = NULL;
+		mij_image_desc d;
+		pthread_mutex_lock(&p->lock);
+		i = p->next++;
+		pthread_mutex_unlock(&p->lock);
+		if (i >= p->n)
+			break;
+		k = m->owner[i];
+		slot = p->slots[i];
+		if (slot >= 0) {
+			mij_batch *b = m->batches[k];
+			int16_t *arena = mij_batch_coef(b, slot, 0);
+			size_t elems;
+			d = p->descs[i];
+			elems = mij_image_coef_bytes(&d) / sizeof(int16_t);
+			if (arena && mjh_decode_memory(p->bufs[i], p->lens[i], p->req_comp, &d, arena, elems, &why)) {
+				if (d.flags)
+					mij_batch_set_flags(b, slot, d.flags);
+				if (d.color != p->descs[i].color)
+					mij_batch_set_color(b, slot, d.color);
+				++good;
+			} else {
+				mij_batch_set_flags(b, slot, MIJ_FLAG_SKIP);
+				p->reasons[i] = why ? why : "decode failed";
+				p->slots[i] = -1 - slot;
+			}
+		}
+		pthread_mutex_lock(&p->lock);
+		last = --m->remaining[k] == 0;
+		pthread_mutex_unlock(&p->lock);
+		if (last && mij_batch_image_count(m->batches[k]) > 0)
+			m->submit_rc[k] = mij_batch_submit(m->batches[k]); /* asynchronous on that batch's own stream */
+	}
+	pthread_mutex_lock(&p->lock);
+	p->ok += good;
+	pthread_mutex_unlock(&p->lock);
+	return NULL;
+}
+
+int mjh_decode_batch_multi(mij_batch *const *batches, int n_batches, const uint8_t *const *bufs, const int *lens, int n, int req_comp, int threads,
+									int *owner, int *slots, const char **reasons)
+{
+	multi_t m;
+	pool_t *p = &m.p;
+	int i, k, rc = MIJ_OK;
+	if (!batches || n_batches < 1 || n_batches > 64 || !bufs || !lens || !owner || !slots || !reasons || n < 0)
+		return MIJ_E_ARG;
+	for (k = 0; k < n_batches; ++k)
+		if (!batches[k])
+			return MIJ_E_ARG;
+	if (threads < 1)
+		threads = 1;
+	if (threads > 256)
+		threads = 256;
+	memset(&m, 0, sizeof m);
+	p->descs = (mij_image_desc *)malloc(sizeof(mij_image_desc) * (size_t)(n > 0 ? n : 1));
+	m.remaining = (int *)calloc((size_t)n_batches, sizeof(int));
+	m.submit_rc = (int *)calloc((size_t)n_batches, sizeof(int));
+	if (!p->descs || !m.remaining || !m.submit_rc) {
+		rc = MIJ_E_NOMEM;
+		goto out;
+	}
+	/* contiguous slices, sizes differing by at most one (the same rule as image-codecs_amd/sharding.py shard_range);
+	 * headers in input order, so slot assignment inside every batch is deterministic */
+	{
+		const int base = n / n_batches, rem = n % n_batches;
+		int lo = 0;
+		for (k = 0; k < n_batches; ++k) {
+			const int cnt = base + (k < rem ? 1 : 0);
+			for (i = lo; i < lo + cnt; ++i)
+				owner[i] = k;
+			m.remaining[k] = cnt;
+			lo += cnt;
+		}
+	}
+	for (i = 0; i < n; ++i) {
+		const char *why = NULL;
+		reasons[i] = NULL;
+		if (!mjh_probe_memory(bufs[i], lens[i], req_comp, &p->descs[i], &why)) {
+			slots[i] = -1;
+			reasons[i] = why;
+			continue;
+		}
+		slots[i] = mij_batch_add_uncleared(batches[owner[i]], &p->descs[i]);
+		if (slots[i] < 0) {
+			rc = slots[i];
+			goto out;
+		}
+	}
+	p->bufs = bufs;
+	p->lens = lens;
+	p->n = n;
+	p->req_comp = req_comp;
+	p->slots = slots;
+	p->reasons = reasons;
+	m.batches = batches;
+	m.owner = owner;
+	m.n_batches = n_batches;
+	pthread_mutex_init(&p->lock, NULL);
+	run_pool(p, multi_worker, threads);
+	pthread_mutex_destroy(&p->lock);
+	rc = p->ok;
+	for (k = 0; k < n_batches; ++k)
+		if (m.submit_rc[k] != MIJ_OK)
+			rc = m.submit_rc[k];
+out:
+	free(p->descs);
+	free(m.remaining);
+	free(m.submit_rc);
+	return rc;
 }

@@ -52,6 +52,19 @@ int mjh_extract_scan(const uint8_t *buf, int len, int req_comp, mjg_scan *scan, 
  */
 int mjh_decode_batch(mij_batch *b, const uint8_t *const *bufs, const int *lens, int n, int req_comp, int threads, int *slots, const char **reasons);
 
+/*
+ * One logical batch over several devices (BASELINE config 3; north_star: "sharded across the 8 GPUs of one node on
+ * separate HIP streams ... no RCCL"): batches[k] belongs to device k's context (any contexts will do -- two on one
+ * device is what the single-GPU test uses), image i goes to owner[i] = the k-th of n_batches contiguous slices (sizes
+ * differing by at most one), slots[i] / reasons[i] as above, relative to that batch.  The host threads are one
+ * shared pool; the thread that walks the last image of a slice SUBMITS that batch (upload + kernels, asynchronous on
+ * its own stream), so device k works while slice k+1 is still being walked.  Follow with mij_batch_wait() on every
+ * batch.  Returns the number of images decoded, or a negative MIJ_E_* code.  No collective, no peer traffic: decoder
+ * state is per image (codec/jpeg.c:2445).
+ */
+int mjh_decode_batch_multi(mij_batch *const *batches, int n_batches, const uint8_t *const *bufs, const int *lens, int n, int req_comp, int threads,
+									int *owner, int *slots, const char **reasons);
+
 /* The same contract with the Huffman walk on the GPU where it applies (mij_batch_entropy_reserve must have
  * been called, otherwise this is mjh_decode_batch): the host threads only parse headers and remove byte
  * stuffing, mij_batch_entropy_run walks the streams, and whatever it does not take or refuses is walked on

@@ -11,6 +11,14 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "spawns_gpu_children: starts child processes that use the GPU; runs before any test that "
+                                       "initialises the GPU in this process (a process that has must not exec)")
+
+
+def pytest_collection_modifyitems(config, items):
+    first = [it for it in items if it.get_closest_marker("spawns_gpu_children")]
+    rest = [it for it in items if not it.get_closest_marker("spawns_gpu_children")]
+    items[:] = first + rest
 
 
 @pytest.fixture(scope="session")

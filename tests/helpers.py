@@ -343,3 +343,48 @@ def baseline_from_du(plan, du, restart_mcus=0, layout="native"):
                             int(restart_mcus), out.ctypes.data_as(C.c_void_p), cap)
     assert 0 < n <= cap, n
     return out[:n].tobytes()
+
+
+# ---------------------------------------------------------------- round-2 golden additions
+
+GOLDEN_R2 = os.path.join(ROOT, "tests", "golden", "jpeg_golden_r2.npz")
+
+
+class GoldenR2:
+    """tests/golden/jpeg_golden_r2.npz (make_golden_r2.py): late JFIF / Adobe markers, config 1, FILE* positions."""
+
+    def __init__(self):
+        self.z = np.load(GOLDEN_R2, allow_pickle=False)
+        self.late_names = bytes(self.z["late_names"]).decode().split("\n")
+        self.filepos_names = bytes(self.z["filepos_names"]).decode().split("\n")
+
+    def late(self, name, req):
+        data = bytes(self.z["late/%s/jpg" % name])
+        k = "late/%s/out%d" % (name, req)
+        if k in self.z:
+            return data, "ok", self.z[k]
+        return data, "fail", bytes(self.z["late/%s/fail%d" % (name, req)]).decode()
+
+    def __getitem__(self, key):
+        return self.z[key]
+
+
+def fnv1a64(a):
+    """FNV-1a 64 of a uint8 array (vectorised: the multiplications by the prime are folded per block of 1)"""
+    h = 1469598103934665603
+    for v in np.ascontiguousarray(a).reshape(-1).tolist():
+        h = ((h ^ v) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+# read() sizes of the k-th callback for the stbi_load_from_callbacks tests (and make_golden_r2.py, which records what
+# the real reference does under each).  The reference rewinds to the FIRST buffer it read after its type test
+# (stbi__rewind; common.c:10-26 refills in place), so a first read shorter than the two SOI bytes makes it fail with
+# "no SOI" -- behaviour the product reproduces; patterns 3 and 4 pin that.
+CB_PATTERNS = (
+    lambda k: 128 if k == 0 else 1 + (k * 7) % 128,
+    lambda k: 2,
+    lambda k: 128 if k % 3 else 5,
+    lambda k: 1,
+    lambda k: 1 + (k * 7) % 128,
+)

@@ -4,6 +4,8 @@ decoded pixels must equal the oracle's; streams it refuses must come back in the
 import numpy as np
 import pytest
 
+import helpers
+
 pytestmark = pytest.mark.gpu
 
 
@@ -251,7 +253,8 @@ def test_compact_planes_are_the_default(ica, oracle, gpu_ctx):
     datas.append(ica.synth_jpeg(320, 200, 7, 95))                                                         # 4:4:4
     datas.append(ica.stbi_write_jpg_to_memory(rng.integers(0, 256, (120, 160, 3)).astype(np.uint8), 90))   # noise: coefficients beyond a byte
     datas.append(ica.synth_jpeg(96, 96, 9, 10))                                                            # quantisers up to 255
-    datas.append(ica.stbi_write_jpg_to_memory(rng.integers(0, 256, (64, 80)).astype(np.uint8), 95))        # grey
+    plan, du = ica.host_transform(rng.integers(0, 256, (64, 80, 3)).astype(np.uint8), 95)
+    datas.append(helpers.baseline_from_du(plan, du, layout="grey"))                                        # one component
     for req in (3, 4):
         b = ica.Batch(gpu_ctx, len(datas) + 2, 64 << 20, 64 << 20, 64 << 20)
         b.entropy_reserve(8 << 20)
