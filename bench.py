@@ -6,25 +6,37 @@
 
 A *step* is one pass of the GPU hot path -- de-quantise + 8x8 integer IDCT + h2v2 upsample +
 YCbCr->RGB, i.e. everything the reference does between the Huffman walk and the pixel buffer
-(codec/jpeg.c:325-365 dequant, :615-679, :1816-1840, :1976-2018, :2301-2432) -- over one batch of
-synthetic 1920x1080 4:2:0 q=90 JPEGs whose quantised coefficients are ALREADY RESIDENT IN HBM
-when the timed region starts (host Huffman walk + H2D happen before it; see DESIGN.md for the
-PCIe/host-inclusive rate, which is never `value`).  Each rank owns `--images` images (default
-1024 = BASELINE configs[1]) in its own device buffers -- every slot has its own coefficient and
-pixel memory (12.8 GB per GPU >> the 256 MiB Infinity Cache) -- and there is no data-path
-collective: images are independent (weak scaling).  The resident planes of the timed batch are byte-coefficient planes
-written by the (experimental) GPU Huffman walk -- AC coefficients as signed bytes, DC aside: half the coefficient bytes --
-whenever they reproduce, in this very run, the pixels of the north-star pipeline (host walk -> int16 planes); that
-pipeline's own kernel figure is reported beside it as `roofline_int16_planes`, and it is the fallback (MIJ_BENCH_INT16=1
-forces it).  `roofline.achieved` keeps the ALGORITHMIC bytes (int16 coefficients) in the numerator either way.
+(codec/jpeg.c:325-365 dequant, :615-679, :1816-1840, :1976-2018, :2301-2432) -- over the rank's batch of
+synthetic 1920x1080 4:2:0 q=90 JPEGs whose quantised coefficients are ALREADY RESIDENT IN HBM when the
+timed region starts (host Huffman walk + H2D + the device-side pack happen before it; see DESIGN.md for
+the PCIe/host-inclusive rates, which are never `value`).
 
-The one JSON line (rank 0) also carries
-  roofline      the fused kernel against the HBM roofline: algorithmic bytes per launch
-                (2 B x 64 x blocks read + 3 B x pixels written = 12 487 680 B per image) divided by
-                the average launch duration measured HERE with HIP events on the kernel's stream.
-  cpu_baseline  the reference itself (oracle/_ref, compiled in place in the build container and
-                shipped as a .so) -- or, if that .so is absent, our CPU restatement (oracle/) --
-                decoding a bounded sample of the same images on this box's host cores.
+Workload.  N = 1: BASELINE configs[1], 1024 images on the one GPU.  N > 1: BASELINE configs[2], ONE logical
+batch of 4096 images cut into contiguous slices with image-codecs_amd/sharding.shard_range -- rank r owns
+images [lo, hi) -- and no data-path collective: images are independent (decoder state is per image,
+codec/jpeg.c:2445).  Every slot has its own coefficient and pixel memory (>= 6 GB per GPU >> the 256 MiB
+Infinity Cache).  The planes are in the library's DEFAULT format -- compact planes with escape bytes
+(include/mij.h) -- produced here by the north-star pipeline: host Huffman walk -> int16 staging -> H2D ->
+k_pack_c8.  No environment knob is involved.  Every owned image is verified before the timed region: the
+distinct sources by hash against the int16 pipeline (and, on rank 0 at N = 1, byte for byte against the
+reference itself in the cpu_baseline leg), every further image by a device-side comparison with its source.
+
+`roofline.achieved` keeps the ALGORITHMIC bytes of SURVEY.md 8(d) in the numerator (int16 coefficients,
+12 487 680 B per image); `roofline.traffic` / `hbm_counter_frac` are what the HBM counters saw (fewer bytes:
+compact planes), from the rocprofv3 --pmc passes committed under profiles/ (tools/profile.sh).
+
+The one JSON line (rank 0) also carries, all OUTSIDE the timed region and only at N = 1:
+  legs.int16_planes     the same kernel family on int16 tile-layout planes
+  legs.harsh_batch      1024 images of a harsher declared content (noise&63 + 24 inverted rectangles per image,
+                        image-codecs_amd/synth.synth_rgb_edges): escaped blocks in most wavefronts
+  legs.config4          BASELINE configs[3]: 32 x 4096x4096 progressive 4:4:4 (k_fused444), 9 B/px
+  legs.config5          BASELINE configs[4]: 1024 x 1080p RGB -> data units (k_encode420), bytes == reference
+  legs.h2v1             512 x 1080p 4:2:2 (k_fused422), 7 B/px
+  end_to_end            bitstream in host RAM -> pixels in HBM (host walk; GPU walk), never `value`
+  cpu_baseline          the reference itself (oracle/_ref, compiled in place in the build container and shipped
+                        as a .so; "reference") -- or, when that .so is absent (clean checkout), our CPU
+                        restatement (oracle/, "port") -- on this box's host cores, same images, pixels compared.
+A failing leg reports its error inside the line; it never costs the headline.
 """
 import argparse
 import ctypes as C
@@ -41,6 +53,7 @@ sys.path.insert(0, ROOT)
 W, H = 1920, 1080
 ALGO_BYTES_PER_IMAGE = 2 * 64 * 48960 + 3 * W * H  # 6 266 880 + 6 220 800
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+CONFIG3_TOTAL = 4096   # BASELINE configs[2]
 
 
 def usable_cores():
@@ -65,19 +78,40 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(datas, want_seconds=12.0, gpu_pixels=None):
-    """Times the CPU checker on a bounded sample (all host cores, one image per task); with gpu_pixels(i) it also
-    acts as what it is -- the checker: its pixels for every distinct image must equal the GPU's."""
+def cpu_checker():
+    """(library, kind): the reference compiled in place when its .so travelled, our CPU restatement otherwise."""
     ref_so = os.path.join(ROOT, "oracle", "_ref", "libstbref.so")
     port_so = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
     if os.path.exists(ref_so):
-        L, fn, kind = C.CDLL(ref_so), "ref_decode_many", "reference"
-    else:
-        if not os.path.exists(port_so):
-            import subprocess
-            subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "port"], check=True)
-        L, fn, kind = C.CDLL(port_so), "orc_decode_many", "port"
-    f = getattr(L, fn)
+        return C.CDLL(ref_so), "reference"
+    if not os.path.exists(port_so):
+        import subprocess
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "port"], check=True)
+    return C.CDLL(port_so), "port"
+
+
+def cpu_decode(L, kind, data, req=3):
+    load = L.stbi_load_from_memory if kind == "reference" else L.orc_load_from_memory
+    load.restype = C.POINTER(C.c_ubyte)
+    ints = [C.POINTER(C.c_int)] * 3
+    load.argtypes = [C.c_char_p, C.c_int] + ints + [C.c_int] + ([C.POINTER(C.c_char_p)] if kind == "port" else [])
+    x, y, c = C.c_int(), C.c_int(), C.c_int()
+    extra = [C.byref(C.c_char_p())] if kind == "port" else []
+    ptr = load(data, len(data), C.byref(x), C.byref(y), C.byref(c), req, *extra)
+    if not ptr:
+        return None
+    out = np.ctypeslib.as_array(ptr, shape=(y.value * x.value * req,)).copy()
+    free = L.stbi_image_free if kind == "reference" else L.orc_free
+    free.argtypes = [C.c_void_p]
+    free(ptr)
+    return out
+
+
+def cpu_baseline(datas, want_seconds=12.0, gpu_pixels=None):
+    """Times the CPU checker on a bounded sample (all host cores, one image per task); with gpu_pixels(i) it also
+    acts as what it is -- the checker: its pixels for every distinct image must equal the GPU's."""
+    L, kind = cpu_checker()
+    f = getattr(L, "ref_decode_many" if kind == "reference" else "orc_decode_many")
     f.restype = C.c_long
     f.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
     n = len(datas)
@@ -87,8 +121,7 @@ def cpu_baseline(datas, want_seconds=12.0, gpu_pixels=None):
     cores = usable_cores()
     # single thread, one pass over the sample
     px1 = f(bufs, lens, n, 1, 1, 3, C.byref(secs))
-    t1 = secs.value
-    single = px1 / t1 / 1e6
+    single = px1 / secs.value / 1e6
     # all usable cores: calibrate with a short run, then size the real one for ~want_seconds of wall time
     cal_reps = max(1, (2 * cores + n - 1) // n)
     f(bufs, lens, n, cal_reps, cores, 3, C.byref(secs))
@@ -96,19 +129,7 @@ def cpu_baseline(datas, want_seconds=12.0, gpu_pixels=None):
     px = f(bufs, lens, n, reps, cores, 3, C.byref(secs))
     parity = None
     if gpu_pixels is not None:
-        load = L.stbi_load_from_memory if kind == "reference" else L.orc_load_from_memory
-        load.restype = C.POINTER(C.c_ubyte)
-        ints = [C.POINTER(C.c_int)] * 3
-        load.argtypes = [C.c_char_p, C.c_int] + ints + [C.c_int] + ([C.POINTER(C.c_char_p)] if kind == "port" else [])
-        parity = True
-        for i, d in enumerate(datas):
-            x, y, c = C.c_int(), C.c_int(), C.c_int()
-            extra = [C.byref(C.c_char_p())] if kind == "port" else []
-            ptr = load(d, len(d), C.byref(x), C.byref(y), C.byref(c), 3, *extra)
-            cpu = np.ctypeslib.as_array(ptr, shape=(y.value * x.value * 3,))
-            if not np.array_equal(cpu, gpu_pixels(i).reshape(-1)):
-                parity = False
-            (L.stbi_image_free if kind == "reference" else L.orc_free)(ptr)
+        parity = all(np.array_equal(cpu_decode(L, kind, d), gpu_pixels(i).reshape(-1)) for i, d in enumerate(datas))
         assert parity, "GPU pixels differ from the CPU checker's"
     model = None
     try:
@@ -131,9 +152,227 @@ def cpu_baseline(datas, want_seconds=12.0, gpu_pixels=None):
     }
 
 
+# ---------------------------------------------------------------------------------------------------- resident batches
+
+def resident_batch(ica, ctx, datas, first, count, fmt, cbytes, obytes):
+    """Images first .. first+count-1 of the logical batch (image g uses source g % len(datas)) resident in HBM in the
+    given plane format: the first occurrence of every source is host-walked into pinned staging, the others are clones
+    with their own device buffers.  -> (batch, (source index, source slot or None) of every slot, seconds of host walk)"""
+    distinct = len(datas)
+    bt = ica.Batch(ctx, count, cbytes * min(distinct, count), cbytes * count, obytes * count)
+    bt.set_coef_format(fmt)
+    src_slot, owners = {}, []
+    t0 = time.time()
+    for i in range(count):
+        k = (first + i) % distinct
+        if k not in src_slot:
+            src_slot[k] = bt.add_jpeg(datas[k], 3)  # host Huffman walk straight into pinned staging
+            owners.append((k, None))
+        else:
+            bt.add_clone(src_slot[k])  # own device buffers, filled device-to-device
+            owners.append((k, src_slot[k]))
+    dt = time.time() - t0
+    bt.upload()
+    bt.wait()
+    return bt, owners, dt
+
+
+def verify_batch(batch, owners, src_hash):
+    """Every image of the batch: sources by hash, clones by a device-side comparison with their source."""
+    pairs = []
+    for slot, (k, src) in enumerate(owners):
+        if src is None:
+            assert batch.hash_out(slot) == src_hash[k], "source image %d differs from the reference pipeline's pixels" % k
+        else:
+            pairs.append((slot, src))
+    for lo in range(0, len(pairs), 256):
+        bad = batch.diff_slots(pairs[lo:lo + 256])
+        assert bad == 0, "%d words of cloned images differ from their source" % bad
+    return len(owners)
+
+
+def warm(bt, launches, settle_ms):
+    t_w = time.perf_counter()
+    k = 0
+    while k < max(1, launches) or (time.perf_counter() - t_w) * 1e3 < settle_ms:
+        bt.launch()
+        k += 1
+        if k % 8 == 0:
+            bt.wait()  # bound the queue depth while watching the wall clock
+    bt.wait()
+    return k
+
+
+def timed_launches(bt, steps):
+    """kernel ms per launch over exactly `steps` launches, HIP events on the batch's own stream"""
+    bt.timer_begin()
+    for _ in range(steps):
+        bt.launch()
+    bt.timer_end()
+    bt.wait()
+    return bt.timer_ms() / steps
+
+
+def frac_of(algo_bytes, ms):
+    return algo_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+
+
+def traffic_entry(key):
+    """profiles/traffic.json[key] = {"hbm_bytes_per_launch": ..., "source": ...} from the committed rocprofv3 --pmc passes"""
+    try:
+        e = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key)
+        if isinstance(e, dict) and "hbm_bytes_per_launch" in e:
+            return e
+    except Exception:  # noqa: BLE001
+        pass
+    return None
+
+
+def add_traffic(res, key):
+    t = traffic_entry(key)
+    res["traffic"] = t["hbm_bytes_per_launch"] if t else None
+    res["traffic_source"] = ("profiles/traffic.json[%s]: %s" % (key, t.get("source", "rocprofv3 --pmc passes"))) if t else \
+        "not measured for this launch shape (profiles/traffic.json has no entry %s)" % key
+    res["hbm_counter_frac"] = round(t["hbm_bytes_per_launch"] / (res["kernel_ms_per_launch"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if t else None
+
+
+# ---------------------------------------------------------------------------------------------------- secondary legs
+
+def leg_decode_1080p(ica, ctx, datas, count, fmt, cbytes, obytes, args, expect_path=1, src_hash=None, checker=None):
+    """Kernel-resident timing of `count` 1080p images in the given plane format; returns (result dict, plane format seen)."""
+    bt, owners, _ = resident_batch(ica, ctx, datas, 0, count, fmt, cbytes, obytes)
+    try:
+        bt.launch()
+        bt.wait()
+        assert {bt.slot_path(s) for s in range(count)} == {expect_path}
+        if src_hash is None:  # this leg's own sources: against the CPU checker (the reference itself when its .so travelled)
+            L, kind = checker
+            src_hash = []
+            for k, d in enumerate(datas):
+                slot = next(s for s, (kk, src) in enumerate(owners) if kk == k and src is None)
+                assert np.array_equal(bt.fetch(slot).reshape(-1), cpu_decode(L, kind, d)), "source %d differs from the CPU checker" % k
+                src_hash.append(bt.hash_out(slot))
+        verify_batch(bt, owners, src_hash)
+        n_warm = warm(bt, args.warmup, args.settle_ms)
+        ms = timed_launches(bt, args.steps)
+        esc = sum(bt.slot_escapes(s) for s, (k, src) in enumerate(owners) if src is None) if fmt == "compact" else 0
+        return {"kernel_ms_per_launch": round(ms, 4), "images": count, "warmup_launches_issued": n_warm, "parity": True,
+                "escaped_blocks_in_sources": esc}, bt.slot_coef_bytes(0)
+    finally:
+        bt.close()
+
+
+def leg_config4(ica, ctx, args, checker):
+    """BASELINE configs[3] at a reduced batch: 32 x 4096x4096 progressive 4:4:4, planes re-staged over ten scans on the
+    host, packed on the device, k_fused444 timed resident.  Algorithmic 9 B/px."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers
+    n, size = args.config4_images, 4096
+    t0 = time.time()
+    plan, du = ica.host_transform(ica.synth_rgb(size, size, 1), 95)  # quality > 90 -> 4:4:4
+    data = helpers.progressive_from_du(plan, du, 1)
+    d = ica.HostDecoder.probe(data, 3)
+    cb, ob = ica.Batch.coef_bytes(d), ica.Batch.out_bytes(d)
+    b = ica.Batch(ctx, n, cb, cb * n, ob * n)
+    try:
+        th = time.time()
+        s0 = b.add_jpeg(data, 3)
+        host_s = time.time() - th
+        for _ in range(n - 1):
+            b.add_clone(s0)
+        b.upload()
+        b.launch()
+        b.wait()
+        assert b.slot_path(0) == 3, b.slot_path(0)
+        L, kind = checker
+        assert np.array_equal(b.fetch(0).reshape(-1), cpu_decode(L, kind, data)), "config 4 pixels differ from the CPU checker"
+        assert b.diff_slots([(s, 0) for s in range(1, n)]) == 0
+        n_warm = warm(b, args.warmup, args.settle_ms)
+        ms = timed_launches(b, args.steps)
+        blocks = 3 * d.comp[0].bw * d.comp[0].bh
+        algo = n * (128 * blocks + 3 * size * size)
+        res = {"workload": "%d x %dx%d progressive 4:4:4 (10 scans, %d bytes each), coefficients resident" % (n, size, size, len(data)),
+               "kernel": "mij::k_fused444<3,false,%s>" % ("true" if b.slot_coef_bytes(0) else "false"), "kernel_ms_per_launch": round(ms, 4),
+               "algorithmic_bytes_per_launch": algo, "mpix_s": round(n * size * size / ms / 1e3, 1), "frac": round(frac_of(algo, ms), 4),
+               "parity": True, "parity_against": kind, "warmup_launches_issued": n_warm,
+               "host_progressive_stage_mpix_s_single_thread": round(size * size / host_s / 1e6, 1), "setup_s": round(time.time() - t0, 1)}
+        add_traffic(res, "k_fused444_compact_%d" % n)
+        return res
+    finally:
+        b.close()
+
+
+def leg_config5(ica, ctx, args, checker):
+    """BASELINE configs[4]: 1024 x 1080p RGB -> quantised data units (k_encode420); the byte streams of the distinct
+    images equal the CPU checker's (the reference's own writer when its .so travelled)."""
+    n, distinct = args.images, 4
+    imgs = [ica.synth_rgb(W, H, s) for s in range(distinct)]
+    pix = (W * H * 3 + 255) // 256 * 256
+    dub = (120 * 68 * 6 * 128 + 255) // 256 * 256
+    enc = ica.Encoder(ctx, n, pix * n, dub * n)
+    try:
+        src = [enc.add(im, 90) for im in imgs]
+        for i in range(distinct, n):
+            enc.add_clone(src[i % distinct])
+        enc.upload()
+        enc.launch()
+        enc.wait()
+        L, kind = checker
+        fenc = L.ref_encode if kind == "reference" else L.orc_encode
+        fenc.restype = C.c_long
+        fenc.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        for k, im in enumerate(imgs):
+            mine = ica.emit_jpeg(enc.plan(src[k]), enc.fetch(src[k]))
+            buf = np.zeros(W * H * 2, np.uint8)
+            nb = fenc(buf.ctypes.data, buf.size, W, H, 3, np.ascontiguousarray(im).ctypes.data, 90)
+            assert nb > 0 and mine == bytes(buf[:nb]), "encoded stream %d differs from the CPU checker's" % k
+        assert np.array_equal(enc.fetch(n - 1), enc.fetch(src[(n - 1) % distinct]))
+        n_warm = 0
+        t_w = time.perf_counter()
+        while n_warm < max(1, args.warmup) or (time.perf_counter() - t_w) * 1e3 < args.settle_ms:
+            enc.launch()
+            n_warm += 1
+            if n_warm % 8 == 0:
+                enc.wait()
+        enc.wait()
+        enc.timer_begin()
+        for _ in range(args.steps):
+            enc.launch()
+        enc.timer_end()
+        ms = enc.timer_ms() / args.steps
+        algo = n * (W * H * 3 + 120 * 68 * 6 * 128)
+        res = {"workload": "%d x 1920x1080 RGB -> 4:2:0 q=90 data units, pixels resident" % n, "kernel": "mij::k_encode420",
+               "kernel_ms_per_launch": round(ms, 4), "algorithmic_bytes_per_launch": algo, "mpix_s": round(n * W * H / ms / 1e3, 1),
+               "frac": round(frac_of(algo, ms), 4), "parity": True, "parity_against": kind + " (byte streams of the %d distinct images)" % distinct,
+               "warmup_launches_issued": n_warm}
+        add_traffic(res, "k_encode420_%d" % n)
+        return res
+    finally:
+        enc.close()
+
+
+def leg_h2v1(ica, ctx, args, checker):
+    """512 x 1080p 4:2:2 (h2v1) through k_fused422; algorithmic 7 B/px."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers
+    n = args.h2v1_images
+    plan, du = ica.host_transform(ica.synth_rgb(W, H, 1), 95)
+    data = helpers.baseline_from_du(plan, du, layout="422")
+    d = ica.HostDecoder.probe(data, 3)
+    cb, ob = ica.Batch.coef_bytes(d), ica.Batch.out_bytes(d)
+    res, fmt = leg_decode_1080p(ica, ctx, [data], n, "compact", cb, ob, args, expect_path=4, checker=checker)
+    blocks = sum(d.comp[c].bw * d.comp[c].bh for c in range(3))
+    algo = n * (128 * blocks + 3 * W * H)
+    ms = res["kernel_ms_per_launch"]
+    res.pop("escaped_blocks_in_sources", None)
+    res.update({"workload": "%d x 1920x1080 baseline 4:2:2, coefficients resident" % n, "kernel": "mij::k_fused422<3,false,%s>" % ("true" if fmt else "false"),
+                "algorithmic_bytes_per_launch": algo, "mpix_s": round(n * W * H / ms / 1e3, 1), "frac": round(frac_of(algo, ms), 4), "parity_against": checker[1]})
+    add_traffic(res, "k_fused422_compact_%d" % n)
+    return res
+
+
 def end_to_end(ica, ctx, datas, distinct, n_img, src_hash, cbytes, obytes, args):
     """Outside the timed region (rank 0, one GPU): bitstream in host RAM -> RGB in HBM, three ways."""
-    e2e = None
     n_e = min(args.e2e_images, n_img)
     threads = usable_cores()
     chunk = max(1, min(64, n_e // 2))
@@ -170,7 +409,7 @@ def end_to_end(ica, ctx, datas, distinct, n_img, src_hash, cbytes, obytes, args)
         "host_threads": threads,
         "chunk_images": chunk,
         "host_stage_only_mpix_s": round(n_e * W * H / t_host / 1e6, 1),
-        "includes": "Huffman walk on the host threads -> pinned staging -> H2D -> fused kernel, two batches ping-pong; pixels left in HBM",
+        "includes": "Huffman walk on the host threads -> pinned staging -> H2D -> pack -> fused kernel, two batches ping-pong; pixels left in HBM",
     }
     # the same pipeline with the pixels brought back to (pinned) host memory: one asynchronous D2H of the
     # chunk's output arena queued behind its kernels, completed when the batch is reused
@@ -192,9 +431,9 @@ def end_to_end(ica, ctx, datas, distinct, n_img, src_hash, cbytes, obytes, args)
         got = pins[side].array[off:off + W * H * 3]
         assert np.array_equal(got, ebs[side].fetch(slot).reshape(-1)), "D2H copy differs from the device image"
     e2e["value_with_d2h"] = round(n_e * W * H / t_d2h / 1e6, 1)
-    # experimental: the Huffman walk itself on the GPU (mjh_decode_batch_gpu): the host threads only parse
-    # headers and remove byte stuffing, 0.45 MB of bitstream per image crosses PCIe instead of 6.3 MB of
-    # coefficients; images the GPU walk refuses are walked on the host
+    # the Huffman walk itself on the GPU (mjh_decode_batch_gpu): the host threads only parse headers and remove byte
+    # stuffing, 0.45 MB of bitstream per image crosses PCIe instead of 6.3 MB of coefficients; images the GPU walk
+    # refuses are walked on the host
     try:
         for eb in ebs:
             eb.close()
@@ -238,8 +477,8 @@ def end_to_end(ica, ctx, datas, distinct, n_img, src_hash, cbytes, obytes, args)
                 eb.wait()
             return time.perf_counter() - t0
 
-        passes = sorted(one_pass() for _ in range(3))  # the leg takes ~0.1 s: three passes, the median is reported
-        t_gpu = passes[1]
+        passes = [one_pass() for _ in range(3)]  # the leg takes ~0.1 s: three passes, in order; the first follows an idle GPU
+        t_gpu = sorted(passes)[1]
         for side, (img, slot) in last.items():
             assert ebs[side].hash_out(slot) == src_hash[img % distinct], "GPU-walked image differs"
         e2e["value_gpu_entropy"] = round(n_g * W * H / t_gpu / 1e6, 1)
@@ -255,7 +494,6 @@ def end_to_end(ica, ctx, datas, distinct, n_img, src_hash, cbytes, obytes, args)
         pb.close()
     for eb in ebs:
         eb.close()
-
     return e2e
 
 
@@ -265,113 +503,76 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=10,
                     help="untimed launches first: after an idle gap the first ~10 launches run 5-30 %% slower (power management ramp, profiles/r01h trace)")
-    ap.add_argument("--images", type=int, default=1024, help="images per GPU (BASELINE configs[1]: 1024)")
+    ap.add_argument("--images", type=int, default=1024, help="images on the GPU at N = 1 (BASELINE configs[1]: 1024)")
+    ap.add_argument("--total-images", type=int, default=CONFIG3_TOTAL, help="N > 1: size of the ONE logical batch sliced over the ranks (BASELINE configs[2]: 4096)")
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic images cycled to fill the batch")
     ap.add_argument("--settle-ms", type=float, default=25.0,
-                    help="the untimed warm-up lasts at least this long (more launches than --warmup if need be; the number "
+                    help="the settled figure's warm-up lasts at least this long (more launches than --warmup if need be; the number "
                          "issued is reported as config.warmup_launches_issued): after an idle gap launch durations take "
-                         "~25 ms to settle (power management), whatever W says.  0 = exactly --warmup launches")
+                         "~25 ms to settle (power management), whatever W says.  The figure with exactly --warmup launches is "
+                         "reported beside it (roofline.frac_at_requested_warmup)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the (untimed-region) end-to-end measurement")
+    ap.add_argument("--no-legs", action="store_true", help="skip the secondary legs (int16 planes, harsh batch, configs 4 and 5, 4:2:2)")
     ap.add_argument("--e2e-images", type=int, default=512)
+    ap.add_argument("--config4-images", type=int, default=32)
+    ap.add_argument("--h2v1-images", type=int, default=512)
     args = ap.parse_args()
 
     import torch  # device sync + launcher plumbing only
     import image_codecs_amd as ica
-    from image_codecs_amd.sharding import ControlPlane
+    from image_codecs_amd.sharding import ControlPlane, shard_range
 
-    cp = ControlPlane()
+    # MIJ_BENCH_SHARE_DEVICE=1: every rank on device 0 and the control plane over gloo -- the multi-rank path rehearsed on a one-GPU box
+    share = os.environ.get("MIJ_BENCH_SHARE_DEVICE") == "1"
+    cp = ControlPlane(backend="gloo" if share else None)
     if cp.world != args.gpus:
         if cp.rank == 0:
             print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, cp.world), file=sys.stderr)
     if cp.local_rank == 0:
-        ica.build_library()  # a no-op when the in-tree .so exists; never from several ranks at once
+        ica.build_library()  # rebuilds only when a source is newer than the in-tree .so; never from several ranks at once
     cp.barrier()
     if not ica.gpu_available():
         raise SystemExit("bench.py needs a gfx950 GPU: the decode path has no CPU fallback")
-    ctx = ica.Context(cp.local_rank)
+    ctx = ica.Context(0 if share else cp.local_rank)
     arch, cus, mem = ctx.info()
 
-    # ---- inputs: `distinct` synthetic images, encoded by the product's own stbi_write_jpg_to_func
-    n_img = args.images
-    distinct = max(1, min(args.distinct, n_img))
+    # ---- the logical batch and this rank's slice of it
+    total = args.images if cp.world == 1 else args.total_images
+    lo, hi = shard_range(total, cp.rank, cp.world)
+    n_img = hi - lo
+    distinct = max(1, min(args.distinct, max(1, n_img)))
     datas = [ica.synth_jpeg(W, H, seed=s, quality=90) for s in range(distinct)]
     d0 = ica.HostDecoder.probe(datas[0], 3)
     cbytes, obytes = ica.Batch.coef_bytes(d0), ica.Batch.out_bytes(d0)
-    nocheck = bool(os.environ.get("MIJ_BENCH_NOCHECK"))  # ablation builds (tools/ab.sh) write wrong or no pixels on purpose
 
-    def warm(bt):
-        t_w = time.perf_counter()
-        k = 0
-        while k < max(1, args.warmup) or (time.perf_counter() - t_w) * 1e3 < args.settle_ms:
-            bt.launch()
-            k += 1
-            if k % 8 == 0:
-                bt.wait()  # bound the queue depth while watching the wall clock
-        bt.wait()
-        return k
-
-    def int16_batch(count):
-        """North-star pipeline: host Huffman walk -> int16 tile planes -> H2D; `count` images (clones beyond `distinct`)."""
-        bt = ica.Batch(ctx, count, cbytes * distinct, cbytes * count, obytes * count)
-        bt.set_coef_format("int16")
-        t0 = time.time()
-        for d in datas:
-            bt.add_jpeg(d, 3)  # host Huffman walk straight into pinned staging
-        dt = time.time() - t0
-        for i in range(distinct, count):
-            bt.add_clone(i % distinct)  # own device buffers, filled device-to-device
-        bt.upload()
-        bt.wait()
-        return bt, dt
-
-    # reference pixels of the distinct images: host walk, int16 planes
-    ref_batch, host_stage_s = int16_batch(distinct)
+    # ---- reference pixels of the distinct images: host walk -> int16 planes -> fused kernel
+    ref_batch, _, host_stage_s = resident_batch(ica, ctx, datas, 0, distinct, "int16", cbytes, obytes)
     ref_batch.launch()
     ref_batch.wait()
     assert {ref_batch.slot_path(s) for s in range(distinct)} == {1}, "the fused kernel did not take the batch"
     src_hash = [ref_batch.hash_out(s) for s in range(distinct)]
     ref_batch.close()
 
-    # the resident coefficient planes of the timed batch: byte planes written by the GPU Huffman walk (half the
-    # coefficient bytes; experimental) when they reproduce the reference pixels here and now, int16 planes otherwise
-    batch, planes, planes_note = None, "int16", None
-    if not os.environ.get("MIJ_BENCH_INT16"):
-        bb = None
-        try:
-            bb = ica.Batch(ctx, n_img, cbytes * 2, cbytes * n_img, obytes * n_img)
-            bb.entropy_reserve(sum(len(x) * 9 // 8 + 4352 for x in datas))
-            ok, slots, reasons = bb.decode_jpegs(datas, 3, threads=usable_cores(), gpu_entropy=True)
-            if ok != distinct or slots != list(range(distinct)) or not all(bb.slot_coef_bytes(s) for s in slots):
-                raise RuntimeError("the GPU walk did not leave byte planes for every image: %r" % (reasons,))
-            for i in range(distinct, n_img):
-                bb.add_clone(i % distinct)
-            bb.submit()
-            bb.wait()
-            if not nocheck and [bb.hash_out(s) for s in range(distinct)] != src_hash:
-                raise RuntimeError("byte-plane pixels differ from the int16 pipeline's")
-            batch, planes, bb = bb, "bytes", None
-        except Exception as exc:  # noqa: BLE001 -- the experimental format must never cost the benchmark its line
-            planes_note = "%s: %s" % (type(exc).__name__, exc)
-        finally:
-            if bb is not None:
-                bb.close()
-    if batch is None:
-        batch, _ = int16_batch(n_img)
-
-    # ---- parity of what the kernel writes, then the warm-up (untimed) directly in front of the timed region: the
-    # checks below leave the GPU idle for ~0.2 s, after which the first launches run 5-30 % slower again
+    # ---- the timed batch: this rank's slice, default plane format, every image verified
+    batch, owners, _ = resident_batch(ica, ctx, datas, lo, n_img, "compact", cbytes, obytes)
     batch.launch()
     batch.wait()
     paths = {batch.slot_path(s) for s in range(n_img)}
     assert paths == {1}, "the fused kernel did not take the batch: %r" % paths
-    rng = np.random.default_rng(cp.rank)
-    for s in [] if nocheck else list(range(distinct)) + [int(v) for v in rng.integers(distinct, n_img, min(24, max(0, n_img - distinct)))] + ([n_img - 1] if n_img > distinct else []):
-        assert batch.hash_out(s) == src_hash[s % distinct], "image %d differs from the reference pipeline's pixels" % s
+    assert all(batch.slot_coef_bytes(s) == 1 for s in range(min(n_img, 32))), "the batch is not in the default (compact) plane format"
+    n_verified = verify_batch(batch, owners, src_hash)
 
-    n_warm = warm(batch)
+    # ---- (a) exactly --warmup untimed launches, then exactly --steps timed ones: the figure at the requested warm-up
+    cp.barrier()
+    for _ in range(max(0, args.warmup)):
+        batch.launch()
+    batch.wait()
+    ms_requested = timed_launches(batch, args.steps)
 
-    # ---- timed region: exactly K steps, barrier + device sync on both sides
+    # ---- (b) the settled figure: a warm-up of at least --settle-ms directly in front of the timed region;
+    # timed region: exactly K steps, barrier + device sync on both sides
+    n_warm = warm(batch, args.warmup, args.settle_ms)
     cp.barrier()
     torch.cuda.synchronize() if torch.cuda.is_available() else None
     batch.wait()
@@ -388,39 +589,59 @@ def main():
     t_max = cp.max(t_local)
     total_px = cp.sum(float(n_img) * W * H * args.steps)
     kernel_ms_max = cp.max(kernel_ms)
+    ms_requested_max = cp.max(ms_requested)
+    per_rank = cp.gather_floats([float(cp.rank), float(lo), float(hi), kernel_ms, ms_requested, float(n_verified)])
 
-    # ---- outside the timed region: the end-to-end path (bitstream in host RAM -> RGB in HBM), rank 0
-    # ---- outside the timed region: the same kernel family on the north-star pipeline's int16 planes, for comparison
-    int16_cmp = None
-    if planes == "bytes" and cp.rank == 0 and cp.world == 1:
-        try:
-            ib, _ = int16_batch(n_img)
-            warm(ib)
-            ib.timer_begin()
-            for _ in range(args.steps):
-                ib.launch()
-            ib.timer_end()
-            ib.wait()
-            ms16 = ib.timer_ms() / args.steps
-            assert nocheck or ib.hash_out(n_img - 1) == src_hash[(n_img - 1) % distinct]
-            ib.close()
-            int16_cmp = {"kernel": "mij::k_fused420<3,false>", "kernel_ms_per_launch": round(ms16, 4),
-                         "achieved": round(ALGO_BYTES_PER_IMAGE * n_img / (ms16 * 1e-3) / 1e9, 1), "unit": "GB/s",
-                         "frac": round(ALGO_BYTES_PER_IMAGE * n_img / (ms16 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                         "note": "host Huffman walk -> int16 coefficient planes (6 266 880 B per image actually read)"}
-        except Exception as exc:  # noqa: BLE001
-            int16_cmp = {"error": "%s: %s" % (type(exc).__name__, exc)}
-
-    # ---- outside the timed region: the end-to-end path (bitstream in host RAM -> RGB in HBM), rank 0.  It must never
-    # cost the benchmark its JSON line: any failure is reported inside the line instead
-    # The timed batch is done: keep its pixels of the distinct images for the CPU checker and release it -- 12.8 GB and,
-    # more to the point, its stream (a process gets 4 hardware queues; a fifth stream would share one with a batch of the
-    # end-to-end ring below and serialise the two)
-    gpu_px = [batch.fetch(i) for i in range(distinct)] if (cp.rank == 0 and cp.world == 1 and not args.no_cpu_baseline) else None
+    solo = cp.rank == 0 and cp.world == 1
+    gpu_px = [batch.fetch(next(s for s, (kk, src) in enumerate(owners) if kk == k and src is None)) for k in range(distinct)] \
+        if (solo and not args.no_cpu_baseline) else None
+    # release the timed batch before the legs: 12.8 GB and, more to the point, its stream (a process gets 4 hardware
+    # queues; a fifth stream would share one with a batch of the end-to-end ring below and serialise the two)
     batch.close()
     batch = None
-    e2e = None
-    if cp.rank == 0 and cp.world == 1 and not args.no_e2e:
+
+    # ---- outside the timed region, one GPU only: the legs.  A failure is reported inside the line.
+    legs, e2e = {}, None
+
+    def run_leg(name, fn):
+        t0 = time.time()
+        try:
+            legs[name] = fn()
+        except Exception as exc:  # noqa: BLE001
+            legs[name] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        legs[name]["leg_s"] = round(time.time() - t0, 1)
+
+    if solo and not args.no_legs:
+        checker = cpu_checker()
+
+        def int16_leg():
+            res, _ = leg_decode_1080p(ica, ctx, datas, n_img, "int16", cbytes, obytes, args, src_hash=src_hash)
+            ms = res["kernel_ms_per_launch"]
+            res.pop("escaped_blocks_in_sources", None)
+            res.update({"kernel": "mij::k_fused420<3,false,false>", "frac": round(frac_of(ALGO_BYTES_PER_IMAGE * n_img, ms), 4),
+                        "achieved": round(ALGO_BYTES_PER_IMAGE * n_img / (ms * 1e-3) / 1e9, 1), "unit": "GB/s",
+                        "note": "the same images as int16 tile-layout planes (mij_batch_set_coef_format): 6 266 880 B of coefficients per image actually read"})
+            add_traffic(res, "k_fused420_int16_%d" % n_img)
+            return res
+
+        def harsh_leg():
+            hd = [ica.stbi_write_jpg_to_memory(ica.synth_rgb_edges(W, H, seed=s), 90) for s in range(distinct)]
+            res, fmt = leg_decode_1080p(ica, ctx, hd, n_img, "compact", cbytes, obytes, args, checker=checker)
+            ms = res["kernel_ms_per_launch"]
+            res.update({"workload": "%d x 1920x1080 4:2:0 q=90 of synth_rgb_edges(seed 0..%d): noise & 63 + 24 inverted rectangles per image, %.2f bit/px"
+                                    % (n_img, distinct - 1, sum(len(x) for x in hd) * 8.0 / (distinct * W * H)),
+                        "kernel": "mij::k_fused420<3,false,true>", "coefficient_planes": "compact" if fmt else "int16",
+                        "escaped_blocks_pct": round(100.0 * res.pop("escaped_blocks_in_sources") / (distinct * 48960), 3), "host_walk_fallbacks": 0,
+                        "frac": round(frac_of(ALGO_BYTES_PER_IMAGE * n_img, ms), 4), "parity_against": checker[1]})
+            add_traffic(res, "k_fused420_compact_harsh_%d" % n_img)
+            return res
+
+        run_leg("int16_planes", int16_leg)
+        run_leg("harsh_batch", harsh_leg)
+        run_leg("config4", lambda: leg_config4(ica, ctx, args, checker))
+        run_leg("config5", lambda: leg_config5(ica, ctx, args, checker))
+        run_leg("h2v1", lambda: leg_h2v1(ica, ctx, args, checker))
+    if solo and not args.no_e2e:
         try:
             e2e = end_to_end(ica, ctx, datas, distinct, n_img, src_hash, cbytes, obytes, args)
         except Exception as exc:  # noqa: BLE001
@@ -428,16 +649,27 @@ def main():
 
     out = None
     if cp.rank == 0:
-        achieved = ALGO_BYTES_PER_IMAGE * n_img / (kernel_ms_max * 1e-3) / 1e9
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf):
-            try:
-                tj = json.load(open(tf))
-                if tj.get("images_per_launch") == n_img:
-                    traffic = tj.get("hbm_bytes_per_launch_byte_planes" if planes == "bytes" else "hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        algo_launch = ALGO_BYTES_PER_IMAGE * n_img  # rank 0's launch (it owns a largest slice)
+        achieved = algo_launch / (kernel_ms_max * 1e-3) / 1e9
+        ranks = [{"rank": int(r[0]), "images": [int(r[1]), int(r[2])], "kernel_ms_per_launch": round(r[3], 4),
+                  "frac": round(frac_of(ALGO_BYTES_PER_IMAGE * (int(r[2]) - int(r[1])), r[3]), 4) if r[3] > 0 else None,
+                  "kernel_mpix_s": round((int(r[2]) - int(r[1])) * W * H / r[3] / 1e3, 1) if r[3] > 0 else None,
+                  "kernel_ms_at_requested_warmup": round(r[4], 4), "images_verified": int(r[5])} for r in per_rank]
+        roof = {
+            "bound": "hbm",
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "kernel": "mij::k_fused420<3,false,true>",
+            "kernel_ms_per_launch": round(kernel_ms_max, 4),
+            "algorithmic_bytes_per_launch": algo_launch,
+            "frac_at_requested_warmup": round(frac_of(algo_launch, ms_requested_max), 4),
+            "kernel_ms_at_requested_warmup": round(ms_requested_max, 4),
+            "note": "frac = algorithmic bytes (int16 coefficients + RGB8, SURVEY 8d) / time / 8 TB/s; hbm_counter_frac = bytes the TCC counters saw / "
+                    "time / 8 TB/s (fewer: compact planes); at this point the kernel is bound by VALU issue, not by HBM (DESIGN.md 3.1)",
+        }
+        add_traffic(roof, "k_fused420_compact_%d" % n_img)
         out = {
             "metric": "JPEG decode Mpixels/sec, 4:2:0 1080p batch, 1/2/4/8 GPU + %HBM roofline",  # BASELINE.json's string
             "value": round(total_px / t_max / 1e6, 1),
@@ -447,43 +679,39 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(t_max / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if cp.world == 1 else "strong",
             "vs_baseline": None,
             "dtype": "int32 (u8/int16 in, u8 out)",
             "data": "synthetic",
             "config": {
-                "workload": "%d x 1920x1080 baseline 4:2:0 q=90 JPEGs per GPU, coefficients resident in HBM, fused dequant+IDCT+h2v2+YCbCr->RGB8" % n_img,
-                "images_per_gpu": n_img,
+                "workload": (("%d x 1920x1080 baseline 4:2:0 q=90 JPEGs (BASELINE configs[1]) on 1 GPU" % total) if cp.world == 1 else
+                             ("ONE batch of %d x 1920x1080 baseline 4:2:0 q=90 JPEGs (BASELINE configs[2]) cut into %d contiguous slices, one per GPU" % (total, cp.world)))
+                            + ", coefficients resident in HBM, fused dequant+IDCT+h2v2+YCbCr->RGB8",
+                "total_images": total,
+                "slices": [r["images"] for r in ranks],
                 "distinct_images": distinct,
-                "sharding": "independent images, contiguous slices per GPU, no collective",
-                "coefficient_planes": ("bytes: AC coefficients as signed bytes + int16 DC array, written by the GPU Huffman walk (experimental); "
-                                       "pixels verified against the host-walk / int16 pipeline in this run") if planes == "bytes" else "int16 tile layout (host Huffman walk)",
-                "coefficient_planes_note": planes_note,
+                "sharding": "independent images, contiguous slices (sharding.shard_range), one process + one HIP stream per GPU, no collective on the data path",
+                "coefficient_planes": "compact (library default): low bytes + escape bytes + int16 DC array, packed on the device from the host walk's int16 staging",
+                "images_verified_per_rank": [r["images_verified"] for r in ranks],
                 "warmup_launches_issued": n_warm,
+                "settle_ms": args.settle_ms,
                 "device": arch,
                 "compute_units": cus,
+                "note_scaling": None if cp.world == 1 else
+                                "total work is fixed at %d images for every N > 1 (strong); the N = 1 line is BASELINE configs[1], 1024 images" % total,
             },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": traffic,
-                "kernel": "mij::k_fused420<3,false,true>" if planes == "bytes" else "mij::k_fused420<3,false>",
-                "kernel_ms_per_launch": round(kernel_ms_max, 4),
-                "algorithmic_bytes_per_launch": ALGO_BYTES_PER_IMAGE * n_img,
-            },
+            "roofline": roof,
+            "per_rank": ranks,
             "host_stage": {
                 "huffman_walk_mpix_s_single_thread": round(distinct * W * H / host_stage_s / 1e6, 1),
                 "note": "host entropy stage, 1 thread, writing pinned staging; outside the timed region",
             },
         }
-        if int16_cmp is not None:
-            out["roofline_int16_planes"] = int16_cmp
+        if legs:
+            out["legs"] = legs
         if e2e is not None:
             out["end_to_end"] = e2e
-        if cp.world == 1 and not args.no_cpu_baseline:
+        if solo and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(datas, gpu_pixels=lambda i: gpu_px[i])
             except Exception as exc:  # noqa: BLE001

@@ -45,4 +45,4 @@ from .binding import (  # noqa: F401
     decode_jpegs_multi,
     gpu_available,
 )
-from .synth import synth_rgb, synth_jpeg  # noqa: F401
+from .synth import synth_rgb, synth_jpeg, synth_rgb_edges  # noqa: F401

@@ -665,6 +665,17 @@ class Batch:
         _check(lib().mij_batch_hash_out(self._h, int(slot), C.byref(h)), "mij_batch_hash_out")
         return h.value
 
+    def diff_slots(self, pairs):
+        """mij_batch_diff_slots: number of 16-byte words in which the device images of the slot pairs differ."""
+        L = lib()
+        n = len(pairs)
+        L.mij_batch_diff_slots.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_uint64)]
+        sa = (C.c_int * n)(*[int(p[0]) for p in pairs])
+        sb = (C.c_int * n)(*[int(p[1]) for p in pairs])
+        out = C.c_uint64()
+        _check(L.mij_batch_diff_slots(self._h, sa, sb, n, C.byref(out)), "mij_batch_diff_slots")
+        return out.value
+
     def slot_path(self, slot):
         return lib().mij_batch_slot_path(self._h, int(slot))
 

@@ -1041,6 +1041,55 @@ extern "C" int mij_batch_hash_out(mij_batch *b, int slot, uint64_t *hash)
 	return MIJ_OK;
 }
 
+/* words of 16 bytes in which two device images differ (parity checks of big batches: clones against their source) */
+__global__ __launch_bounds__(256) void k_count_diff(const uint4 *__restrict__ a, const uint4 *__restrict__ b, uint32_t n, unsigned long long *__restrict__ out)
+{
+	uint32_t bad = 0;
+	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+		const uint4 x = a[i], y = b[i];
+		bad += (x.x != y.x) | (x.y != y.y) | (x.z != y.z) | (x.w != y.w);
+	}
+	if (bad)
+		atomicAdd(out, (unsigned long long)bad);
+}
+
+extern "C" int mij_batch_diff_slots(mij_batch *b, const int *sa, const int *sb, int n, uint64_t *ndiff)
+{
+	if (!b || !sa || !sb || !ndiff || n < 0)
+		return set_err(MIJ_E_ARG, "bad argument");
+	if (!b->launched)
+		return set_err(MIJ_E_STATE, "mij_batch_diff_slots before launch");
+	HIP_TRY(hipSetDevice(b->ctx->device));
+	unsigned long long *d_cnt = nullptr, h_cnt = 0;
+	HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_cnt), sizeof(unsigned long long)));
+	hipError_t e = hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), b->stream);
+	for (int i = 0; i < n && e == hipSuccess; ++i) {
+		if (sa[i] < 0 || sb[i] < 0 || sa[i] >= (int)b->slots.size() || sb[i] >= (int)b->slots.size()) {
+			(void)hipFree(d_cnt);
+			return set_err(MIJ_E_ARG, "bad slot pair %d", i);
+		}
+		const Slot &x = b->slots[(size_t)sa[i]], &y = b->slots[(size_t)sb[i]];
+		const size_t bytes = align_up((size_t)x.desc.n_out * x.desc.width * x.desc.height, 16);
+		if (bytes != align_up((size_t)y.desc.n_out * y.desc.width * y.desc.height, 16)) {
+			(void)hipFree(d_cnt);
+			return set_err(MIJ_E_ARG, "slot pair %d: different sizes", i);
+		}
+		/* outputs are 256-byte aligned and padded in the arena, so whole 16-byte words may be compared */
+		hipLaunchKernelGGL(k_count_diff, dim3(1024), dim3(256), 0, b->stream, reinterpret_cast<const uint4 *>(b->d_out + x.dev.out_off),
+								 reinterpret_cast<const uint4 *>(b->d_out + y.dev.out_off), (uint32_t)(bytes / 16), d_cnt);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess)
+		e = hipMemcpyAsync(&h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost, b->stream);
+	if (e == hipSuccess)
+		e = hipStreamSynchronize(b->stream);
+	(void)hipFree(d_cnt);
+	if (e != hipSuccess)
+		return set_err(MIJ_E_HIP, "mij_batch_diff_slots: %s", hipGetErrorString(e));
+	*ndiff = (uint64_t)h_cnt;
+	return MIJ_OK;
+}
+
 /* ------------------------------------------------------------------ GPU entropy stage (mij_batch_entropy_*)
  *
  * See mij_entropy_kernels.h for the algorithm.  The arena holds everything the five kernels touch besides the

@@ -71,6 +71,15 @@ class ControlPlane:
     def sum(self, value):
         return self._reduce(value, dist.ReduceOp.SUM)
 
+    def gather_floats(self, values):
+        """Every rank's list of floats, in rank order (control plane only: a few scalars per rank)."""
+        if not self._dist:
+            return [[float(v) for v in values]]
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=self.device)
+        out = [torch.zeros_like(t) for _ in range(self.world)]
+        dist.all_gather(out, t)
+        return [[float(x) for x in o.tolist()] for o in out]
+
     def close(self):
         if self._dist and dist.is_initialized():
             dist.destroy_process_group()

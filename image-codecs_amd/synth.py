@@ -46,3 +46,25 @@ def synth_jpeg(width, height, seed=0, quality=90, noise_mask=15):
     if data is None:
         raise binding.MijError("stbi_write_jpg_to_func failed")
     return data
+
+
+def synth_rgb_edges(width, height, seed=0, noise_mask=63, rects=24):
+    """The harsher declared content of the benchmark's second leg: synth_rgb with noise_mask 63 (four times the noise
+    amplitude: ~3.5 bit/px at q=90) and `rects` axis-aligned rectangles whose pixels are inverted (255 - v): hard edges
+    of full contrast, whose low-frequency coefficients leave the byte range at q=90 (escaped blocks of the compact
+    planes).  Rectangle k of image `seed`: LCG state s0 = 777 + 1000003*seed, four draws per rectangle
+    (s = s*1664525 + 1013904223 mod 2^32): x0 = (s>>8) % W, y0 = (s>>8) % H, w = 16 + (s>>8) % (W/3), h = 16 + (s>>8) % (H/3),
+    clipped to the picture."""
+    img = synth_rgb(width, height, seed, noise_mask).astype(np.int32)
+    s = (777 + 1000003 * seed) & 0xFFFFFFFF
+
+    def draw():
+        nonlocal s
+        s = (s * 1664525 + 1013904223) & 0xFFFFFFFF
+        return s >> 8
+
+    for _ in range(rects):
+        x0, y0 = draw() % width, draw() % height
+        w, h = 16 + draw() % max(1, width // 3), 16 + draw() % max(1, height // 3)
+        img[y0:min(height, y0 + h), x0:min(width, x0 + w)] = 255 - img[y0:min(height, y0 + h), x0:min(width, x0 + w)]
+    return img.astype(np.uint8)

@@ -209,6 +209,10 @@ int mij_batch_timer_elapsed_ms(mij_batch *b, float *ms);
 /* FNV-1a 64 of an image's output computed on the device copy (D2H + hash on host); for parity checks of big batches */
 int mij_batch_hash_out(mij_batch *b, int slot, uint64_t *hash);
 
+/* Parity of big batches without bringing the pixels to the host: *ndiff = number of 16-byte words in which the
+ * device images of the slot pairs (sa[i], sb[i]) differ (same sizes required); e.g. every clone against its source. */
+int mij_batch_diff_slots(mij_batch *b, const int *sa, const int *sb, int n, uint64_t *ndiff);
+
 /* which kernel family the last upload chose for a slot: 0 none (skipped), 1 fused 4:2:0, 2 generic two-pass,
  * 3 fused 4:4:4, 4 fused 4:2:2, 5 fused grey */
 int mij_batch_slot_path(const mij_batch *b, int slot);

@@ -45,8 +45,9 @@ WORKER = textwrap.dedent("""
         desc, arena = ica.HostDecoder.decode(d, 3)
         blocks += sum(desc.comp[c].bw * desc.comp[c].bh for c in range(desc.ncomp))
     all_blocks = cp.sum(blocks)
+    rows = cp.gather_floats([cp.rank, lo, hi])
     cp.barrier()
-    print(json.dumps({"rank": cp.rank, "world": cp.world, "lo": lo, "hi": hi, "t_max": t_max, "total": total, "blocks": all_blocks}))
+    print(json.dumps({"rank": cp.rank, "world": cp.world, "lo": lo, "hi": hi, "t_max": t_max, "total": total, "blocks": all_blocks, "rows": rows}))
     cp.close()
 """)
 
@@ -72,4 +73,5 @@ def test_two_ranks_over_gloo(tmp_path):
     assert (res[0]["lo"], res[0]["hi"], res[1]["lo"], res[1]["hi"]) == (0, 2048, 2048, 4096)
     assert res[0]["t_max"] == res[1]["t_max"] == 2.0          # MAX over ranks
     assert res[0]["total"] == res[1]["total"] == 4096.0       # every image owned exactly once
+    assert res[0]["rows"] == res[1]["rows"] == [[0.0, 0.0, 2048.0], [1.0, 2048.0, 4096.0]]  # all_gather in rank order
     assert res[0]["blocks"] == res[1]["blocks"] == 6 * (4 * 2 + 2 + 2)  # 32x16 4:2:0: 2 MCUs x 6 blocks... per image
