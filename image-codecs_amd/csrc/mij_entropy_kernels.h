@@ -13,11 +13,15 @@
  *                    started from last time; the true chain from subsequence 0 wins; stops changing after a
  *                    few rounds because wrong starts re-synchronise inside one subsequence
  *   3. k_es_offsets  prefix sum of the blocks completed per subsequence -> the block ordinal each one starts at
- *   4. k_es_write    decode once more, now knowing where every coefficient goes: straight into the (cleared)
- *                    planes the IDCT kernels read -- compact planes by default (low byte into the tile, and for a
- *                    value outside -128..127 its escape byte and the block's flag: nothing is handed back for
- *                    size), int16 tile layout on request -- DC differences aside;
- *                    k_es_tails adds the rest of blocks that began in the previous subsequence
+ *   4. k_es_write    decode once more, now knowing where every coefficient goes, DC differences aside.  Compact
+ *                    planes (the default): into a cleared intermediate image of 64 bytes per block in ZIGZAG order,
+ *                    block after block in scan order -- consecutive coefficients are neighbouring bytes, so a lane
+ *                    gathers them in a 64-bit register and stores eight at a time (2-3 stores per block instead of
+ *                    one scattered store per coefficient); a value outside -128..127 also gets its escape byte
+ *                    (nothing is handed back for size).  int16 tile layout (on request): every coefficient straight
+ *                    to its place in the cleared planes.
+ *                    k_es_tails adds the rest of blocks that began in the previous subsequence (single bytes);
+ *      k_es_pack     intermediate image -> the tile order of the compact planes (one block per lane, coalesced)
  *   5. k_es_dc       per component running sum of the DC differences (codec/jpeg.c:323-325), per-block L1
  *                    bound (MIJ_FLAG_WIDE_IDCT), completion checks, the left-over-0xff rule
  * Symbol decoding is the reference's (codec/jpeg.c:193-265: 9-bit fast table, maxcode/delta slow path,
@@ -176,41 +180,92 @@ struct EsWriter { /* where the blocks of the write pass go */
 	const DevScan *sc;
 	const EsLocal *loc;
 	int16_t *coef;       /* coefficient arena */
-	int16_t *dcdiff;     /* per block */
-	uint32_t *l1;        /* per block */
-	const uint16_t *toff; /* zigzag index -> element offset inside the block's tile slot */
+	uint64_t *meta;      /* per block of the scan: L1 of its de-quantised AC coefficients (low dword) | DC difference << 32 */
+	const uint16_t *toff; /* zigzag index -> element offset inside the block's tile slot (int16 planes) */
 	const uint8_t *zpos;  /* zigzag index -> in-block position P (the order of a block's escape bytes) */
 	bool skip;            /* the block in progress was begun by the previous subsequence: k_es_tails stores its rest */
 	bool stop_after_block;
-	bool owner;          /* k_es_write: this thread stores the L1 word of the blocks it begins (k_es_tails adds) */
+	bool owner;          /* k_es_write: this thread stores the meta word of the blocks it begins (k_es_tails adds to the L1) */
 	uint32_t ord;        /* ordinal of the current block */
-	uint32_t mx, my;     /* its MCU */
+	uint32_t mx, my;     /* its MCU (int16 planes only) */
 	int16_t *blk;        /* its tile slot (int16 planes) */
-	uint8_t *blk8;       /* its tile slot (compact planes) */
-	uint8_t *hi8;        /* its 64 escape bytes (compact planes) */
-	uint32_t L;          /* its index in the component's block grid */
+	uint8_t *zz;         /* compact planes: its 64 bytes, zigzag order, in the intermediate image (blocks in scan order) */
+	uint64_t grp;        /* the eight bytes of group curq gathered so far */
+	uint32_t curq;
+	bool esc;            /* the current block has an escaped coefficient (written by this thread) */
+	bool bytewise;       /* k_es_tails: single byte stores (the head's group stores came first and wrote zeros beside them) */
+	int dcd;             /* DC difference of the current block */
 	uint32_t acc;        /* L1 of the AC coefficients written by this thread into it */
 	uint32_t *pfinal;    /* where the bit position after the scan's last block is recorded */
+	/* int16 planes: the tile slot of block-in-MCU c of MCU (mx, my) */
 	__device__ __forceinline__ void locate(uint32_t c)
 	{
 		const uint32_t g = loc->geo[c];
 		const uint32_t bx = mx * (g & 255u) + ((g >> 16) & 255u), by = my * ((g >> 8) & 255u) + (g >> 24);
-		L = bx + by * loc->bw[c];
-		uint8_t *plane = reinterpret_cast<uint8_t *>(coef) + loc->plane[c];
-		blk = reinterpret_cast<int16_t *>(plane) + ((size_t)(L >> 6) << 12) + ((L & 63u) << 3);
-		blk8 = plane + ((size_t)(L >> 6) << 12) + ((L & 63u) << 3);
-		hi8 = reinterpret_cast<uint8_t *>(coef) + loc->hi[c] + ((size_t)L << 6);
+		const uint32_t L = bx + by * loc->bw[c];
+		blk = reinterpret_cast<int16_t *>(reinterpret_cast<uint8_t *>(coef) + loc->plane[c]) + ((size_t)(L >> 6) << 12) + ((L & 63u) << 3);
 	}
-	__device__ __forceinline__ void put(uint32_t k, int v)
+	/* compact planes, rare: the 64 escape bytes of the current block (block-in-MCU c), from its ordinal */
+	__device__ __forceinline__ uint8_t *escape_bytes(uint32_t c) const
+	{
+		const uint32_t m = sc->first_mcu + (ord - c) / sc->bpm;
+		const uint32_t ym = m / sc->mcu_x, xm = m - ym * sc->mcu_x;
+		const uint32_t g = loc->geo[c];
+		const uint32_t bx = xm * (g & 255u) + ((g >> 16) & 255u), by = ym * ((g >> 8) & 255u) + (g >> 24);
+		return reinterpret_cast<uint8_t *>(coef) + loc->hi[c] + ((size_t)(bx + by * loc->bw[c]) << 6);
+	}
+	__device__ __forceinline__ void flush_group()
+	{
+		if (grp && !((MIJ_VARIANT & 256) && grp != 0x123456789abcdefull)) /* all-zero groups are the cleared image already; ablation bit 256: no group stores */
+			*reinterpret_cast<uint64_t *>(zz + 8u * curq) = grp;
+		grp = 0;
+	}
+	__device__ __forceinline__ void put(uint32_t k, int v, uint32_t c)
 	{
 		if (sc->fmt) {
-			blk8[toff[k]] = (uint8_t)v; /* low byte */
+			if (bytewise)
+				zz[k] = (uint8_t)v;
+			else {
+				const uint32_t q = k >> 3;
+				if (q != curq) {
+					flush_group();
+					curq = q;
+				}
+				grp |= (uint64_t)(uint8_t)v << (8u * (k & 7u)); /* low byte */
+			}
 			if ((uint32_t)(v + 128) > 255u) { /* escape: v == sext8(low) + 256 * h (mij_kernels.h, load_block_b8) */
+				uint8_t *hi8 = escape_bytes(c);
+				/* the block's first escape clears its 64 escape bytes (nothing else does); a tail looks at the flag
+				 * the head may have left (an earlier kernel) */
+				if (!esc && !(bytewise && zz[0] != 0)) {
+					uint4 *h = reinterpret_cast<uint4 *>(hi8);
+					h[0] = h[1] = h[2] = h[3] = make_uint4(0, 0, 0, 0);
+				}
+				esc = true;
 				hi8[zpos[k]] = (uint8_t)((v + 128) >> 8);
-				blk8[0] = 1; /* the block's flags byte sits in the DC's place; every writer stores the same value */
 			}
 		} else
 			blk[toff[k]] = (int16_t)v;
+	}
+	/* the block (or the head of one that continues in the next subsequence) is done: its bytes and its meta word.  Per-block
+	 * L1 without atomics: whoever holds the block's start stores the word, the thread that finishes a block begun elsewhere
+	 * (k_es_tails, a later launch) adds to its L1 half */
+	__device__ __forceinline__ void end_block()
+	{
+		if (sc->fmt) {
+			if (!bytewise)
+				flush_group();
+			if (esc)
+				zz[0] = 1; /* the flags byte sits in the DC's place; behind this lane's own store of group 0 */
+		}
+		if (owner) {
+			if (!((MIJ_VARIANT & 512) && acc != 0x12345678u)) /* ablation bit 512: no meta stores */
+				meta[ord] = (uint64_t)acc | ((uint64_t)(uint16_t)(int16_t)dcd << 32);
+		} else
+			reinterpret_cast<uint32_t *>(meta + ord)[0] += acc;
+		acc = 0;
+		esc = false;
+		curq = 0;
 	}
 };
 
@@ -228,6 +283,9 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &
 	EsBits br;
 	br.start(stream, s.p);
 	uint32_t tb = loc.tabs[s.c]; /* the current block's component and tables; changes with s.c only */
+	/* ONE symbol per iteration whatever it is: the lanes of a wave sit at DC terms, AC runs and block ends all the time,
+	 * so a loop with a DC branch and an AC branch executes both on almost every iteration (each at a fraction of the
+	 * lanes).  Here the table is chosen by data and the state update is a handful of selects. */
 	while (s.p < p_end && s.z != MIJ_ES_DEAD) {
 		if (++guard > MIJ_ES_BITS + 64u) { /* every symbol takes at least one bit: cannot happen, but a wave must always end */
 			s.z = MIJ_ES_DEAD;
@@ -236,68 +294,47 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &
 		if (WRITE && wr->ord >= sc.nblocks)
 			break;
 		const uint64_t win = br.win;
-		const uint32_t ci = tb & 255u;
+		const bool isdc = s.z == 0;
 		uint32_t len = 0;
-		if (s.z == 0) {
-			const int t = es_symbol(tabs[(tb >> 8) & 255u], win, len);
-			if (t < 0 || t > 11 || len == 0) { /* the reference takes categories up to 16; nothing a conforming stream uses */
-				if (!WRITE) { /* a guessed start ran into a non-code: slip one bit and keep looking for the true sequence */
-					s.p += 1;
-					br.take(1);
-					continue;
-				}
-				atomicOr(anom, 1u);
-				s.z = MIJ_ES_DEAD;
-				break;
+		const int sym = es_symbol(tabs[isdc ? (tb >> 8) & 255u : tb >> 16], win, len);
+		/* DC: the reference takes categories up to 16; nothing a conforming stream uses beyond 11 */
+		if (sym < 0 || len == 0 || (isdc && sym > 11)) {
+			if (!WRITE) { /* a guessed start ran into a non-code: slip one bit and keep looking for the true sequence */
+				s.p += 1;
+				br.take(1);
+				continue;
 			}
-			const int diff = t ? es_extend(win, len, (uint32_t)t) : 0;
+			atomicOr(anom, 1u);
+			s.z = MIJ_ES_DEAD;
+			break;
+		}
+		const uint32_t n = isdc ? (uint32_t)sym : ((uint32_t)sym & 15u), r = isdc ? 0u : ((uint32_t)sym >> 4);
+		const int ext = es_extend(win, len, n ? n : 1u);
+		const int v = n ? ext : 0;
+		s.p += len + n;
+		br.take(len + n);
+		if (isdc) {
 			if (WRITE)
-				wr->dcdiff[wr->ord] = (int16_t)diff;
-			s.p += len + (uint32_t)t;
-			br.take(len + (uint32_t)t);
+				wr->dcd = v;
 			s.z = 1;
+		} else if (n == 0) {
+			/* ZRL, or EOB (EOBn only exists in progressive scans; the reference treats it like EOB here, :355) */
+			s.z = r == 15u ? s.z + 16u : 64u;
 		} else {
-			const int rs = es_symbol(tabs[tb >> 16], win, len);
-			if (rs < 0 || len == 0) {
-				if (!WRITE) {
-					s.p += 1;
-					br.take(1);
-					continue;
-				}
-				atomicOr(anom, 1u);
-				s.z = MIJ_ES_DEAD;
-				break;
-			}
-			const uint32_t r = (uint32_t)rs >> 4, n = (uint32_t)rs & 15u;
-			if (n == 0) {
-				s.p += len;
-				br.take(len);
-				if (r == 15u)
-					s.z += 16; /* ZRL */
-				else if (r == 0u)
-					s.z = 64; /* EOB */
-				else { /* EOBn only exists in progressive scans; the reference treats it like EOB here (:355) */
-					s.z = 64;
-				}
+			const uint32_t k = s.z + r;
+			if (k > 63u) { /* the reference would write through its padded de-zigzag table: leave that to the host */
+				if (WRITE)
+					atomicOr(anom, 1u);
+				s.z = 64;
 			} else {
-				const uint32_t k = s.z + r;
-				if (k > 63u) { /* the reference would write through its padded de-zigzag table: leave that to the host */
-					if (WRITE)
-						atomicOr(anom, 1u);
-					s.p += len + n;
-					br.take(len + n);
-					s.z = 64;
-				} else {
-					const int v = es_extend(win, len, n);
-					if (WRITE && !wr->skip) {
-						wr->put(k, v);
-						const int dq = (int)(int16_t)((uint32_t)v * loc.qz[ci][k]);
+				if (WRITE && !wr->skip) {
+					wr->put(k, v, s.c);
+					if (!(MIJ_VARIANT & 1024)) { /* ablation bit 1024: no L1 accumulation */
+						const int dq = (int)(int16_t)((uint32_t)v * loc.qz[tb & 255u][k]);
 						wr->acc += (uint32_t)(dq < 0 ? -dq : dq);
 					}
-					s.p += len + n;
-					br.take(len + n);
-					s.z = k + 1;
 				}
+				s.z = k + 1;
 			}
 		}
 		if (s.z >= 64u) { /* block complete (ZRL past the end ends it too: same as the host loop's k < 64 test) */
@@ -306,13 +343,8 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &
 			if (WRITE) {
 				if (s.p > sc.nbits)
 					atomicOr(anom, 16u); /* the data ran out inside this block: the reference decodes on with zero bits */
-				/* per-block L1 of the AC coefficients without atomics: whoever holds the block's start stores, the
-				 * thread that finishes a block begun elsewhere (k_es_tails, a later launch) adds */
-				if (wr->owner) {
-					if (!wr->skip)
-						wr->l1[wr->ord] = wr->acc;
-				} else
-					wr->l1[wr->ord] += wr->acc;
+				if (!wr->skip)
+					wr->end_block();
 				wr->acc = 0;
 				if (wr->stop_after_block) { /* k_es_tails: only the rest of the block the subsequence started in */
 					s.z = 0;
@@ -321,10 +353,11 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &
 				wr->skip = false;
 				if (++wr->ord == sc.nblocks)
 					*wr->pfinal = s.p;
+				wr->zz += 64;
 			}
 			if (++s.c == sc.bpm) {
 				s.c = 0;
-				if (WRITE) {
+				if (WRITE && !sc.fmt) {
 					if (++wr->mx == sc.mcu_x) {
 						wr->mx = 0;
 						++wr->my;
@@ -332,7 +365,7 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &
 				}
 			}
 			tb = loc.tabs[s.c];
-			if (WRITE && wr->ord < sc.nblocks)
+			if (WRITE && !sc.fmt && wr->ord < sc.nblocks)
 				wr->locate(s.c);
 		}
 		if (s.p > limit) {
@@ -341,7 +374,7 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &
 		}
 	}
 	if (WRITE && wr->owner && wr->ord < sc.nblocks && !wr->skip && s.z != 0 && s.z != MIJ_ES_DEAD)
-		wr->l1[wr->ord] = wr->acc; /* a block that continues in the next subsequence: the L1 of its head */
+		wr->end_block(); /* a block that continues in the next subsequence: its bytes so far and the meta word of its head */
 	return done;
 }
 
@@ -410,20 +443,25 @@ __global__ __launch_bounds__(256) void k_es_sync(const DevScan *__restrict__ sca
 	__shared__ EsLocal loc;
 	const EsWork wk = work[blockIdx.x];
 	const DevScan &sc = scans[wk.scan];
-	es_load_tables(sc, nullptr, huff + sc.tab_off, tabs, &loc);
 	const uint32_t i = wk.first + threadIdx.x;
-	if (i >= sc.nsub)
-		return;
 	const uint32_t slot = sc.sub_off + i;
-	if (i == 0) {
-		end_out[slot] = end_in[slot];
-		return;
+	/* who has to decode again?  From the second round on almost nobody: a workgroup without such a thread leaves
+	 * before it has copied the eight tables into LDS (which is most of what an idle round used to cost) */
+	uint64_t want = 0;
+	bool redo = false;
+	if (i < sc.nsub) {
+		if (i > 0) {
+			want = end_in[slot - 1];
+			redo = want != start[slot];
+		}
+		if (!redo)
+			end_out[slot] = end_in[slot];
 	}
-	const uint64_t want = end_in[slot - 1];
-	if (want == start[slot]) {
-		end_out[slot] = end_in[slot];
+	if (!__syncthreads_or(redo ? 1 : 0))
 		return;
-	}
+	es_load_tables(sc, nullptr, huff + sc.tab_off, tabs, &loc);
+	if (!redo)
+		return;
 	start[slot] = want;
 	EsState s = es_unpack(want);
 	const uint32_t pe = min((i + 1u) * MIJ_ES_BITS, sc.nbits);
@@ -467,8 +505,8 @@ __global__ __launch_bounds__(256) void k_es_offsets(const DevScan *__restrict__ 
  * it whole: 37 KiB of LDS per workgroup, 3 waves per SIMD, 5.4 ms against 3.4 ms per 256 images -- removed.) */
 __global__ __launch_bounds__(256) void k_es_write(const DevScan *__restrict__ scans, const EsWork *__restrict__ work, const DevHuff *__restrict__ huff,
 																  const uint8_t *__restrict__ streams, const DevImage *__restrict__ imgs, const uint64_t *__restrict__ start,
-																  const uint32_t *__restrict__ base, int16_t *__restrict__ coef, int16_t *__restrict__ dcdiff, uint32_t *__restrict__ l1,
-																  uint32_t *__restrict__ anom, uint32_t *__restrict__ pfinal)
+																  const uint32_t *__restrict__ base, int16_t *__restrict__ coef, uint64_t *__restrict__ meta,
+																  uint32_t *__restrict__ anom, uint32_t *__restrict__ pfinal, uint8_t *__restrict__ zz)
 {
 	__shared__ EsTab tabs[8];
 	__shared__ EsLocal loc;
@@ -491,11 +529,17 @@ __global__ __launch_bounds__(256) void k_es_write(const DevScan *__restrict__ sc
 	wr.sc = &sc;
 	wr.loc = &loc;
 	wr.coef = coef;
-	wr.dcdiff = dcdiff + sc.blk_off;
-	wr.l1 = l1 + sc.blk_off;
+	wr.meta = meta + sc.blk_off;
 	wr.toff = toff;
 	wr.zpos = zpos;
 	wr.owner = true;
+	wr.grp = 0;
+	wr.curq = 0;
+	wr.esc = false;
+	wr.bytewise = false;
+	wr.dcd = 0;
+	wr.blk = nullptr;
+	wr.mx = wr.my = 0;
 	wr.skip = s.z != 0; /* begun by the previous subsequence */
 	wr.stop_after_block = false;
 	wr.ord = base[slot];
@@ -508,9 +552,12 @@ __global__ __launch_bounds__(256) void k_es_write(const DevScan *__restrict__ sc
 		atomicOr(&anom[wk.scan], 2u);
 		return;
 	}
-	wr.my = m / sc.mcu_x;
-	wr.mx = m - wr.my * sc.mcu_x;
-	wr.locate(s.c);
+	wr.zz = zz + ((size_t)(sc.blk_off + wr.ord) << 6);
+	if (!sc.fmt) {
+		wr.my = m / sc.mcu_x;
+		wr.mx = m - wr.my * sc.mcu_x;
+		wr.locate(s.c);
+	}
 	const uint32_t pe = min((i + 1u) * MIJ_ES_BITS, sc.nbits);
 	es_decode<true>(sc, loc, tabs, streams + sc.stream_off, s, pe, &wr, &anom[wk.scan]);
 }
@@ -519,8 +566,8 @@ __global__ __launch_bounds__(256) void k_es_write(const DevScan *__restrict__ sc
  * previous thread's k_es_write stored whole (stream order makes this the later write) */
 __global__ __launch_bounds__(256) void k_es_tails(const DevScan *__restrict__ scans, const EsWork *__restrict__ work, const DevHuff *__restrict__ huff,
 																  const uint8_t *__restrict__ streams, const DevImage *__restrict__ imgs, const uint64_t *__restrict__ start,
-																  const uint32_t *__restrict__ base, int16_t *__restrict__ coef, int16_t *__restrict__ dcdiff, uint32_t *__restrict__ l1,
-																  uint32_t *__restrict__ scratch)
+																  const uint32_t *__restrict__ base, int16_t *__restrict__ coef, uint64_t *__restrict__ meta,
+																  uint32_t *__restrict__ scratch, uint8_t *__restrict__ zz)
 {
 	__shared__ EsTab tabs[8];
 	__shared__ EsLocal loc;
@@ -533,23 +580,33 @@ __global__ __launch_bounds__(256) void k_es_tails(const DevScan *__restrict__ sc
 		zpos[threadIdx.x] = (uint8_t)P;
 		toff[threadIdx.x] = (uint16_t)(((P >> 3) << 9) + (P & 7u));
 	}
-	es_load_tables(sc, &imgs[sc.img], huff + sc.tab_off, tabs, &loc);
 	const uint32_t i = wk.first + threadIdx.x;
-	if (i >= sc.nsub)
-		return;
 	const uint32_t slot = sc.sub_off + i;
-	EsState s = es_unpack(start[slot]);
-	if (s.z == 0 || s.z == MIJ_ES_DEAD)
+	EsState s;
+	s.p = s.z = s.c = 0;
+	if (i < sc.nsub)
+		s = es_unpack(start[slot]);
+	const bool mine = i < sc.nsub && s.z != 0 && s.z != MIJ_ES_DEAD; /* a block begun by the previous subsequence */
+	if (!__syncthreads_or(mine ? 1 : 0))
+		return;
+	es_load_tables(sc, &imgs[sc.img], huff + sc.tab_off, tabs, &loc);
+	if (!mine)
 		return;
 	EsWriter wr;
 	wr.sc = &sc;
 	wr.loc = &loc;
 	wr.coef = coef;
-	wr.dcdiff = dcdiff + sc.blk_off;
-	wr.l1 = l1 + sc.blk_off;
+	wr.meta = meta + sc.blk_off;
 	wr.toff = toff;
 	wr.zpos = zpos;
 	wr.owner = false;
+	wr.grp = 0;
+	wr.curq = 0;
+	wr.esc = false;
+	wr.bytewise = true;
+	wr.dcd = 0;
+	wr.blk = nullptr;
+	wr.mx = wr.my = 0;
 	wr.skip = false;
 	wr.stop_after_block = true;
 	wr.ord = base[slot];
@@ -560,16 +617,63 @@ __global__ __launch_bounds__(256) void k_es_tails(const DevScan *__restrict__ sc
 	const uint32_t ml = wr.ord / sc.bpm, m = sc.first_mcu + ml;
 	if (wr.ord - ml * sc.bpm != s.c)
 		return;
-	wr.my = m / sc.mcu_x;
-	wr.mx = m - wr.my * sc.mcu_x;
-	wr.locate(s.c);
+	wr.zz = zz + ((size_t)(sc.blk_off + wr.ord) << 6);
+	if (!sc.fmt) {
+		wr.my = m / sc.mcu_x;
+		wr.mx = m - wr.my * sc.mcu_x;
+		wr.locate(s.c);
+	}
 	/* k_es_write walked the same symbols and reported what there was to report: verdict bits go to a scratch word */
 	es_decode<true>(sc, loc, tabs, streams + sc.stream_off, s, sc.nbits, &wr, scratch + 1);
 }
 
+/* The intermediate image of the write pass (64 bytes per block in zigzag order, blocks in scan order) -> the tiles of
+ * the compact planes: one block per lane, its bytes permuted in registers into in-block position order P (mij.h), chunk
+ * rows stored coalesced.  Byte 0 (the DC's place) carries the block's flags through.  Blocks of a tile beyond the
+ * component's grid come out as zeros.  work.comp = component, work.first = first block. */
+__global__ __launch_bounds__(256) void k_es_pack(const DevImage *__restrict__ imgs, const WorkIdct *__restrict__ work, const uint8_t *__restrict__ zz,
+																 uint8_t *__restrict__ coef)
+{
+	const WorkIdct wk = work[blockIdx.x];
+	const DevImage &im = imgs[wk.img];
+	const DevComp &cp = im.comp[wk.comp];
+	const uint32_t nblk = (uint32_t)(cp.bw * cp.bh), ntile = (nblk + 63u) >> 6;
+	const uint32_t L = wk.first + threadIdx.x;
+	if (L >= ntile * 64u)
+		return;
+	uint32_t in[16];
+#pragma unroll
+	for (int i = 0; i < 16; ++i)
+		in[i] = 0;
+	if (L < nblk) {
+		const uint32_t by = L / (uint32_t)cp.bw, bx = L - by * (uint32_t)cp.bw;
+		const uint32_t mx = bx / (uint32_t)cp.h, dx = bx - mx * (uint32_t)cp.h, my = by / (uint32_t)cp.v, dy = by - my * (uint32_t)cp.v;
+		const uint32_t ord = (my * (uint32_t)im.mcu_x + mx) * im.es_bpm + im.es_j0[wk.comp] + dy * (uint32_t)cp.h + dx;
+		const uint4 *src = reinterpret_cast<const uint4 *>(zz + ((size_t)(im.es_blk_off + ord) << 6));
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			const u4v v = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(src + i));
+			in[4 * i] = v.x, in[4 * i + 1] = v.y, in[4 * i + 2] = v.z, in[4 * i + 3] = v.w;
+		}
+	}
+	uint32_t out[16];
+#pragma unroll
+	for (int i = 0; i < 16; ++i)
+		out[i] = 0;
+#pragma unroll
+	for (int k = 0; k < 64; ++k) { /* constant indices: the compiler folds this into byte permutes */
+		const int P = mij_zigzag_pos[k];
+		out[P >> 2] |= ((in[k >> 2] >> (8 * (k & 3))) & 255u) << (8 * (P & 3));
+	}
+	uint8_t *dst = coef + cp.coef_off + ((size_t)(L >> 6) << 12) + ((size_t)(L & 63u) << 3);
+#pragma unroll
+	for (int c = 0; c < 8; ++c)
+		*reinterpret_cast<uint2 *>(dst + (c << 9)) = make_uint2(out[2 * c], out[2 * c + 1]);
+}
+
 /* DC prediction (codec/jpeg.c:323-325), L1 bound and the completion checks; one workgroup per scan */
 __global__ __launch_bounds__(256) void k_es_dc(const DevScan *__restrict__ scans, const DevImage *__restrict__ imgs, const uint32_t *__restrict__ total, const uint32_t *__restrict__ changed, int16_t *__restrict__ coef,
-															  const int16_t *__restrict__ dcdiff, const uint32_t *__restrict__ l1, uint32_t *__restrict__ anom,
+															  const uint64_t *__restrict__ meta, uint32_t *__restrict__ anom,
 															  uint32_t *__restrict__ l1max, const uint32_t *__restrict__ pfinal, const uint8_t *__restrict__ streams)
 {
 	__shared__ int part[256][4];
@@ -579,8 +683,7 @@ __global__ __launch_bounds__(256) void k_es_dc(const DevScan *__restrict__ scans
 	const uint32_t nmcu = sc.nblocks / sc.bpm;
 	const uint32_t per = (nmcu + 255u) / 256u;
 	const uint32_t lo = min(threadIdx.x * per, nmcu), hi = min(lo + per, nmcu);
-	const int16_t *dd = dcdiff + sc.blk_off;
-	const uint32_t *bl1 = l1 + sc.blk_off;
+	const uint64_t *mt = meta + sc.blk_off; /* L1 of the AC coefficients | DC difference << 32 (EsWriter::end_block) */
 	if (threadIdx.x == 0) {
 		if (total[blockIdx.x] < sc.nblocks)
 			atomicOr(&anom[blockIdx.x], 4u); /* the stream ends before the last block */
@@ -607,7 +710,7 @@ __global__ __launch_bounds__(256) void k_es_dc(const DevScan *__restrict__ scans
 	int sum[4] = {0, 0, 0, 0};
 	for (uint32_t m = lo; m < hi; ++m)
 		for (uint32_t c = 0; c < sc.bpm; ++c)
-			sum[sc.blk_comp[c]] += dd[m * sc.bpm + c];
+			sum[sc.blk_comp[c]] += (int)(int16_t)(mt[m * sc.bpm + c] >> 32);
 	for (int k = 0; k < 4; ++k)
 		part[threadIdx.x][k] = sum[k];
 	__syncthreads();
@@ -629,7 +732,8 @@ __global__ __launch_bounds__(256) void k_es_dc(const DevScan *__restrict__ scans
 		for (uint32_t c = 0; c < sc.bpm; ++c) {
 			const uint32_t ci = sc.blk_comp[c];
 			const DevComp &cp = im.comp[ci];
-			pred[ci] = (int)((unsigned)pred[ci] + (unsigned)(int)dd[m * sc.bpm + c]);
+			const uint64_t w = mt[m * sc.bpm + c];
+			pred[ci] = (int)((unsigned)pred[ci] + (unsigned)(int)(int16_t)(w >> 32));
 			const uint32_t bx = mx * (uint32_t)cp.h + sc.blk_dx[c], by = my * (uint32_t)cp.v + sc.blk_dy[c];
 			const uint32_t L = bx + by * (uint32_t)cp.bw;
 			if (sc.fmt)
@@ -637,7 +741,7 @@ __global__ __launch_bounds__(256) void k_es_dc(const DevScan *__restrict__ scans
 			else
 				(reinterpret_cast<int16_t *>(reinterpret_cast<uint8_t *>(coef) + cp.coef_off) + ((size_t)(L >> 6) << 12) + ((L & 63u) << 3))[0] = (int16_t)pred[ci];
 			const int dq = (int)(int16_t)((uint32_t)pred[ci] * sc.qz[ci][0]);
-			const uint32_t tot = bl1[m * sc.bpm + c] + (uint32_t)(dq < 0 ? -dq : dq);
+			const uint32_t tot = (uint32_t)w + (uint32_t)(dq < 0 ? -dq : dq);
 			mymax = tot > mymax ? tot : mymax;
 		}
 		if (++mx == sc.mcu_x) {

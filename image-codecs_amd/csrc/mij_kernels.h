@@ -57,6 +57,8 @@ struct DevImage {
 	int32_t ncomp, flags, mcu_x, mcu_y;
 	uint64_t out_off; /* byte offset of the pixels in the output arena */
 	uint64_t src16_off; /* k_pack_c8 only: byte offset of the image's int16 tile-layout planes (back to back) in the upload scratch */
+	uint32_t es_blk_off; /* GPU entropy stage: index of the image's first block in the per-block arrays (scan order) */
+	uint8_t es_bpm, es_j0[4], es_pad[3]; /* blocks per MCU; first block-in-MCU of every component */
 	uint64_t plane_bytes_total;
 	DevComp comp[4];
 	uint32_t dq[4][32]; /* per component: quantisation table as u16 pairs in in-block position order P */

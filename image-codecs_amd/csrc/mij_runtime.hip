@@ -1105,11 +1105,13 @@ struct EsArena {
 	DevHuff *h_huff, *d_huff;
 	EsWork *h_work, *d_work;
 	size_t work_cap;
+	WorkIdct *h_pack, *d_pack; /* k_es_pack: (slot, component, first block) per 256 blocks of every compact-plane slot */
+	size_t pack_cap, pack_used;
 	uint64_t *d_start, *d_end[2];
 	uint32_t *d_cnt, *d_base;
 	size_t sub_cap;
-	int16_t *d_dcdiff;
-	uint32_t *d_l1;
+	uint64_t *d_meta; /* per block: L1 of its AC coefficients | DC difference << 32 */
+	uint8_t *d_zz; /* compact planes: the write pass's intermediate image, 64 bytes per block in zigzag order */
 	size_t blk_cap;
 	uint32_t *d_verdict, *h_verdict; /* [5][scan_cap]: anomaly, changed, total, l1max, final bit position */
 	uint32_t *d_rounds_changed, *h_rounds_changed; /* [MAX_ROUNDS] sum over scans, for tuning */
@@ -1133,13 +1135,15 @@ static void es_free(EsArena *e)
 	if (e->d_huff) (void)hipFree(e->d_huff);
 	if (e->h_work) (void)hipHostFree(e->h_work);
 	if (e->d_work) (void)hipFree(e->d_work);
+	if (e->h_pack) (void)hipHostFree(e->h_pack);
+	if (e->d_pack) (void)hipFree(e->d_pack);
 	if (e->d_start) (void)hipFree(e->d_start);
 	if (e->d_end[0]) (void)hipFree(e->d_end[0]);
 	if (e->d_end[1]) (void)hipFree(e->d_end[1]);
 	if (e->d_cnt) (void)hipFree(e->d_cnt);
 	if (e->d_base) (void)hipFree(e->d_base);
-	if (e->d_dcdiff) (void)hipFree(e->d_dcdiff);
-	if (e->d_l1) (void)hipFree(e->d_l1);
+	if (e->d_meta) (void)hipFree(e->d_meta);
+	if (e->d_zz) (void)hipFree(e->d_zz);
 	if (e->d_verdict) (void)hipFree(e->d_verdict);
 	if (e->h_verdict) (void)hipHostFree(e->h_verdict);
 	if (e->d_rounds_changed) (void)hipFree(e->d_rounds_changed);
@@ -1154,6 +1158,7 @@ static void es_reset_fwd(EsArena *e)
 		return;
 	e->scan_slot.clear();
 	e->sub_used = e->blk_used = e->work_used = e->n_tabs = 0;
+	e->pack_used = 0;
 	e->in_flight = false;
 }
 
@@ -1174,6 +1179,7 @@ extern "C" int mij_batch_entropy_reserve(mij_batch *b, size_t stream_bytes)
 	e->sub_cap = e->stream_cap * 8 / MIJ_ES_BITS + 2 * e->scan_cap;
 	e->blk_cap = b->coef_cap / 128 + n;
 	e->work_cap = e->sub_cap / 256 + 2 * e->scan_cap;
+	e->pack_cap = e->blk_cap / 256 + 8 * n;
 	hipError_t r = hipHostMalloc(reinterpret_cast<void **>(&e->stage), e->stream_cap, hipHostMallocDefault);
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_stream), e->stream_cap);
 	if (r == hipSuccess) r = hipHostMalloc(reinterpret_cast<void **>(&e->h_scans), sizeof(DevScan) * e->scan_cap, hipHostMallocDefault);
@@ -1182,13 +1188,15 @@ extern "C" int mij_batch_entropy_reserve(mij_batch *b, size_t stream_bytes)
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_huff), sizeof(DevHuff) * 8 * n);
 	if (r == hipSuccess) r = hipHostMalloc(reinterpret_cast<void **>(&e->h_work), sizeof(EsWork) * e->work_cap, hipHostMallocDefault);
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_work), sizeof(EsWork) * e->work_cap);
+	if (r == hipSuccess) r = hipHostMalloc(reinterpret_cast<void **>(&e->h_pack), sizeof(WorkIdct) * e->pack_cap, hipHostMallocDefault);
+	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_pack), sizeof(WorkIdct) * e->pack_cap);
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_start), sizeof(uint64_t) * e->sub_cap);
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_end[0]), sizeof(uint64_t) * e->sub_cap);
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_end[1]), sizeof(uint64_t) * e->sub_cap);
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_cnt), sizeof(uint32_t) * e->sub_cap);
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_base), sizeof(uint32_t) * e->sub_cap);
-	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_dcdiff), sizeof(int16_t) * e->blk_cap);
-	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_l1), sizeof(uint32_t) * e->blk_cap);
+	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_meta), sizeof(uint64_t) * e->blk_cap);
+	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_zz), 64 * e->blk_cap);
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_verdict), sizeof(uint32_t) * 5 * e->scan_cap);
 	if (r == hipSuccess) r = hipHostMalloc(reinterpret_cast<void **>(&e->h_verdict), sizeof(uint32_t) * 5 * e->scan_cap, hipHostMallocDefault);
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_rounds_changed), sizeof(uint32_t) * ES_MAX_ROUNDS);
@@ -1238,7 +1246,19 @@ extern "C" int mij_batch_add_stream(mij_batch *b, const mjg_scan *scan, uint8_t 
 		for (int c = 0; c < sd.ncomp; ++c)
 			if (scan->dc_tab[c] > 3 || scan->ac_tab[c] < 4 || scan->ac_tab[c] > 7)
 				return set_err(MIJ_E_ARG, "bad Huffman table index for component %d", c);
+		/* blocks of an MCU in the order of the interleaved scan (codec/jpeg.c:1204-1219): component, then row, then column */
+		uint32_t k = 0;
+		for (int c = 0; c < sd.ncomp; ++c)
+			for (int y = 0; y < sd.comp[c].v; ++y)
+				for (int x = 0; x < sd.comp[c].h; ++x, ++k)
+					if (scan->blk_comp[k] != c || scan->blk_dx[k] != x || scan->blk_dy[k] != y)
+						return set_err(MIJ_E_ARG, "scan block %u is not in interleaved-scan order", k);
 	}
+	size_t need_pack = 0;
+	for (int c = 0; c < scan->desc.ncomp; ++c)
+		need_pack += (comp_tiles(scan->desc.comp[c]) * 64 + 255) / 256;
+	if (b->coef_fmt && b->es->pack_used + need_pack > b->es->pack_cap)
+		return set_err(MIJ_E_NOMEM, "entropy arena exhausted");
 	/* one DevScan per restart interval (one for the whole stream without restart markers) */
 	const uint32_t nseg = scan->n_seg ? scan->n_seg : 1u;
 	if ((size_t)scan->seg_table_off + 8u * (size_t)nseg > stream_len || (scan->seg_table_off & 3u))
@@ -1270,6 +1290,18 @@ extern "C" int mij_batch_add_stream(mij_batch *b, const mjg_scan *scan, uint8_t 
 	 * int16 tile layout on request (mij_batch_set_coef_format). */
 	s.coef_bytes_fmt = b->coef_fmt ? 1 : 0;
 	layout_coef(s);
+	if (s.coef_bytes_fmt)
+		for (int c = 0; c < scan->desc.ncomp; ++c)
+			for (uint32_t f = 0, nb = (uint32_t)comp_tiles(scan->desc.comp[c]) * 64u; f < nb; f += 256) {
+				WorkIdct w = {(uint32_t)slot, (uint32_t)c, f, 0u};
+				e->h_pack[e->pack_used++] = w;
+			}
+	s.dev.es_blk_off = (uint32_t)e->blk_used;
+	s.dev.es_bpm = (uint8_t)scan->blocks_per_mcu;
+	for (int c = 0, j = 0; c < scan->desc.ncomp; ++c) {
+		s.dev.es_j0[c] = (uint8_t)j;
+		j += scan->desc.comp[c].h * scan->desc.comp[c].v;
+	}
 	static_assert(sizeof(DevHuff) == sizeof(mjg_huff), "mjg_huff and DevHuff must match");
 	const size_t tab = e->n_tabs++;
 	memcpy(&e->h_huff[8 * tab], scan->huff, sizeof(mjg_huff) * 8);
@@ -1324,11 +1356,15 @@ static int es_enqueue_tail(mij_batch *b)
 	hipLaunchKernelGGL(k_es_offsets, gs, blk, 0, st, e->d_scans, e->d_cnt, e->d_base, v_total);
 	HIP_TRY(hipGetLastError());
 	{
-		/* clear the planes of the walked images (neighbours in the arena as one range): the write pass only stores
-		 * non-zero coefficients, and escape bytes only where a value needs one */
+		/* compact planes: the write pass fills a cleared intermediate image (k_es_pack then writes every byte of the
+		 * tiles, k_es_dc the DC array, the first escape of a block clears its escape bytes: the planes themselves need
+		 * no clearing).  int16 planes: the write pass only stores non-zero coefficients, so the planes of those images
+		 * are cleared (neighbours in the arena as one range). */
+		if (e->pack_used)
+			HIP_TRY(hipMemsetAsync(e->d_zz, 0, 64 * e->blk_used, st));
 		size_t lo = 0, hi = 0;
 		for (const Slot &sl : b->slots) {
-			if (!sl.dev_coef || sl.clone_of >= 0)
+			if (!sl.dev_coef || sl.clone_of >= 0 || sl.coef_bytes_fmt)
 				continue;
 			const size_t a = sl.coef_base, z = a + sl.coef_bytes;
 			if (a == hi && hi > lo) {
@@ -1343,13 +1379,17 @@ static int es_enqueue_tail(mij_batch *b)
 		if (hi > lo)
 			HIP_TRY(hipMemsetAsync(b->d_coef + lo, 0, hi - lo, st));
 		hipLaunchKernelGGL(k_es_write, gw, blk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, b->d_imgs, e->d_start, e->d_base,
-								 reinterpret_cast<int16_t *>(b->d_coef), e->d_dcdiff, e->d_l1, v_anom, v_pfinal);
+								 reinterpret_cast<int16_t *>(b->d_coef), e->d_meta, v_anom, v_pfinal, e->d_zz);
 	}
 	HIP_TRY(hipGetLastError());
 	hipLaunchKernelGGL(k_es_tails, gw, blk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, b->d_imgs, e->d_start, e->d_base,
-							 reinterpret_cast<int16_t *>(b->d_coef), e->d_dcdiff, e->d_l1, e->d_rounds_changed);
+							 reinterpret_cast<int16_t *>(b->d_coef), e->d_meta, e->d_rounds_changed, e->d_zz);
 	HIP_TRY(hipGetLastError());
-	hipLaunchKernelGGL(k_es_dc, gs, blk, 0, st, e->d_scans, b->d_imgs, v_total, v_changed, reinterpret_cast<int16_t *>(b->d_coef), e->d_dcdiff, e->d_l1,
+	if (e->pack_used) {
+		hipLaunchKernelGGL(k_es_pack, dim3((unsigned)e->pack_used), blk, 0, st, b->d_imgs, e->d_pack, e->d_zz, b->d_coef);
+		HIP_TRY(hipGetLastError());
+	}
+	hipLaunchKernelGGL(k_es_dc, gs, blk, 0, st, e->d_scans, b->d_imgs, v_total, v_changed, reinterpret_cast<int16_t *>(b->d_coef), e->d_meta,
 							 v_anom, v_l1, v_pfinal, e->d_stream);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipMemcpyAsync(e->h_verdict, e->d_verdict, sizeof(uint32_t) * 5 * e->scan_cap, hipMemcpyDeviceToHost, st));
@@ -1391,6 +1431,7 @@ extern "C" int mij_batch_entropy_launch(mij_batch *b)
 	HIP_TRY(copy_table(e->d_scans, e->h_scans, sizeof(DevScan) * ns, st));
 	HIP_TRY(copy_table(e->d_huff, e->h_huff, sizeof(DevHuff) * 8 * e->n_tabs, st));
 	HIP_TRY(copy_table(e->d_work, e->h_work, sizeof(EsWork) * e->work_used, st));
+	HIP_TRY(copy_table(e->d_pack, e->h_pack, sizeof(WorkIdct) * e->pack_used, st));
 	/* streams: one copy from the first to the last byte in use */
 	size_t lo = (size_t)-1, hi = 0;
 	for (size_t k = 0; k < ns; ++k) {
