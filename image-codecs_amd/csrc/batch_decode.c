@@ -7,6 +7,8 @@
  * this path is the failure-reason pointer, which here is per image (reasons[i]).
  */
 #include <pthread.h>
+#include <stdio.h>
+#include <time.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -71,11 +73,12 @@ static void *worker(void *arg)
 	return NULL;
 }
 
+static void run_pool(pool_t *p, void *(*fn)(void *), int threads);
+
 int mjh_decode_batch(mij_batch *b, const uint8_t *const *bufs, const int *lens, int n, int req_comp, int threads, int *slots, const char **reasons)
 {
 	pool_t p;
-	pthread_t tid[256];
-	int i, started = 0;
+	int i;
 	if (!b || !bufs || !lens || !slots || !reasons || n < 0)
 		return MIJ_E_ARG;
 	if (threads < 1)
@@ -112,14 +115,7 @@ int mjh_decode_batch(mij_batch *b, const uint8_t *const *bufs, const int *lens, 
 	p.ok = 0;
 	p.todo = NULL;
 	pthread_mutex_init(&p.lock, NULL);
-	if (threads > n)
-		threads = n > 0 ? n : 1;
-	for (i = 1; i < threads; ++i)
-		if (pthread_create(&tid[started], NULL, worker, &p) == 0)
-			++started;
-	worker(&p);
-	for (i = 0; i < started; ++i)
-		pthread_join(tid[i], NULL);
+	run_pool(&p, worker, threads);
 	pthread_mutex_destroy(&p.lock);
 	free(p.descs);
 	return p.ok;
@@ -144,19 +140,85 @@ static void *extract_worker(void *arg)
 	return NULL;
 }
 
+/* A process-wide pool of helper threads, created on first use and kept: spawning and joining 15 threads per call cost
+ * more than the work of a 128-image chunk's header stage.  One job at a time (callers queue on job_lock); a job is
+ * "run fn(arg) on up to `want` helpers besides the caller" -- fn pulls work items itself, so helpers that wake up late
+ * simply find nothing left, and tickets nobody took are cancelled once the caller's own fn(arg) has returned. */
+static struct {
+	pthread_mutex_t job_lock, m;
+	pthread_cond_t cv_work, cv_done;
+	void *(*fn)(void *);
+	void *arg;
+	int tickets, running, nthreads;
+} g_pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, NULL, NULL, 0, 0, 0};
+
+static void *pool_helper(void *unused)
+{
+	(void)unused;
+	pthread_mutex_lock(&g_pool.m);
+	for (;;) {
+		void *(*fn)(void *);
+		void *arg;
+		while (g_pool.tickets == 0)
+			pthread_cond_wait(&g_pool.cv_work, &g_pool.m);
+		--g_pool.tickets;
+		++g_pool.running;
+		fn = g_pool.fn;
+		arg = g_pool.arg;
+		pthread_mutex_unlock(&g_pool.m);
+		fn(arg);
+		pthread_mutex_lock(&g_pool.m);
+		if (--g_pool.running == 0 && g_pool.tickets == 0)
+			pthread_cond_signal(&g_pool.cv_done);
+	}
+	return NULL;
+}
+
+static void run_on_pool(void *(*fn)(void *), void *arg, int threads)
+{
+	int want = threads - 1;
+	if (want > 255)
+		want = 255;
+	if (want <= 0) {
+		fn(arg);
+		return;
+	}
+	pthread_mutex_lock(&g_pool.job_lock);
+	pthread_mutex_lock(&g_pool.m);
+	while (g_pool.nthreads < want) {
+		pthread_t t;
+		pthread_attr_t a;
+		pthread_attr_init(&a);
+		pthread_attr_setdetachstate(&a, PTHREAD_CREATE_DETACHED);
+		if (pthread_create(&t, &a, pool_helper, NULL) != 0) {
+			pthread_attr_destroy(&a);
+			break;
+		}
+		pthread_attr_destroy(&a);
+		++g_pool.nthreads;
+	}
+	if (want > g_pool.nthreads)
+		want = g_pool.nthreads;
+	g_pool.fn = fn;
+	g_pool.arg = arg;
+	g_pool.tickets = want;
+	pthread_cond_broadcast(&g_pool.cv_work);
+	pthread_mutex_unlock(&g_pool.m);
+	fn(arg);
+	pthread_mutex_lock(&g_pool.m);
+	g_pool.tickets = 0; /* helpers that have not started yet would find no work left */
+	while (g_pool.running > 0)
+		pthread_cond_wait(&g_pool.cv_done, &g_pool.m);
+	pthread_mutex_unlock(&g_pool.m);
+	pthread_mutex_unlock(&g_pool.job_lock);
+}
+
 static void run_pool(pool_t *p, void *(*fn)(void *), int threads)
 {
-	pthread_t tid[256];
-	int i, started = 0;
 	p->next = 0;
 	if (threads > p->n)
 		threads = p->n > 0 ? p->n : 1;
-	for (i = 1; i < threads; ++i)
-		if (pthread_create(&tid[started], NULL, fn, p) == 0)
-			++started;
-	fn(p);
-	for (i = 0; i < started; ++i)
-		pthread_join(tid[i], NULL);
+	run_on_pool(fn, p, threads);
 }
 
 struct mjh_gpu_job {
@@ -243,9 +305,15 @@ mjh_gpu_job *mjh_decode_batch_gpu_begin(mij_batch *b, const uint8_t *const *bufs
 		rc = MIJ_E_NOMEM;
 		goto fail;
 	}
+	double t0_ = 0, t1_ = 0, t2_ = 0, t3_ = 0;
+	struct timespec ts_;
+	const int timing_ = getenv("MIJ_TIMING") != NULL;
+#define NOW_(v) do { if (timing_) { clock_gettime(CLOCK_MONOTONIC, &ts_); v = ts_.tv_sec * 1e3 + ts_.tv_nsec * 1e-6; } } while (0)
+	NOW_(t0_);
 	pthread_mutex_init(&p->lock, NULL);
 	run_pool(p, extract_worker, threads);
 	pthread_mutex_destroy(&p->lock);
+	NOW_(t1_);
 	/* slots in input order */
 	for (i = 0; i < n; ++i) {
 		p->descs[i] = p->scans[i].desc;
@@ -270,7 +338,11 @@ mjh_gpu_job *mjh_decode_batch_gpu_begin(mij_batch *b, const uint8_t *const *bufs
 		if (slots[i] > j->max_slot)
 			j->max_slot = slots[i];
 	}
+	NOW_(t2_);
 	rc = mij_batch_entropy_launch(b);
+	NOW_(t3_);
+	if (timing_)
+		fprintf(stderr, "gpu_begin: extract %.3f ms, add_stream %.3f ms, launch %.3f ms\n", t1_ - t0_, t2_ - t1_, t3_ - t2_);
 	if (rc != MIJ_OK)
 		goto fail;
 	return j;
@@ -316,12 +388,17 @@ int mjh_decode_batch_gpu_end(mjh_gpu_job *j)
 	for (i = 0; i < p->n; ++i)
 		if (p->status[i] == 1 && !j->todo[i])
 			++gpu_ok;
-	/* the host walk for what the GPU did not take */
+	/* the host walk for what the GPU did not take (usually nothing) */
 	p->todo = j->todo;
 	p->ok = 0;
-	pthread_mutex_init(&p->lock, NULL);
-	run_pool(p, worker, j->threads);
-	pthread_mutex_destroy(&p->lock);
+	for (i = 0; i < p->n; ++i)
+		if (p->slots[i] >= 0 && j->todo[i])
+			break;
+	if (i < p->n) {
+		pthread_mutex_init(&p->lock, NULL);
+		run_pool(p, worker, j->threads);
+		pthread_mutex_destroy(&p->lock);
+	}
 	rc = gpu_ok + p->ok;
 out:
 	free(img_of_slot);

@@ -261,7 +261,7 @@ struct EsWriter { /* where the blocks of the write pass go */
 		if (owner) {
 			if (!((MIJ_VARIANT & 512) && acc != 0x12345678u)) /* ablation bit 512: no meta stores */
 				meta[ord] = (uint64_t)acc | ((uint64_t)(uint16_t)(int16_t)dcd << 32);
-		} else
+		} else if (!sc->fmt)
 			reinterpret_cast<uint32_t *>(meta + ord)[0] += acc;
 		acc = 0;
 		esc = false;
@@ -329,7 +329,7 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &
 			} else {
 				if (WRITE && !wr->skip) {
 					wr->put(k, v, s.c);
-					if (!(MIJ_VARIANT & 1024)) { /* ablation bit 1024: no L1 accumulation */
+					if (!sc.fmt) { /* compact planes: k_es_pack has the whole block in registers and sums its L1 there */
 						const int dq = (int)(int16_t)((uint32_t)v * loc.qz[tb & 255u][k]);
 						wr->acc += (uint32_t)(dq < 0 ? -dq : dq);
 					}
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(256) void k_es_tails(const DevScan *__restrict__ sc
  * rows stored coalesced.  Byte 0 (the DC's place) carries the block's flags through.  Blocks of a tile beyond the
  * component's grid come out as zeros.  work.comp = component, work.first = first block. */
 __global__ __launch_bounds__(256) void k_es_pack(const DevImage *__restrict__ imgs, const WorkIdct *__restrict__ work, const uint8_t *__restrict__ zz,
-																 uint8_t *__restrict__ coef)
+																 uint8_t *__restrict__ coef, uint64_t *__restrict__ meta)
 {
 	const WorkIdct wk = work[blockIdx.x];
 	const DevImage &im = imgs[wk.img];
@@ -645,10 +645,11 @@ __global__ __launch_bounds__(256) void k_es_pack(const DevImage *__restrict__ im
 #pragma unroll
 	for (int i = 0; i < 16; ++i)
 		in[i] = 0;
+	uint32_t ord = 0;
 	if (L < nblk) {
 		const uint32_t by = L / (uint32_t)cp.bw, bx = L - by * (uint32_t)cp.bw;
 		const uint32_t mx = bx / (uint32_t)cp.h, dx = bx - mx * (uint32_t)cp.h, my = by / (uint32_t)cp.v, dy = by - my * (uint32_t)cp.v;
-		const uint32_t ord = (my * (uint32_t)im.mcu_x + mx) * im.es_bpm + im.es_j0[wk.comp] + dy * (uint32_t)cp.h + dx;
+		ord = (my * (uint32_t)im.mcu_x + mx) * im.es_bpm + im.es_j0[wk.comp] + dy * (uint32_t)cp.h + dx;
 		const uint4 *src = reinterpret_cast<const uint4 *>(zz + ((size_t)(im.es_blk_off + ord) << 6));
 #pragma unroll
 		for (int i = 0; i < 4; ++i) {
@@ -669,6 +670,33 @@ __global__ __launch_bounds__(256) void k_es_pack(const DevImage *__restrict__ im
 #pragma unroll
 	for (int c = 0; c < 8; ++c)
 		*reinterpret_cast<uint2 *>(dst + (c << 9)) = make_uint2(out[2 * c], out[2 * c + 1]);
+	if (L >= nblk)
+		return;
+	/* the block's L1 of de-quantised AC coefficients (the bound behind MIJ_FLAG_WIDE_IDCT; k_es_dc adds the DC term and takes
+	 * the maximum): sum over the positions of |(short)(coef * q)|, escape bytes included where the block has them */
+	const uint32_t *dq = im.dq[wk.comp];
+	const bool esc = (out[0] & 1u) != 0;
+	uint32_t hi[16];
+#pragma unroll
+	for (int i = 0; i < 16; ++i)
+		hi[i] = 0;
+	if (esc) {
+		const uint4 *hp = reinterpret_cast<const uint4 *>(coef + cp.hi_off + ((size_t)L << 6));
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			const uint4 v = hp[i];
+			hi[4 * i] = v.x, hi[4 * i + 1] = v.y, hi[4 * i + 2] = v.z, hi[4 * i + 3] = v.w;
+		}
+	}
+	uint32_t l1 = 0;
+#pragma unroll
+	for (int P = 1; P < 64; ++P) { /* position 0 is the DC's place */
+		const int lo8 = (int)(int8_t)((out[P >> 2] >> (8 * (P & 3))) & 255u), hi8 = (int)(int8_t)((hi[P >> 2] >> (8 * (P & 3))) & 255u);
+		const uint32_t q = (dq[P >> 1] >> (16 * (P & 1))) & 0xffffu;
+		const int v = (int)(int16_t)((uint32_t)(lo8 + 256 * hi8) * q);
+		l1 += (uint32_t)(v < 0 ? -v : v);
+	}
+	reinterpret_cast<uint32_t *>(meta + im.es_blk_off + ord)[0] = l1;
 }
 
 /* DC prediction (codec/jpeg.c:323-325), L1 bound and the completion checks; one workgroup per scan */
