@@ -381,7 +381,7 @@ def end_to_end(ica, ctx, datas, distinct, n_img, src_hash, cbytes, obytes, args)
     ebs = [ica.Batch(ctx, chunk, cbytes * chunk, cbytes * chunk, obytes * chunk) for _ in range(2)]
     jl = [datas[i % distinct] for i in range(n_e)]
     for eb in ebs:  # warm the pool / page in staging
-        eb.decode_jpegs(jl[:chunk], 3, threads)
+        eb.decode_jpegs(jl[:chunk], 3, threads, gpu_entropy=False)
         eb.submit()
         eb.wait()
     t_host = 0.0
@@ -392,7 +392,7 @@ def end_to_end(ica, ctx, datas, distinct, n_img, src_hash, cbytes, obytes, args)
         eb.reset()  # waits for this batch's previous chunk
         part = jl[lo:lo + chunk]
         th = time.perf_counter()
-        ok, slots, reasons = eb.decode_jpegs(part, 3, threads)
+        ok, slots, reasons = eb.decode_jpegs(part, 3, threads, gpu_entropy=False)
         t_host += time.perf_counter() - th
         assert ok == len(part), reasons
         eb.submit()
@@ -419,7 +419,7 @@ def end_to_end(ica, ctx, datas, distinct, n_img, src_hash, cbytes, obytes, args)
         eb = ebs[k & 1]
         eb.reset()
         part = jl[lo:lo + chunk]
-        ok, slots, reasons = eb.decode_jpegs(part, 3, threads)
+        ok, slots, reasons = eb.decode_jpegs(part, 3, threads, gpu_entropy=False)
         eb.submit()
         eb.fetch_all_async(pins[k & 1].ptr, pins[k & 1].nbytes)
         last[k & 1] = (lo + len(part) - 1, slots[len(part) - 1])

@@ -566,9 +566,10 @@ class Batch:
             d.color = d2.color
         return slot
 
-    def decode_jpegs(self, datas, req_comp=0, threads=1, gpu_entropy=False):
-        """mjh_decode_batch: host stage of many JPEGs on a thread pool into this batch's staging
-        (gpu_entropy: mjh_decode_batch_gpu -- the Huffman walk itself on the GPU where it applies).
+    def decode_jpegs(self, datas, req_comp=0, threads=1, gpu_entropy=None):
+        """gpu_entropy None: mjh_decode_batch, the default front end (Huffman walk on the GPU where it applies, host walk
+        as the fallback; the batch gets its entropy arena on first use); False: mjh_decode_batch_host (every walk on the
+        host threads); True: mjh_decode_batch_gpu (needs entropy_reserve).
         -> (n_ok, slots, reasons); slots[i] < 0 marks a rejected image (reasons[i] says why)."""
         n = len(datas)
         bufs = (C.c_char_p * n)(*[bytes(d) for d in datas])
@@ -576,7 +577,7 @@ class Batch:
         slots = (C.c_int * n)()
         reasons = (C.c_char_p * n)()
         first = len(self.descs)
-        fn = lib().mjh_decode_batch_gpu if gpu_entropy else lib().mjh_decode_batch
+        fn = lib().mjh_decode_batch if gpu_entropy is None else (lib().mjh_decode_batch_gpu if gpu_entropy else lib().mjh_decode_batch_host)
         fn.argtypes = lib().mjh_decode_batch.argtypes
         rc = fn(self._h, bufs, lens, n, int(req_comp), int(threads), slots, reasons)
         if rc < 0:

@@ -75,7 +75,8 @@ static void *worker(void *arg)
 
 static void run_pool(pool_t *p, void *(*fn)(void *), int threads);
 
-int mjh_decode_batch(mij_batch *b, const uint8_t *const *bufs, const int *lens, int n, int req_comp, int threads, int *slots, const char **reasons)
+/* the host-only front end: every Huffman walk on the host threads */
+int mjh_decode_batch_host(mij_batch *b, const uint8_t *const *bufs, const int *lens, int n, int req_comp, int threads, int *slots, const char **reasons)
 {
 	pool_t p;
 	int i;
@@ -412,10 +413,49 @@ int mjh_decode_batch_gpu(mij_batch *b, const uint8_t *const *bufs, const int *le
 	mjh_gpu_job *j = mjh_decode_batch_gpu_begin(b, bufs, lens, n, req_comp, threads, slots, reasons, &rc);
 	if (!j) {
 		if (rc == MIJ_E_STATE) /* no entropy arena reserved: the host-only front end */
-			return mjh_decode_batch(b, bufs, lens, n, req_comp, threads, slots, reasons);
+			return mjh_decode_batch_host(b, bufs, lens, n, req_comp, threads, slots, reasons);
 		return rc;
 	}
 	return mjh_decode_batch_gpu_end(j);
+}
+
+/* bytes of entropy arena a list of files needs (mjh_decode_batch_gpu_begin gives every image a region a little larger
+ * than its file) */
+static size_t entropy_bytes_for(const int *lens, int n)
+{
+	size_t used = 0;
+	int i;
+	for (i = 0; i < n; ++i) {
+		const size_t len = (size_t)(lens[i] > 0 ? lens[i] : 0);
+		used += (len + len / 8 + 4096 + 255) / 256 * 256;
+	}
+	return used;
+}
+
+/* 1: the Huffman walk runs on the GPU by default, host walk as the fallback (MIJ_ENTROPY=host turns that off) */
+int mjh_gpu_walk_default(void)
+{
+	const char *e = getenv("MIJ_ENTROPY");
+	return !(e && !strcmp(e, "host"));
+}
+
+/* The default front end: the Huffman walk on the GPU wherever it applies.  The batch gets its entropy arena on first
+ * use, sized for this call; a later call that needs more than the arena holds takes the host walk. */
+int mjh_decode_batch(mij_batch *b, const uint8_t *const *bufs, const int *lens, int n, int req_comp, int threads, int *slots, const char **reasons)
+{
+	size_t cap = 0;
+	if (!b || !bufs || !lens || !slots || !reasons || n < 0)
+		return MIJ_E_ARG;
+	if (!mjh_gpu_walk_default() || n == 0)
+		return mjh_decode_batch_host(b, bufs, lens, n, req_comp, threads, slots, reasons);
+	if (!mij_batch_entropy_stage(b, &cap)) {
+		if (mij_batch_image_count(b) != 0 || mij_batch_entropy_reserve(b, entropy_bytes_for(lens, n) + 4096) != MIJ_OK)
+			return mjh_decode_batch_host(b, bufs, lens, n, req_comp, threads, slots, reasons);
+		(void)mij_batch_entropy_stage(b, &cap);
+	}
+	if (entropy_bytes_for(lens, n) > cap)
+		return mjh_decode_batch_host(b, bufs, lens, n, req_comp, threads, slots, reasons);
+	return mjh_decode_batch_gpu(b, bufs, lens, n, req_comp, threads, slots, reasons);
 }
 
 /* ------------------------------------------------------------------ one logical batch over several devices

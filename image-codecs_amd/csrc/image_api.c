@@ -60,10 +60,10 @@ static mij_ctx *shared_ctx(void)
 
 typedef struct {
 	mij_batch *b;
-	size_t coef_cap, out_cap;
+	size_t coef_cap, out_cap, stream_cap;
 } tl_batch;
 
-static __thread tl_batch t_batch = {NULL, 0, 0};
+static __thread tl_batch t_batch = {NULL, 0, 0, 0};
 static pthread_key_t g_batch_key;
 static pthread_once_t g_batch_key_once = PTHREAD_ONCE_INIT;
 
@@ -74,19 +74,22 @@ static void batch_key_dtor(void *p)
 }
 static void batch_key_init(void) { pthread_key_create(&g_batch_key, batch_key_dtor); }
 
-/* a one-image batch big enough for `d`, grown geometrically and reused across calls */
-static mij_batch *thread_batch(mij_ctx *ctx, const mij_image_desc *d)
+/* a one-image batch big enough for `d` (and, stream_bytes > 0, with an entropy arena for a file of that many bytes: the GPU
+ * Huffman walk), grown geometrically and reused across calls */
+static mij_batch *thread_batch(mij_ctx *ctx, const mij_image_desc *d, size_t stream_bytes)
 {
 	size_t cb = mij_image_coef_bytes(d), ob = mij_image_out_bytes(d);
-	if (t_batch.b && cb <= t_batch.coef_cap && ob <= t_batch.out_cap) {
+	if (t_batch.b && cb <= t_batch.coef_cap && ob <= t_batch.out_cap && stream_bytes <= t_batch.stream_cap) {
 		if (mij_batch_reset(t_batch.b) != MIJ_OK)
 			return NULL;
 		return t_batch.b;
 	}
 	if (t_batch.b) {
+		if (stream_bytes < t_batch.stream_cap)
+			stream_bytes = t_batch.stream_cap; /* keep what earlier calls needed */
 		mij_batch_destroy(t_batch.b);
 		t_batch.b = NULL;
-		t_batch.coef_cap = t_batch.out_cap = 0;
+		t_batch.coef_cap = t_batch.out_cap = t_batch.stream_cap = 0;
 	}
 	{
 		size_t ccap = cb + cb / 4 + 4096, ocap = ob + ob / 4 + 4096;
@@ -98,9 +101,15 @@ static mij_batch *thread_batch(mij_ctx *ctx, const mij_image_desc *d)
 			ccap = cb;
 			ocap = ob;
 		}
+		if (stream_bytes) {
+			stream_bytes += stream_bytes / 4 + 8192;
+			if (mij_batch_entropy_reserve(b, stream_bytes) != MIJ_OK)
+				stream_bytes = 0; /* no arena: the host walk does it */
+		}
 		t_batch.b = b;
 		t_batch.coef_cap = ccap;
 		t_batch.out_cap = ocap;
+		t_batch.stream_cap = stream_bytes;
 		pthread_once(&g_batch_key_once, batch_key_init);
 		pthread_setspecific(g_batch_key, b);
 	}
@@ -128,6 +137,53 @@ static void vertical_flip(void *image, int w, int h, int bytes_per_pixel)
 			left -= n;
 		}
 	}
+}
+
+static size_t gpu_walk_min_pixels(void)
+{
+	const char *e = getenv("MIJ_GPU_WALK_MIN_PIXELS");
+	return e ? (size_t)strtoull(e, NULL, 10) : (size_t)512 * 512;
+}
+
+/* One image through the GPU Huffman walk: NULL when the file is not a layout the walk takes, when the walk reports the
+ * stream back, or on any resource problem -- the caller then takes the host walk. */
+static unsigned char *load_gpu_walk(mij_ctx *ctx, const uint8_t *buf, int len, int req_comp, const mij_image_desc *desc)
+{
+	mjg_scan *scan;
+	mij_batch *b;
+	uint8_t *stage;
+	size_t cap = 0, slen = 0, nbytes;
+	const char *why = NULL;
+	unsigned char *pixels = NULL;
+	int slot, nfb = 0, fb[1];
+	if (len <= 0)
+		return NULL;
+	b = thread_batch(ctx, desc, (size_t)len + (size_t)len / 8 + 8192);
+	if (!b || !(stage = mij_batch_entropy_stage(b, &cap)))
+		return NULL;
+	scan = (mjg_scan *)malloc(sizeof(*scan));
+	if (!scan)
+		return NULL;
+	if (mjh_extract_scan(buf, len, req_comp, scan, stage, cap, &slen, &why) != 1)
+		goto out;
+	slot = mij_batch_add_stream(b, scan, stage, slen);
+	if (slot < 0)
+		goto out;
+	if (mij_batch_entropy_run(b, fb, 1, &nfb) != MIJ_OK || nfb != 0)
+		goto out;
+	nbytes = (size_t)scan->desc.n_out * (size_t)scan->desc.width * (size_t)scan->desc.height;
+	if (nbytes > 0x7fffffffu - 1)
+		goto out;
+	pixels = (unsigned char *)malloc(nbytes + 1); /* codec/jpeg.c:2293: n * x * y + 1 bytes */
+	if (!pixels)
+		goto out;
+	if (mij_batch_submit(b) != MIJ_OK || mij_batch_fetch(b, slot, pixels, nbytes) != MIJ_OK) {
+		free(pixels);
+		pixels = NULL;
+	}
+out:
+	free(scan);
+	return pixels;
 }
 
 /* stbi__load_main (image_api.c:3-56) + stbi__jpeg_load / load_jpeg_image (codec/jpeg.c:2224-2452) */
@@ -172,7 +228,22 @@ static unsigned char *load_main(mjh_reader *r, int *x, int *y, int *comp, int re
 		free(d);
 		return fail_ptr("no gpu device");
 	}
-	b = thread_batch(ctx, &desc);
+	/* Large pictures from memory: the Huffman walk itself on the GPU (mij.h, "GPU entropy stage") when the file is a layout
+	 * it takes; whatever it does not take, or reports back, is walked below exactly as before, so failure reasons and
+	 * the treatment of damaged streams stay the reference's.  Small pictures are quicker on the host (the GPU walk is a
+	 * dozen launches); callback and FILE sources are walked as they arrive. */
+	if (r->io.read == NULL && mjh_gpu_walk_default() && (size_t)desc.width * (size_t)desc.height >= gpu_walk_min_pixels()) {
+		unsigned char *px = load_gpu_walk(ctx, r->orig, (int)(r->orig_end - r->orig), req_comp, &desc);
+		if (px) {
+			*x = desc.width;
+			*y = desc.height;
+			if (comp)
+				*comp = d->img_n >= 3 ? 3 : 1;
+			free(d);
+			return px;
+		}
+	}
+	b = thread_batch(ctx, &desc, 0);
 	if (!b) {
 		free(d);
 		return fail_ptr("outofmem");

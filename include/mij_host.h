@@ -41,16 +41,24 @@ int mjh_decode_memory(const uint8_t *buf, int len, int req_comp, mij_image_desc 
 int mjh_extract_scan(const uint8_t *buf, int len, int req_comp, mjg_scan *scan, uint8_t *stream, size_t stream_cap, size_t *stream_len, const char **reason);
 
 /*
- * Batch front end: the host stage of n JPEGs on `threads` host threads (one image per task),
- * straight into a mij batch's pinned staging.  Images are added to the batch in input order
+ * Batch front end: n JPEGs into a mij batch.  Images are added to the batch in input order
  * (slots[i] = the slot of image i, or -1 with reasons[i] set when its header is rejected);
  * an image whose entropy data is rejected keeps its slot but is flagged MIJ_FLAG_SKIP (reasons[i]
  * set, slot reported as -1 - slot).  Follow with mij_batch_submit().  Returns the number of
  * images decoded successfully, or a negative MIJ_E_* code when the batch arenas are too small.
- * The end-to-end rate of this path is bounded by the Huffman walk (about 0.25-0.5 Gpix/s per host
- * core) and by PCIe (3 B/px up), not by the GPU.
+ *
+ * mjh_decode_batch       the DEFAULT: the Huffman walk itself runs on the GPU wherever it applies (single-scan baseline
+ *                        files; mjh_decode_batch_gpu below), the host walk is the fallback for every other layout and for
+ *                        any stream the GPU walk reports back.  The batch gets its entropy arena on first use (sized for
+ *                        that call; a later, larger call takes the host walk).  Environment MIJ_ENTROPY=host selects the
+ *                        host-only front end instead (mjh_gpu_walk_default() says which is in force).
+ * mjh_decode_batch_host  the host stage of every image on `threads` host threads (one image per task), straight into the
+ *                        batch's pinned staging -- what north_star describes ("the C host keeps the Huffman walk"); its
+ *                        end-to-end rate is bounded by the walk (about 0.25-0.5 Gpix/s per host core) and by PCIe.
  */
 int mjh_decode_batch(mij_batch *b, const uint8_t *const *bufs, const int *lens, int n, int req_comp, int threads, int *slots, const char **reasons);
+int mjh_decode_batch_host(mij_batch *b, const uint8_t *const *bufs, const int *lens, int n, int req_comp, int threads, int *slots, const char **reasons);
+int mjh_gpu_walk_default(void);
 
 /*
  * One logical batch over several devices (BASELINE config 3; north_star: "sharded across the 8 GPUs of one node on

@@ -272,3 +272,59 @@ def test_compact_planes_are_the_default(ica, oracle, gpu_ctx):
         assert b.slot_escapes(slots[7]) > 0
         assert {b.slot_path(s_) for s_ in slots} == {1, 3, 5}
         b.close()
+
+
+def test_gpu_walk_is_the_default_front_end(ica, oracle, gpu_ctx, golden, monkeypatch):
+    """mjh_decode_batch without any preparation: the batch gets its entropy arena on first use, baseline single-scan files
+    are walked on the GPU (no staging needed for them), everything else and every damaged stream by the host walk --
+    verdicts, reasons and pixels are the oracle's.  MIJ_ENTROPY=host turns the default off."""
+    import helpers
+    good = [ica.synth_jpeg(200 + 16 * i, 120 + 8 * i, i, (90, 95, 50)[i % 3]) for i in range(6)]
+    datas = good + [golden.jpg(n) for n in ("prog_420_64x64", "cmyk_40x30", "grey_33x20", "garbage", "trunc_noeoi", "rst_blocks_64x48")]
+    datas += [helpers.mutate(good[k % 6], 900 + k, n_mut=1 + k % 3, allow_markers=(k % 5 == 0)) for k in range(40)]
+    for mode in ("default", "host"):
+        if mode == "host":
+            monkeypatch.setenv("MIJ_ENTROPY", "host")
+        b = ica.Batch(gpu_ctx, len(datas), 64 << 20, 64 << 20, 64 << 20)
+        ok, slots, reasons = b.decode_jpegs(datas, 3, threads=4)
+        b.submit()
+        b.wait()
+        n_ok = 0
+        for i, d in enumerate(datas):
+            kind, want, _ = oracle.load(d, 3)
+            if slots[i] >= 0:
+                assert kind == "ok", (mode, i, want)
+                assert np.array_equal(b.fetch(slots[i]), want), (mode, i)
+                n_ok += 1
+            else:
+                assert kind == "fail" and reasons[i] == want, (mode, i, reasons[i], want)
+        assert ok == n_ok
+        b.close()
+    monkeypatch.delenv("MIJ_ENTROPY")
+
+
+def test_stbi_load_from_memory_takes_the_gpu_walk_for_large_pictures(ica, oracle, gpu_ctx, golden, monkeypatch):
+    """>= 512x512 pixels from memory: header on the host, Huffman walk + everything else on the GPU.  With the threshold
+    at zero every golden stream goes through the same entry: what the GPU walk does not take or reports back falls
+    through to the host walk, so results and failure reasons stay the reference's."""
+    for (w, h, q) in ((512, 512, 90), (1920, 1080, 90), (800, 600, 95)):
+        data = ica.synth_jpeg(w, h, seed=w, quality=q)
+        for req in (0, 3, 4, 1):
+            got = ica.stbi_load_from_memory(data, req)
+            assert got is not None, ica.stbi_failure_reason()
+            assert np.array_equal(got[0], oracle.load(data, req)[1]), (w, h, req)
+    monkeypatch.setenv("MIJ_GPU_WALK_MIN_PIXELS", "0")
+    for name in golden.names:
+        data = golden.jpg(name)
+        for req in (0, 3):
+            kind, want = golden.expect(name, req)
+            if kind == "skip":
+                continue
+            got = ica.stbi_load_from_memory(data, req)
+            if kind == "fail":
+                assert got is None and ica.stbi_failure_reason() == want, (name, req, ica.stbi_failure_reason())
+            else:
+                assert got is not None, (name, req, ica.stbi_failure_reason())
+                if name == "dri_without_rst":
+                    want = oracle.load(data, req)[1]
+                assert np.array_equal(got[0], want), (name, req)
