@@ -552,7 +552,11 @@ static bool fused_grey_ok(const mij_batch *b, const mij_image_desc &d)
 {
 	if (b->force_generic || (d.flags & MIJ_FLAG_SKIP))
 		return false;
-	return d.ncomp == 1 && d.color == MIJ_COLOR_GREY && d.n_out >= 1 && d.n_out <= 4 && (uint64_t)d.width * d.height * d.n_out < 0xfffffff0ull;
+	/* one component -- or the luma of a YCbCr file asked for as grey (req_comp 1 / 2: the reference resamples only component 0
+	 * then, codec/jpeg.c:2246,:2380-2430), when the luma plane has the picture's own resolution: the chroma planes are not even
+	 * transformed */
+	const bool luma_only = d.ncomp == 3 && d.comp[0].h == d.h_max && d.comp[0].v == d.v_max && d.n_out < 3;
+	return (d.ncomp == 1 || luma_only) && d.color == MIJ_COLOR_GREY && d.n_out >= 1 && d.n_out <= 4 && (uint64_t)d.width * d.height * d.n_out < 0xfffffff0ull;
 }
 
 /* can the fused h2v1 kernel take this image? */
