@@ -32,6 +32,8 @@ The one JSON line (rank 0) also carries, all OUTSIDE the timed region and only a
   legs.config4          BASELINE configs[3]: 32 x 4096x4096 progressive 4:4:4 (k_fused444), 9 B/px
   legs.config5          BASELINE configs[4]: 1024 x 1080p RGB -> data units (k_encode420), bytes == reference
   legs.h2v1             512 x 1080p 4:2:2 (k_fused422), 7 B/px
+  legs.two_pass         256 x 1080p through the two-pass family (sample planes in HBM, pass 2 compiled per resampler):
+                        the headline images forced off the fused kernel, 4:4:0 and Adobe CMYK
   end_to_end            bitstream in host RAM -> pixels in HBM (host walk; GPU walk), never `value`
   cpu_baseline          the reference itself (oracle/_ref, compiled in place in the build container and shipped
                         as a .so; "reference") -- or, when that .so is absent (clean checkout), our CPU
@@ -154,13 +156,15 @@ def cpu_baseline(datas, want_seconds=12.0, gpu_pixels=None):
 
 # ---------------------------------------------------------------------------------------------------- resident batches
 
-def resident_batch(ica, ctx, datas, first, count, fmt, cbytes, obytes):
+def resident_batch(ica, ctx, datas, first, count, fmt, cbytes, obytes, generic=0):
     """Images first .. first+count-1 of the logical batch (image g uses source g % len(datas)) resident in HBM in the
     given plane format: the first occurrence of every source is host-walked into pinned staging, the others are clones
     with their own device buffers.  -> (batch, (source index, source slot or None) of every slot, seconds of host walk)"""
     distinct = len(datas)
     bt = ica.Batch(ctx, count, cbytes * min(distinct, count), cbytes * count, obytes * count)
     bt.set_coef_format(fmt)
+    if generic:
+        bt.force_generic(generic)
     src_slot, owners = {}, []
     t0 = time.time()
     for i in range(count):
@@ -238,9 +242,9 @@ def add_traffic(res, key):
 
 # ---------------------------------------------------------------------------------------------------- secondary legs
 
-def leg_decode_1080p(ica, ctx, datas, count, fmt, cbytes, obytes, args, expect_path=1, src_hash=None, checker=None):
+def leg_decode_1080p(ica, ctx, datas, count, fmt, cbytes, obytes, args, expect_path=1, src_hash=None, checker=None, generic=0):
     """Kernel-resident timing of `count` 1080p images in the given plane format; returns (result dict, plane format seen)."""
-    bt, owners, _ = resident_batch(ica, ctx, datas, 0, count, fmt, cbytes, obytes)
+    bt, owners, _ = resident_batch(ica, ctx, datas, 0, count, fmt, cbytes, obytes, generic)
     try:
         bt.launch()
         bt.wait()
@@ -369,6 +373,28 @@ def leg_h2v1(ica, ctx, args, checker):
                 "algorithmic_bytes_per_launch": algo, "mpix_s": round(n * W * H / ms / 1e3, 1), "frac": round(frac_of(algo, ms), 4), "parity_against": checker[1]})
     add_traffic(res, "k_fused422_compact_%d" % n)
     return res
+
+
+def leg_two_pass(ica, ctx, datas, args, checker):
+    """The two-pass family (k_idct_planes, then k_resample_fast compiled per resampler) on 256 x 1080p: the headline 4:2:0
+    images forced off the fused kernel, and two layouts that only have this path (4:4:0, Adobe CMYK).  ms = both passes of
+    one launch; algorithmic bytes as for the fused kernels (2 B x coefficients + 3 x W x H)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers
+    n = 256
+    plan, du = ica.host_transform(ica.synth_rgb(W, H, 2), 92)
+    cases = (("h2v2_forced", datas[0], 1), ("h1v2_440", helpers.baseline_layout_from_444(plan, du, [(1, 2), (1, 1), (1, 1)], -1), 0),
+             ("cmyk_adobe", helpers.baseline_layout_from_444(plan, du, [(1, 1)] * 4, 0), 0))
+    out = {"images": n, "kernels": "mij::k_idct_planes<false,true> + mij::k_resample_fast<RS_HV2 | RS_V2 | RS_ROW1, ...>", "parity_against": checker[1]}
+    for name, data, generic in cases:
+        d = ica.HostDecoder.probe(data, 3)
+        cb, ob = ica.Batch.coef_bytes(d), ica.Batch.out_bytes(d)
+        res, _ = leg_decode_1080p(ica, ctx, [data], n, "compact", cb, ob, args, expect_path=2, checker=checker, generic=generic)
+        algo = n * (128 * sum(d.comp[c].bw * d.comp[c].bh for c in range(d.ncomp)) + 3 * W * H)
+        ms = res["kernel_ms_per_launch"]
+        out[name] = {"ms_per_launch": round(ms, 4), "mpix_s": round(n * W * H / ms / 1e3, 1), "algorithmic_bytes_per_launch": algo,
+                     "frac": round(frac_of(algo, ms), 4), "parity": res["parity"]}
+    return out
 
 
 def end_to_end(ica, ctx, datas, distinct, n_img, src_hash, cbytes, obytes, args):
@@ -641,6 +667,7 @@ def main():
         run_leg("config4", lambda: leg_config4(ica, ctx, args, checker))
         run_leg("config5", lambda: leg_config5(ica, ctx, args, checker))
         run_leg("h2v1", lambda: leg_h2v1(ica, ctx, args, checker))
+        run_leg("two_pass", lambda: leg_two_pass(ica, ctx, datas, args, checker))
     if solo and not args.no_e2e:
         try:
             e2e = end_to_end(ica, ctx, datas, distinct, n_img, src_hash, cbytes, obytes, args)

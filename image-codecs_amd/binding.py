@@ -623,7 +623,8 @@ class Batch:
         _check(lib().mij_batch_set_flags(self._h, int(slot), int(flags)), "mij_batch_set_flags")
 
     def force_generic(self, on=True):
-        _check(lib().mij_batch_force_generic(self._h, int(bool(on))), "mij_batch_force_generic")
+        """True / 1: two-pass path for every image; 2: and the run-time-general pass 2; False / 0: default choice."""
+        _check(lib().mij_batch_force_generic(self._h, int(on)), "mij_batch_force_generic")
 
     def upload(self):
         _check(lib().mij_batch_upload(self._h), "mij_batch_upload")

@@ -967,8 +967,15 @@ __device__ __forceinline__ void strip_row(const ColorK &K, uint32_t wk, uint32_t
 	store_px4<NOUT>(dst, p0, p1, p2, p3);
 }
 
+/* threads per workgroup of k_fused420 (A/B knob: 256 = three workgroups of four waves per CU at 1080p, 512 = two of eight) */
+#ifndef MIJ_F420_NT
+#define MIJ_F420_NT 256
+#endif
+#ifndef MIJ_F420_ATTR
+#define MIJ_F420_ATTR
+#endif
 template <int NOUT, bool WIDE, bool B8 = false>
-__global__ __launch_bounds__(256) void k_fused420(const DevImage *__restrict__ imgs, const WorkBand *__restrict__ work, const uint8_t *__restrict__ coef,
+__global__ __launch_bounds__(MIJ_F420_NT) MIJ_F420_ATTR void k_fused420(const DevImage *__restrict__ imgs, const WorkBand *__restrict__ work, const uint8_t *__restrict__ coef,
 																  uint8_t *__restrict__ outbase)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -1010,7 +1017,7 @@ __global__ __launch_bounds__(256) void k_fused420(const DevImage *__restrict__ i
 
 	/* ---- chroma-only IDCT of block row mc, keeping sample row 7 (keep != 0) or 0 in dstCb/dstCr (halo rows) */
 	auto chroma_halo = [&](int mc, int keep, uint8_t *dstCb, uint8_t *dstCr) {
-		for (int ww = wave; ww < 2 * nCw; ww += 4) {
+		for (int ww = wave; ww < 2 * nCw; ww += MIJ_F420_NT / 64) {
 			const int comp = ww < nCw ? 1 : 2;
 			const int bx = (comp == 1 ? ww : ww - nCw) * 64 + lane;
 			if (bx < bwC) {
@@ -1080,8 +1087,15 @@ __global__ __launch_bounds__(256) void k_fused420(const DevImage *__restrict__ i
 			if (doA)
 				strip_row<NOUT>(KC, KC.wAk, KC.wAk1, vb0, vb1, vb2, vr0, vr1, vr2, in.yA, out + (offA + xo));
 		};
-		for (int base = 0; base < nfast; base += 512) {
-			const int sa = base + tid, sb = sa + 256;
+		if (MIJ_F420_NT >= 512) { /* one strip per thread and iteration: a 1080p row is 480 strips */
+			for (int sa = tid; sa < nfast; sa += MIJ_F420_NT) {
+				StripIn ia;
+				load_strip(sa, ia);
+				do_strip(sa, ia);
+			}
+		} else
+		for (int base = 0; base < nfast; base += 2 * MIJ_F420_NT) {
+			const int sa = base + tid, sb = sa + MIJ_F420_NT;
 			StripIn ia, ib;
 			load_strip(min(sa, nfast - 1), ia);
 			load_strip(min(sb, nfast - 1), ib);
@@ -1091,7 +1105,7 @@ __global__ __launch_bounds__(256) void k_fused420(const DevImage *__restrict__ i
 				do_strip(sb, ib);
 		}
 		/* the rest (partial last strip, unaligned widths): careful per-pixel path */
-		for (int s = nfast + tid; s < nstrip; s += 256) {
+		for (int s = nfast + tid; s < nstrip; s += MIJ_F420_NT) {
 			const int x0 = 4 * s, xe = min(x0 + 4, W);
 			for (int x = x0; x < xe; ++x) {
 				if (doA)
@@ -1110,7 +1124,7 @@ __global__ __launch_bounds__(256) void k_fused420(const DevImage *__restrict__ i
 	for (int m = m0; m < m1; ++m) {
 		__syncthreads(); /* previous phase B (and the prologue) done with the planes / save buffers */
 		/* ---- phase A: IDCT of MCU row m, one block per lane, component uniform per wave */
-		for (int ww = wave; ww < nYw + 2 * nCw; ww += 4) {
+		for (int ww = wave; ww < nYw + 2 * nCw; ww += MIJ_F420_NT / 64) {
 			uint4 c[8];
 			uint2 rows[8];
 			if (ww < nYw) {
@@ -1165,9 +1179,9 @@ __global__ __launch_bounds__(256) void k_fused420(const DevImage *__restrict__ i
 		/* keep the last rows of this MCU row for the next step (other save buffer: no extra barrier) */
 		{
 			const int nv = sv ^ 1;
-			for (int i = tid; i < YP / 4; i += 256)
+			for (int i = tid; i < YP / 4; i += MIJ_F420_NT)
 				reinterpret_cast<uint32_t *>(saveY + nv * YP)[i] = reinterpret_cast<const uint32_t *>(sY + 15 * YP)[i];
-			for (int i = tid; i < CP / 4; i += 256) {
+			for (int i = tid; i < CP / 4; i += MIJ_F420_NT) {
 				reinterpret_cast<uint32_t *>(saveCb + nv * CP)[i] = reinterpret_cast<const uint32_t *>(sCb + 7 * CP)[i];
 				reinterpret_cast<uint32_t *>(saveCr + nv * CP)[i] = reinterpret_cast<const uint32_t *>(sCr + 7 * CP)[i];
 			}
@@ -1410,6 +1424,198 @@ __global__ __launch_bounds__(256) void k_fused444(const DevImage *__restrict__ i
 			for (int j = 0; j < 8; ++j)
 				if (x0 + j < W)
 					store_rgb_px<NOUT>(dst + j * NOUT, clamp255(opaque(px[j].r >> 12)), clamp255(opaque(px[j].g >> 12)), clamp255(opaque(px[j].b >> 12)));
+		}
+	}
+}
+
+/* ------------------------------------------------------------------ two-pass path, pass 2, specialised per layout
+ *
+ * k_resample_color above decides everything at run time, per sample (resampler, row scheduler, colour branch, byte
+ * loads with a clamp each): about 110 VALU instructions per pixel.  The layouts that actually reach the two-pass path
+ * have component 0 (and 3) at full resolution and components 1 and 2 sharing one pair of factors, so pass 2 is
+ * compiled once per resampler of load_jpeg_image's choice (codec/jpeg.c:2280-2289):
+ *   RS_ROW1  hs 1, vs != 2   resample_row_1, or the generic resampler with hs == 1 (:1765, :1962): the near row
+ *   RS_V2    hs 1, vs 2      resample_row_v_2 (:1774-1782): (3 near + far + 2) >> 2, four samples at once in 16-bit lanes
+ *   RS_H2    hs 2, vs 1      resample_row_h_2 (:1784-1812): one v_dot4_u32_u8 per sample, as k_fused422
+ *   RS_HV2   hs 2, vs 2      resample_row_hv_2 (:1816-1840): one v_dot4_u32_u8 per sample, as k_fused420
+ *   RS_GEN2  hs 2, vs > 2    resample_row_generic (:1962-1971): every sample of the near row twice
+ *   RS_GEN4  hs 4            the same, four times (4:1:1, 4:1:0)
+ * Work item = MIJ_RESAMPLE_ROWS output rows of one image, a thread takes 4-pixel strips: plane bytes come in as dwords,
+ * pixels leave as n_out dwords.  YCC = YCbCr -> RGB through color_px / store_px4 (the fused kernels' arithmetic); otherwise
+ * the colour branch is store_pixel's (RGB-tagged, CMYK, YCCK).  The host sends an image here only if W % 4 == 0,
+ * n_out >= 3 and its factors divide (resample_fast_kind in mij_runtime.hip); everything else stays with k_resample_color.
+ */
+enum { RS_ROW1 = 0, RS_V2, RS_H2, RS_HV2, RS_GEN2, RS_GEN4, RS_KINDS };
+
+/* bytes (c[i0-1], c[i0], c[i0+1], c[i0+2]) of a plane row, i0 even; bytes outside the row are whatever the neighbouring
+ * dword holds (the caller's edge selector replaces them); never reads in front of the row or behind its last dword */
+__device__ __forceinline__ uint32_t rs_window(const uint8_t *__restrict__ row, int i0, int last_dword)
+{
+	/* no branch (the loads of a strip's windows must be in flight together): i0 == 0 takes dword 0 twice and shifts by 3 bytes,
+	 * which leaves (c[3], c[0], c[1], c[2]) -- byte 0 is the one the edge selector replaces */
+	const uint32_t *p = reinterpret_cast<const uint32_t *>(row);
+	const int d0 = (i0 - 1) >> 2;
+	const uint32_t lo = p[max(d0, 0)], hi = p[min(d0 + 1, last_dword)];
+	return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(i0 - 1) & 3u);
+}
+
+/* (3 n + f + 2) >> 2 on the four bytes of n and f (even and odd bytes in 16-bit lanes: 3*255 + 255 + 2 < 2^16) */
+__device__ __forceinline__ uint32_t rs_v2(uint32_t n, uint32_t f)
+{
+	const uint32_t m = 0x00ff00ffu;
+	const uint32_t te = (n & m) * 3u + (f & m) + 0x00020002u, to = ((n >> 8) & m) * 3u + ((f >> 8) & m) + 0x00020002u;
+	return ((te >> 2) & m) | (((to >> 2) & m) << 8);
+}
+
+template <int KIND, bool YCC, int NOUT>
+__global__ __launch_bounds__(256) void k_resample_fast(const DevImage *__restrict__ imgs, const WorkIdct *__restrict__ work, const uint8_t *__restrict__ planes,
+																		 uint8_t *__restrict__ outbase)
+{
+	/* chroma of a strip: four samples packed in one dword (PACKED), or one register per sample with the sample in byte 1 */
+	constexpr bool PACKED = KIND != RS_H2 && KIND != RS_HV2;
+	/* vs == 2 resamplers work on the row pair (2C-1, 2C), which shares the chroma rows C-1 and C (as k_fused420 does): work item
+	 * `first` = chroma rows first/2 and first/2 + 1, i.e. output rows first-1 .. first+2 */
+	constexpr bool PAIRS = KIND == RS_V2 || KIND == RS_HV2;
+	const WorkIdct wk = work[blockIdx.x];
+	const DevImage &im = imgs[wk.img];
+	const int W = im.width, H = im.height;
+	const int nstrip = W >> 2;
+	const int w2Y = im.comp[0].bw * 8, w2C = im.comp[1].bw * 8;
+	const int wc = (W + 1) >> 1, lastdw = (w2C >> 2) - 1;
+	const int vsC = im.comp[1].vs, yC = im.comp[1].y;
+	const bool four = !YCC && (im.color == MIJ_COLOR_CMYK || im.color == MIJ_COLOR_YCCK);
+	const uint8_t *const pY = planes + im.comp[0].plane_off, *const pB = planes + im.comp[1].plane_off, *const pR = planes + im.comp[2].plane_off;
+	const uint8_t *const pK = planes + im.comp[four ? 3 : 0].plane_off;
+	const int w2K = im.comp[four ? 3 : 0].bw * 8;
+	uint8_t *const out = outbase + im.out_off;
+	ColorK KC;
+	KC.init();
+	const uint32_t wE0 = vreg(0x0000c040u), wO0 = vreg(0x0040c000u), wE1 = vreg(0x00c04000u), wO1 = vreg(0x40c00000u); /* h_2 weights x64, see k_fused422 */
+
+	/* colour + store of one strip of row r from its up-sampled chroma */
+	auto luma = [&](int r, int s) -> uint32_t { return *reinterpret_cast<const uint32_t *>(pY + (size_t)r * w2Y + 4 * s); };
+	auto black = [&](int r, int s) -> uint32_t { return four ? *reinterpret_cast<const uint32_t *>(pK + (size_t)r * w2K + 4 * s) : 0u; };
+	auto finish = [&](int r, int s, uint32_t yv, uint32_t kv, uint32_t cb4, uint32_t cr4, const uint32_t (&cbv)[4], const uint32_t (&crv)[4]) {
+		uint8_t *dst = out + ((size_t)r * W + 4 * s) * NOUT;
+		if (YCC) {
+			Rgb12 p[4];
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				/* (chroma | luma << 16): byte j of the packed dword, or byte 1 of the sample's own register */
+				const uint32_t sel = PACKED ? (0x0c000c04u + (uint32_t)j * 0x00010001u) : (0x0c000c05u + ((uint32_t)j << 16));
+				p[j] = color_px(KC, __builtin_amdgcn_perm(PACKED ? cr4 : crv[j], yv, sel), __builtin_amdgcn_perm(PACKED ? cb4 : cbv[j], yv, sel));
+			}
+			store_px4<NOUT>(dst, p[0], p[1], p[2], p[3]);
+		} else {
+			uint8_t px[4][4];
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				const int smp[4] = {(int)((yv >> (8 * j)) & 255u), (int)(PACKED ? (cb4 >> (8 * j)) & 255u : (cbv[j] >> 8) & 255u),
+										  (int)(PACKED ? (cr4 >> (8 * j)) & 255u : (crv[j] >> 8) & 255u), (int)((kv >> (8 * j)) & 255u)};
+				store_pixel(px[j], NOUT, im.color, smp);
+			}
+			uint32_t *q = reinterpret_cast<uint32_t *>(dst);
+			if (NOUT == 4) {
+#pragma unroll
+				for (int j = 0; j < 4; ++j)
+					q[j] = px[j][0] | px[j][1] << 8 | px[j][2] << 16 | (uint32_t)px[j][3] << 24;
+			} else {
+				q[0] = px[0][0] | px[0][1] << 8 | px[0][2] << 16 | (uint32_t)px[1][0] << 24;
+				q[1] = px[1][1] | px[1][2] << 8 | px[2][0] << 16 | (uint32_t)px[2][1] << 24;
+				q[2] = px[2][2] | px[3][0] << 8 | px[3][1] << 16 | (uint32_t)px[3][2] << 24;
+			}
+		}
+	};
+	/* the image's left / right edge of a 2:1 window: column -1 -> 0, column wc -> wc-1 (the reference's end cases are the
+	 * general form with the neighbour clamped); *last: the strip holds pixel 2*(wc-1), h_2's odd one out (codec/jpeg.c:1805) */
+	auto edge_sel = [&](int i0, bool *last) -> uint32_t {
+		uint32_t sel = 0x03020100u;
+		if (i0 == 0)
+			sel = (sel & 0xffffff00u) | 0x01u;
+		*last = i0 + 2 > wc - 1;
+		if (*last)
+			sel = (sel & 0x00ffffffu) | 0x02000000u;
+		return sel;
+	};
+	const uint32_t none[4] = {0, 0, 0, 0};
+
+	if (PAIRS) {
+		for (int C = (int)wk.first >> 1; C < ((int)wk.first >> 1) + 2; ++C) {
+			const int ra = 2 * C - 1, rb = 2 * C;
+			const bool doA = ra >= 0 && ra < H, doB = rb < H;
+			if (!doA && !doB)
+				continue;
+			/* chroma rows line0 / line1 of the scheduler (select_rows): A is near for row 2C-1, B for row 2C */
+			const int rowA = C ? min(C - 1, yC - 1) : 0, rowB = min(C, yC - 1);
+			const uint8_t *const bA_ = pB + (size_t)rowA * w2C, *const bB_ = pB + (size_t)rowB * w2C;
+			const uint8_t *const rA_ = pR + (size_t)rowA * w2C, *const rB_ = pR + (size_t)rowB * w2C;
+			for (int s = threadIdx.x; s < nstrip; s += 256) {
+				const uint32_t yA = luma(doA ? ra : rb, s), yB = luma(doB ? rb : ra, s), kA = black(doA ? ra : rb, s), kB = black(doB ? rb : ra, s);
+				if (KIND == RS_V2) {
+					const uint32_t ba = *reinterpret_cast<const uint32_t *>(bA_ + 4 * s), bb = *reinterpret_cast<const uint32_t *>(bB_ + 4 * s);
+					const uint32_t ra4 = *reinterpret_cast<const uint32_t *>(rA_ + 4 * s), rb4 = *reinterpret_cast<const uint32_t *>(rB_ + 4 * s);
+					if (doB)
+						finish(rb, s, yB, kB, rs_v2(bb, ba), rs_v2(rb4, ra4), none, none);
+					if (doA)
+						finish(ra, s, yA, kA, rs_v2(ba, bb), rs_v2(ra4, rb4), none, none);
+				} else {
+					const int i0 = 2 * s;
+					uint32_t bA = rs_window(bA_, i0, lastdw), bB = rs_window(bB_, i0, lastdw), rA = rs_window(rA_, i0, lastdw), rB = rs_window(rB_, i0, lastdw);
+					if (i0 == 0 || i0 + 2 > wc - 1) {
+						bool last;
+						const uint32_t sel = edge_sel(i0, &last);
+						bA = __builtin_amdgcn_perm(0, bA, sel);
+						bB = __builtin_amdgcn_perm(0, bB, sel);
+						rA = __builtin_amdgcn_perm(0, rA, sel);
+						rB = __builtin_amdgcn_perm(0, rB, sel);
+					}
+					const uint32_t vb0 = __builtin_amdgcn_perm(bA, bB, KC.v0), vb1 = __builtin_amdgcn_perm(bA, bB, KC.v1), vb2 = __builtin_amdgcn_perm(bA, bB, KC.v2);
+					const uint32_t vr0 = __builtin_amdgcn_perm(rA, rB, KC.v0), vr1 = __builtin_amdgcn_perm(rA, rB, KC.v1), vr2 = __builtin_amdgcn_perm(rA, rB, KC.v2);
+					if (doB) {
+						const uint32_t cbv[4] = {dot4(vb0, KC.wBk1, KC.w128), dot4(vb1, KC.wBk, KC.w128), dot4(vb1, KC.wBk1, KC.w128), dot4(vb2, KC.wBk, KC.w128)};
+						const uint32_t crv[4] = {dot4(vr0, KC.wBk1, KC.w128), dot4(vr1, KC.wBk, KC.w128), dot4(vr1, KC.wBk1, KC.w128), dot4(vr2, KC.wBk, KC.w128)};
+						finish(rb, s, yB, kB, 0, 0, cbv, crv);
+					}
+					if (doA) {
+						const uint32_t cbv[4] = {dot4(vb0, KC.wAk1, KC.w128), dot4(vb1, KC.wAk, KC.w128), dot4(vb1, KC.wAk1, KC.w128), dot4(vb2, KC.wAk, KC.w128)};
+						const uint32_t crv[4] = {dot4(vr0, KC.wAk1, KC.w128), dot4(vr1, KC.wAk, KC.w128), dot4(vr1, KC.wAk1, KC.w128), dot4(vr2, KC.wAk, KC.w128)};
+						finish(ra, s, yA, kA, 0, 0, cbv, crv);
+					}
+				}
+			}
+		}
+		return;
+	}
+
+	const int r0 = (int)wk.first, r1 = min(r0 + MIJ_RESAMPLE_ROWS, H);
+	for (int r = r0; r < r1; ++r) {
+		const RowSel rs = select_rows(r, vsC, yC);
+		const uint8_t *const bN = pB + (size_t)rs.near * w2C, *const rN = pR + (size_t)rs.near * w2C;
+		for (int s = threadIdx.x; s < nstrip; s += 256) {
+			const uint32_t yv = luma(r, s), kv = black(r, s);
+			if (KIND == RS_ROW1) {
+				finish(r, s, yv, kv, *reinterpret_cast<const uint32_t *>(bN + 4 * s), *reinterpret_cast<const uint32_t *>(rN + 4 * s), none, none);
+			} else if (KIND == RS_GEN2) {
+				finish(r, s, yv, kv, __builtin_amdgcn_perm(0, *reinterpret_cast<const uint16_t *>(bN + 2 * s), 0x01010000u),
+						 __builtin_amdgcn_perm(0, *reinterpret_cast<const uint16_t *>(rN + 2 * s), 0x01010000u), none, none);
+			} else if (KIND == RS_GEN4) {
+				finish(r, s, yv, kv, (uint32_t)bN[s] * 0x01010101u, (uint32_t)rN[s] * 0x01010101u, none, none);
+			} else { /* RS_H2 */
+				const int i0 = 2 * s;
+				uint32_t vb = rs_window(bN, i0, lastdw), vr = rs_window(rN, i0, lastdw);
+				uint32_t w2 = wE1;
+				if (i0 == 0 || i0 + 2 > wc - 1) {
+					bool last;
+					const uint32_t sel = edge_sel(i0, &last);
+					if (last)
+						w2 = wO0;
+					vb = __builtin_amdgcn_perm(0, vb, sel);
+					vr = __builtin_amdgcn_perm(0, vr, sel);
+				}
+				const uint32_t cbv[4] = {dot4(vb, wE0, KC.w128), dot4(vb, wO0, KC.w128), dot4(vb, w2, KC.w128), dot4(vb, wO1, KC.w128)};
+				const uint32_t crv[4] = {dot4(vr, wE0, KC.w128), dot4(vr, wO0, KC.w128), dot4(vr, w2, KC.w128), dot4(vr, wO1, KC.w128)};
+				finish(r, s, yv, kv, 0, 0, cbv, crv);
+			}
 		}
 	}
 }

@@ -135,7 +135,8 @@ struct Slot {
 };
 
 /* kernel families of a launch plan, in launch order */
-enum { MK_PLANES = 0, MK_RESAMPLE, MK_420, MK_422, MK_444, MK_GREY, MK_KINDS };
+/* MK_RS_FAST + RS_*: pass 2 compiled per resampler (k_resample_fast); list index [n_out == 4][YCbCr colour][0] */
+enum { MK_PLANES = 0, MK_RESAMPLE, MK_RS_FAST, MK_420 = MK_RS_FAST + RS_KINDS, MK_422, MK_444, MK_GREY, MK_KINDS };
 struct Work4 { /* WorkBand and WorkIdct are both four u32 */
 	uint32_t a, b, c, d;
 };
@@ -166,7 +167,8 @@ struct mij_batch {
 		size_t first, count, lds;
 	};
 	std::vector<Launch> launches;
-	bool uploaded, launched, force_generic;
+	bool uploaded, launched;
+	int force_generic; /* 0: fused kernels where they apply; 1: two-pass path for every image; 2: and its run-time-general pass 2 */
 	int coef_fmt;  /* format new coefficient planes get in HBM: 1 compact (default), 0 int16 (MIJ_COEF_FORMAT=int16, mij_batch_set_coef_format) */
 	int band_rows; /* MCU rows per fused workgroup; 0 = automatic */
 	struct EsArena *es; /* GPU entropy stage, allocated by mij_batch_entropy_reserve */
@@ -212,7 +214,8 @@ extern "C" int mij_batch_create(mij_ctx *ctx, int max_images, size_t stage_bytes
 	b->stage_used = b->coef_used = b->out_used = 0;
 	b->planes_cap = 0;
 	b->work_cap = 0;
-	b->uploaded = b->launched = b->force_generic = false;
+	b->uploaded = b->launched = false;
+	b->force_generic = 0;
 	b->band_rows = 0;
 	{
 		const char *fmt = getenv("MIJ_COEF_FORMAT");
@@ -526,7 +529,7 @@ extern "C" int mij_batch_force_generic(mij_batch *b, int on)
 {
 	if (!b)
 		return set_err(MIJ_E_ARG, "batch is NULL");
-	b->force_generic = on != 0;
+	b->force_generic = on < 0 ? 0 : (on > 2 ? 2 : on);
 	b->uploaded = b->launched = false;
 	return MIJ_OK;
 }
@@ -575,6 +578,31 @@ static bool fused422_ok(const mij_batch *b, const mij_image_desc &d)
 }
 
 /* can the register-resident 4:4:4 kernel take this image? */
+/* Which specialised pass 2 (RS_*, mij_kernels.h) serves an image of the two-pass path, or -1 for the run-time-general
+ * k_resample_color: component 0 (and 3) at full resolution, components 1 and 2 sharing factors that divide, W % 4 == 0,
+ * three or four output channels.  *ycc: YCbCr colour (stbi__YCbCr_to_RGB_row) as opposed to RGB-tagged / CMYK / YCCK. */
+static int resample_fast_kind(const mij_batch *b, const mij_image_desc &d, int *ycc)
+{
+	if (b->force_generic >= 2 || (d.n_out != 3 && d.n_out != 4) || (d.width & 3) || d.ncomp < 3)
+		return -1;
+	const bool four = d.color == MIJ_COLOR_CMYK || d.color == MIJ_COLOR_YCCK;
+	if (d.color != MIJ_COLOR_YCBCR && d.color != MIJ_COLOR_YCBCRA && d.color != MIJ_COLOR_RGB && !four)
+		return -1;
+	if ((four && d.ncomp != 4) || d.comp[0].h != d.h_max || d.comp[0].v != d.v_max)
+		return -1;
+	if (four && (d.comp[3].h != d.h_max || d.comp[3].v != d.v_max))
+		return -1;
+	if (d.comp[1].h != d.comp[2].h || d.comp[1].v != d.comp[2].v || d.h_max % d.comp[1].h || d.v_max % d.comp[1].v)
+		return -1;
+	const int hs = d.h_max / d.comp[1].h, vs = d.v_max / d.comp[1].v;
+	*ycc = (d.color == MIJ_COLOR_YCBCR || d.color == MIJ_COLOR_YCBCRA) ? 1 : 0;
+	if (hs == 1)
+		return vs == 2 ? RS_V2 : RS_ROW1;
+	if (hs == 2)
+		return vs == 1 ? RS_H2 : (vs == 2 ? RS_HV2 : RS_GEN2);
+	return hs == 4 ? RS_GEN4 : -1;
+}
+
 static bool fused444_ok(const mij_batch *b, const mij_image_desc &d)
 {
 	if (b->force_generic || (d.flags & MIJ_FLAG_SKIP))
@@ -713,8 +741,10 @@ extern "C" int mij_batch_upload(mij_batch *b)
 		}
 	int auto_nb = 1;
 	if (n_fused) {
-		const size_t per_cu = lds_max ? (size_t)b->ctx->max_dyn_lds / lds_max : 1;
-		const size_t slots = (size_t)cu * (per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu));
+		size_t per_cu = lds_max ? (size_t)b->ctx->max_dyn_lds / lds_max : 1;
+		const size_t by_waves = 16 / (MIJ_F420_NT / 64); /* four waves per SIMD by registers */
+		per_cu = per_cu < 1 ? 1 : (per_cu > by_waves ? by_waves : per_cu);
+		const size_t slots = (size_t)cu * per_cu;
 		const double avg_rows = (double)mcu_rows_sum / (double)n_fused;
 		double best = 1e30;
 		for (int nb = 1; nb <= 16 && nb <= (int)avg_rows; ++nb) {
@@ -774,8 +804,13 @@ extern "C" int mij_batch_upload(mij_batch *b)
 			per_blocks(lists[MK_444][o4][wide][b8], 0);
 		} else {
 			s.path = 2;
-			for (uint32_t r = 0; r < (uint32_t)d.height; r += MIJ_RESAMPLE_ROWS)
-				lists[MK_RESAMPLE][0][0][0].push_back(Work4{(uint32_t)i, 0u, r, 0u});
+			int ycc = 0;
+			const int rk = resample_fast_kind(b, d, &ycc);
+			std::vector<Work4> &R = rk < 0 ? lists[MK_RESAMPLE][0][0][0] : lists[MK_RS_FAST + rk][o4][ycc][0];
+			/* the vs == 2 forms of k_resample_fast take item r as output rows r-1 .. r+2 (row pairs around a chroma row) */
+			const uint32_t r_end = (uint32_t)d.height + ((rk == RS_V2 || rk == RS_HV2) ? 2u : 0u);
+			for (uint32_t r = 0; r < r_end; r += MIJ_RESAMPLE_ROWS)
+				R.push_back(Work4{(uint32_t)i, 0u, r, 0u});
 			for (int c = 0; c < d.ncomp; ++c)
 				per_blocks(lists[MK_PLANES][0][wide][b8], c);
 			/* rebase this image's sample planes into the scratch arena */
@@ -918,7 +953,7 @@ extern "C" int mij_batch_launch(mij_batch *b)
 		return set_err(MIJ_E_STATE, "mij_batch_launch before mij_batch_upload");
 	HIP_TRY(hipSetDevice(b->ctx->device));
 	for (const auto &L : b->launches) { /* in family order: pass 2 of the two-pass family runs behind every pass-1 launch */
-		const dim3 grid((unsigned)L.count), block(256);
+		const dim3 grid((unsigned)L.count), block(L.kind == MK_420 ? MIJ_F420_NT : 256);
 		const Work4 *wk = b->d_work + L.first;
 		switch (L.kind) {
 		case MK_420:
@@ -936,9 +971,33 @@ extern "C" int mij_batch_launch(mij_batch *b)
 		case MK_PLANES:
 			MIJ_LAUNCH_WB(k_idct_planes, MIJ_COEF_OUT_PLANES);
 			break;
-		default:
+		case MK_RESAMPLE:
 			hipLaunchKernelGGL(k_resample_color, grid, block, 0, b->stream, b->d_imgs, reinterpret_cast<const WorkIdct *>(wk), b->d_planes, b->d_out);
 			break;
+		default: { /* MK_RS_FAST + RS_*: L.nout, L.wide = YCbCr colour */
+#define MIJ_RS(KIND)                                                                                                                             \
+	case KIND:                                                                                                                                    \
+		if (L.wide) {                                                                                                                              \
+			if (L.nout == 4) hipLaunchKernelGGL((k_resample_fast<KIND, true, 4>), grid, block, 0, b->stream, b->d_imgs, reinterpret_cast<const WorkIdct *>(wk), b->d_planes, b->d_out); \
+			else hipLaunchKernelGGL((k_resample_fast<KIND, true, 3>), grid, block, 0, b->stream, b->d_imgs, reinterpret_cast<const WorkIdct *>(wk), b->d_planes, b->d_out);            \
+		} else {                                                                                                                                   \
+			if (L.nout == 4) hipLaunchKernelGGL((k_resample_fast<KIND, false, 4>), grid, block, 0, b->stream, b->d_imgs, reinterpret_cast<const WorkIdct *>(wk), b->d_planes, b->d_out); \
+			else hipLaunchKernelGGL((k_resample_fast<KIND, false, 3>), grid, block, 0, b->stream, b->d_imgs, reinterpret_cast<const WorkIdct *>(wk), b->d_planes, b->d_out);            \
+		}                                                                                                                                          \
+		break
+			switch (L.kind - MK_RS_FAST) {
+				MIJ_RS(RS_ROW1);
+				MIJ_RS(RS_V2);
+				MIJ_RS(RS_H2);
+				MIJ_RS(RS_HV2);
+				MIJ_RS(RS_GEN2);
+				MIJ_RS(RS_GEN4);
+			default:
+				return set_err(MIJ_E_STATE, "unknown launch kind %d", L.kind);
+			}
+#undef MIJ_RS
+			break;
+		}
 		}
 		HIP_TRY(hipGetLastError());
 	}

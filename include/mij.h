@@ -216,7 +216,9 @@ int mij_batch_diff_slots(mij_batch *b, const int *sa, const int *sb, int n, uint
 /* which kernel family the last upload chose for a slot: 0 none (skipped), 1 fused 4:2:0, 2 generic two-pass,
  * 3 fused 4:4:4, 4 fused 4:2:2, 5 fused grey */
 int mij_batch_slot_path(const mij_batch *b, int slot);
-/* force the generic (unfused) path for every image of a batch: parity tests compare both */
+/* parity tests compare the kernel families: on = 1 sends every image of the batch down the two-pass path (IDCT to sample
+ * planes, then resampling + colour; its pass 2 compiled per resampler where the layout allows), on = 2 also insists on
+ * the run-time-general pass 2 (k_resample_color), on = 0 is the default choice */
 int mij_batch_force_generic(mij_batch *b, int on);
 
 /* ---- GPU entropy stage (experimental): the baseline Huffman walk itself on the GPU, for single-scan interleaved

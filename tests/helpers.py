@@ -345,6 +345,38 @@ def baseline_from_du(plan, du, restart_mcus=0, layout="native"):
     return out[:n].tobytes()
 
 
+def baseline_layout_from_444(plan, du, hv, app14=-1, restart_mcus=0):
+    """A baseline stream with arbitrary sampling factors (and optionally an Adobe APP14 segment / a fourth component)
+    from the 4:4:4 data units of a picture of the same size: component c with factors hv[c] = (h, v) gets every
+    (hmax/h)-th block column and (vmax/v)-th block row of the 4:4:4 plane (component 3: the luma plane again).  The
+    content is not a faithful down-sampling -- only a valid stream of that layout is needed; parity is always against
+    the oracle's decode of the same bytes."""
+    assert plan.du_per_mcu == 3
+    L = C.CDLL(build_prog_writer())
+    L.pw_write_baseline_ex.restype = C.c_long
+    L.pw_write_baseline_ex.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, P_INT, P_INT, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_long]
+    planes444, _ = du_to_planes(plan, du)
+    n_c = len(hv)
+    hmax, vmax = max(h for h, _ in hv), max(v for _, v in hv)
+    mcu_x, mcu_y = (plan.width + 8 * hmax - 1) // (8 * hmax), (plan.height + 8 * vmax - 1) // (8 * vmax)
+    planes = []
+    for c, (h, v) in enumerate(hv):
+        src = planes444[c if c < 3 else 0]
+        sub = src[0::max(1, vmax // v), 0::max(1, hmax // h)]
+        p = np.zeros((mcu_y * v, mcu_x * h, 64), np.int16)
+        hh, ww = min(sub.shape[0], p.shape[0]), min(sub.shape[1], p.shape[1])
+        p[:hh, :ww] = sub[:hh, :ww]
+        planes.append(p)
+    ptrs = (C.c_void_p * n_c)(*[p.ctypes.data for p in planes])
+    qt = np.concatenate([np.frombuffer(bytes(plan.ytab), np.uint8), np.frombuffer(bytes(plan.ctab), np.uint8)])
+    cap = 4096 + sum(p.size for p in planes) * 3
+    out = np.empty(cap, np.uint8)
+    n = L.pw_write_baseline_ex(ptrs, n_c, plan.width, plan.height, (C.c_int * n_c)(*[h for h, _ in hv]), (C.c_int * n_c)(*[v for _, v in hv]),
+                               qt.ctypes.data_as(C.c_void_p), int(restart_mcus), int(app14), out.ctypes.data_as(C.c_void_p), cap)
+    assert 0 < n <= cap, n
+    return out[:n].tobytes()
+
+
 # ---------------------------------------------------------------- round-2 golden additions
 
 GOLDEN_R2 = os.path.join(ROOT, "tests", "golden", "jpeg_golden_r2.npz")

@@ -562,15 +562,28 @@ static void bl_scan(pw_state *s, bl_tabs *t, pw_frame *f, int restart_mcus)
 		}
 }
 
+/* app14_transform >= 0: an Adobe APP14 segment with that colour-transform byte in front of the tables (3 components,
+ * transform 0: RGB-tagged; 4 components: 0 CMYK, 2 YCCK -- codec/jpeg.c:1528-1549, :2234-2244); -1: none */
+long pw_write_baseline_ex(const int16_t *const *planes, int ncomp, int width, int height, const int *hs, const int *vs, const uint8_t *qtab /* [2][64] */,
+								  int restart_mcus, int app14_transform, uint8_t *out, long cap);
+
 long pw_write_baseline(const int16_t *const *planes, int ncomp, int width, int height, const int *hs, const int *vs, const uint8_t *qtab /* [2][64] */,
 							  int restart_mcus, uint8_t *out, long cap)
+{
+	if (ncomp != 1 && ncomp != 3)
+		return -1;
+	return pw_write_baseline_ex(planes, ncomp, width, height, hs, vs, qtab, restart_mcus, -1, out, cap);
+}
+
+long pw_write_baseline_ex(const int16_t *const *planes, int ncomp, int width, int height, const int *hs, const int *vs, const uint8_t *qtab /* [2][64] */,
+								  int restart_mcus, int app14_transform, uint8_t *out, long cap)
 {
 	pw_state *s;
 	bl_tabs *t;
 	pw_frame f;
 	int c, i, k;
 	long len;
-	if ((ncomp != 1 && ncomp != 3) || width < 1 || height < 1 || width > 65535 || height > 65535 || restart_mcus < 0 || restart_mcus > 65535)
+	if ((ncomp != 1 && ncomp != 3 && ncomp != 4) || width < 1 || height < 1 || width > 65535 || height > 65535 || restart_mcus < 0 || restart_mcus > 65535)
 		return -1;
 	memset(&f, 0, sizeof f);
 	f.ncomp = ncomp;
@@ -606,6 +619,17 @@ long pw_write_baseline(const int16_t *const *planes, int ncomp, int width, int h
 	bl_scan(s, t, &f, restart_mcus);
 	s->gather = 0;
 	put_u16(s, 0xffd8);
+	if (app14_transform >= 0) {
+		static const char tag[5] = {'A', 'd', 'o', 'b', 'e'};
+		put_u16(s, 0xffee);
+		put_u16(s, 14);
+		for (k = 0; k < 5; ++k)
+			put_byte(s, (unsigned char)tag[k]);
+		put_u16(s, 100); /* version */
+		put_u16(s, 0);   /* flags0 */
+		put_u16(s, 0);   /* flags1 */
+		put_byte(s, (unsigned)app14_transform);
+	}
 	for (i = 0; i < (ncomp == 1 ? 1 : 2); ++i) {
 		put_u16(s, 0xffdb);
 		put_u16(s, 67);

@@ -98,7 +98,7 @@ def test_seeded_images_vs_oracle_fused_and_generic(ica, oracle, gpu_ctx):
         datas.append(ica.stbi_write_jpg_to_memory(img, q))
     for req in (3, 4):
         wants = [oracle.load(d, req)[1] for d in datas]
-        for generic in (False, True):
+        for generic in (0, 1, 2):
             b, slots = _batch_for(ica, gpu_ctx, datas, req)
             b.force_generic(generic)
             b.submit()
@@ -226,7 +226,7 @@ def test_progressive_and_444(ica, oracle, gpu_ctx, golden):
     datas.append(ica.synth_jpeg(1024, 768, 3, quality=95))
     for req in (3, 4):
         wants = [oracle.load(d, req)[1] for d in datas]
-        for generic in (False, True):
+        for generic in (0, 1, 2):
             b, slots = _batch_for(ica, gpu_ctx, datas, req)
             b.force_generic(generic)
             b.submit()
@@ -358,7 +358,7 @@ def test_fused_422_kernel_vs_oracle_and_two_pass(ica, oracle, gpu_ctx, golden):
         datas.append(helpers.progressive_422_from_444(plan, du, i & 1))
     for req in (3, 4):
         wants = [oracle.load(d, req)[1] for d in datas]
-        for generic in (False, True):
+        for generic in (0, 1, 2):
             b, slots = _batch_for(ica, gpu_ctx, datas, req)
             b.force_generic(generic)
             b.submit()
@@ -378,7 +378,7 @@ def test_fused_grey_kernel_vs_oracle_and_two_pass(ica, oracle, gpu_ctx, golden):
         datas.append(helpers.progressive_grey_from_444(plan, du, i & 1))
     for req in (0, 1, 2, 3, 4):
         wants = [oracle.load(d, req)[1] for d in datas]
-        for generic in (False, True):
+        for generic in (0, 1, 2):
             b, slots = _batch_for(ica, gpu_ctx, datas, req)
             b.force_generic(generic)
             b.submit()
@@ -387,3 +387,55 @@ def test_fused_grey_kernel_vs_oracle_and_two_pass(ica, oracle, gpu_ctx, golden):
                 got = b.fetch(s)
                 assert np.array_equal(got.reshape(-1), want.reshape(-1)), (s, req, generic, want.shape)
             b.close()
+
+
+def test_two_pass_layouts_specialised_and_general_pass2(ica, oracle, gpu_ctx):
+    """Every layout the fused kernels do not take -- 4:4:0, 4:1:1, 4:1:0, h2v4, h1v4, RGB-tagged, CMYK, YCCK, four-component
+    YCbCr with sub-sampled chroma -- through the two-pass family with the pass 2 compiled per resampler (k_resample_fast:
+    row_1 / v_2 / h_2 / hv_2 / generic x2 / generic x4, codec/jpeg.c:1765-1840, :1962-1971) and with the run-time-general
+    pass 2 (k_resample_color), both equal to the oracle; widths that are not a multiple of four stay on the general one."""
+    layouts = [  # (factors per component, Adobe transform or -1)
+        ([(1, 2), (1, 1), (1, 1)], -1),          # 4:4:0  v_2
+        ([(4, 1), (1, 1), (1, 1)], -1),          # 4:1:1  generic x4
+        ([(4, 2), (1, 1), (1, 1)], -1),          # 4:1:0  generic x4, two rows
+        ([(2, 4), (1, 1), (1, 1)], -1),          # h2v4   generic x2
+        ([(1, 4), (1, 1), (1, 1)], -1),          # h1v4   generic x1 = the near row
+        ([(2, 2), (1, 1), (1, 1)], -1),          # 4:2:0 (forced off the fused kernel below)
+        ([(2, 1), (1, 1), (1, 1)], -1),          # 4:2:2
+        ([(1, 1), (1, 1), (1, 1)], 0),           # RGB-tagged
+        ([(2, 2), (1, 1), (1, 1)], 0),           # RGB-tagged with sub-sampled G / B planes
+        ([(1, 1), (1, 1), (1, 1), (1, 1)], 0),   # CMYK
+        ([(1, 1), (1, 1), (1, 1), (1, 1)], 2),   # YCCK
+        ([(2, 2), (1, 1), (1, 1), (2, 2)], 2),   # YCCK, chroma sub-sampled
+        ([(2, 1), (1, 1), (1, 1), (2, 1)], 0),   # CMYK, h2v1 on the middle planes
+        ([(1, 1), (1, 1), (1, 1), (1, 1)], 1),   # four components, other transform: YCbCr, fourth ignored
+        ([(2, 2), (1, 1), (1, 1), (1, 1)], 2),   # fourth component not at full resolution: general pass 2 only
+        ([(1, 1), (2, 2), (2, 2)], -1),          # luma below the chroma resolution: general pass 2 only
+    ]
+    sizes = ((64, 48), (36, 20), (128, 72), (4, 4), (30, 17), (200, 97))
+    datas, fast = [], []
+    for li, (hv, app14) in enumerate(layouts):
+        for si, (w, h) in enumerate(sizes):
+            plan, du = ica.host_transform(ica.synth_rgb(w, h, 300 + 7 * li + si), 92)
+            datas.append(helpers.baseline_layout_from_444(plan, du, hv, app14, restart_mcus=(3 if si == 2 else 0)))
+            fast.append(w % 4 == 0 and li < 14)
+    for req in (3, 4):
+        wants = [oracle.load(d, req) for d in datas]
+        assert all(k == "ok" for k, _, _ in wants)
+        for generic in (1, 2):
+            b, slots = _batch_for(ica, gpu_ctx, datas, req)
+            b.force_generic(generic)
+            b.submit()
+            b.wait()
+            for i, (s, (_, want, _)) in enumerate(zip(slots, wants)):
+                assert b.slot_path(s) == 2
+                got = b.fetch(s)
+                assert np.array_equal(got, want), (i, layouts[i // len(sizes)], sizes[i % len(sizes)], req, generic, int((got != want).sum()))
+            b.close()
+    # default choice: the same pixels again (fused kernels where they apply, two-pass elsewhere)
+    b, slots = _batch_for(ica, gpu_ctx, datas, 3)
+    b.submit()
+    b.wait()
+    for i, s in enumerate(slots):
+        assert np.array_equal(b.fetch(s), oracle.load(datas[i], 3)[1]), i
+    b.close()

@@ -123,3 +123,32 @@ def test_oracle_vs_live_reference_fuzz(golden, oracle):
                 assert np.array_equal(a[1], b[1]), (name, seed)
             agree += 1
     assert agree == 420
+
+
+LAYOUTS_R2 = [  # (factors per component, Adobe transform or -1): the layouts of tests/test_gpu_parity.py::test_two_pass_layouts_*
+    ([(1, 2), (1, 1), (1, 1)], -1), ([(4, 1), (1, 1), (1, 1)], -1), ([(4, 2), (1, 1), (1, 1)], -1), ([(2, 4), (1, 1), (1, 1)], -1),
+    ([(1, 4), (1, 1), (1, 1)], -1), ([(2, 2), (1, 1), (1, 1)], -1), ([(2, 1), (1, 1), (1, 1)], -1), ([(1, 1), (1, 1), (1, 1)], 0),
+    ([(2, 2), (1, 1), (1, 1)], 0), ([(1, 1), (1, 1), (1, 1), (1, 1)], 0), ([(1, 1), (1, 1), (1, 1), (1, 1)], 2),
+    ([(2, 2), (1, 1), (1, 1), (2, 2)], 2), ([(2, 1), (1, 1), (1, 1), (2, 1)], 0), ([(1, 1), (1, 1), (1, 1), (1, 1)], 1),
+    ([(2, 2), (1, 1), (1, 1), (1, 1)], 2), ([(1, 1), (2, 2), (2, 2)], -1),
+]
+
+
+@pytest.mark.skipif(not helpers.Reference.available(), reason="oracle/_ref not built (reference absent on this box)")
+def test_oracle_vs_live_reference_sampling_layouts(oracle):
+    """Streams of the test-side writer with unusual sampling factors, Adobe-tagged RGB / CMYK / YCCK and a fourth
+    component: the oracle decodes them exactly as the reference does (resample_row_v_2 / _generic, codec/jpeg.c:1774-1782,
+    :1962-1971; colour branches :2320-2431), for every req_comp.  These are the inputs of the GPU layout tests."""
+    import image_codecs_amd as ica
+    ref = helpers.Reference()
+    n = 0
+    for li, (hv, app14) in enumerate(LAYOUTS_R2):
+        for si, (w, h) in enumerate(((64, 48), (36, 20), (4, 4), (30, 17), (200, 97))):
+            plan, du = ica.host_transform(ica.synth_rgb(w, h, 300 + 7 * li + si), 92)
+            data = helpers.baseline_layout_from_444(plan, du, hv, app14, restart_mcus=(3 if si == 1 else 0))
+            for req in (0, 1, 2, 3, 4):
+                a, b = ref.load(data, req), oracle.load(data, req)
+                assert a[0] == b[0] == "ok", (hv, app14, w, h, req)
+                assert np.array_equal(a[1], b[1]), (hv, app14, w, h, req)
+                n += 1
+    assert n == len(LAYOUTS_R2) * 5 * 5

@@ -42,3 +42,38 @@ def test_host_stage_colour_mode_after_late_markers(ica, g2):
         assert kind == "ok"
         desc, _ = ica.HostDecoder.decode(data, 3)
         assert desc.color == color[name], (name, desc.color)
+
+
+def _layout_cases():
+    import os
+    z = np.load(os.path.join(helpers.ROOT, "tests", "golden", "jpeg_golden_r2b.npz"))
+    return z, int(z["lay/count"][0])
+
+
+def test_oracle_sampling_layout_vectors(oracle):
+    """4:4:0, 4:1:1, 4:1:0, h2v4, h1v4, RGB-tagged, CMYK, YCCK, four-component YCbCr, sub-sampled luma: the reference's own
+    outputs (tests/golden/make_golden_r2b.py), every req_comp."""
+    z, n = _layout_cases()
+    assert n == 48
+    for k in range(n):
+        data = bytes(z["lay/%d/jpg" % k])
+        for req in range(5):
+            kind, px, _ = oracle.load(data, req)
+            assert kind == "ok", (k, req)
+            assert helpers.fnv1a64(px) == int(z["lay/%d/fnv" % k][req]), (k, req, z["lay/%d/hv" % k].tolist())
+            if req == 3:
+                assert np.array_equal(px, z["lay/%d/out3" % k]), k
+
+
+@pytest.mark.gpu
+def test_gpu_sampling_layout_vectors(ica, gpu_ctx):
+    """The same vectors through stbi_load_from_memory on the GPU (default kernel choice per layout)."""
+    z, n = _layout_cases()
+    for k in range(n):
+        data = bytes(z["lay/%d/jpg" % k])
+        for req in range(5):
+            got = ica.stbi_load_from_memory(data, req)
+            assert got is not None, (k, req, ica.stbi_failure_reason())
+            assert helpers.fnv1a64(got[0]) == int(z["lay/%d/fnv" % k][req]), (k, req, z["lay/%d/hv" % k].tolist())
+            if req == 3:
+                assert np.array_equal(got[0], z["lay/%d/out3" % k]), k
