@@ -32,6 +32,7 @@ The one JSON line (rank 0) also carries, all OUTSIDE the timed region and only a
   legs.config4          BASELINE configs[3]: 32 x 4096x4096 progressive 4:4:4 (k_fused444), 9 B/px
   legs.config5          BASELINE configs[4]: 1024 x 1080p RGB -> data units (k_encode420), bytes == reference
   legs.h2v1             512 x 1080p 4:2:2 (k_fused422), 7 B/px
+  legs.config1          BASELINE configs[0]: one 512x512 4:2:0 JPEG per stbi_load_from_memory call (latency of the drop-in call)
   legs.two_pass         256 x 1080p through the two-pass family (sample planes in HBM, pass 2 compiled per resampler):
                         the headline images forced off the fused kernel, 4:4:0 and Adobe CMYK
   end_to_end            bitstream in host RAM -> pixels in HBM (host walk; GPU walk), never `value`
@@ -375,6 +376,46 @@ def leg_h2v1(ica, ctx, args, checker):
     return res
 
 
+def leg_config1(ica, checker):
+    """BASELINE configs[0]: ONE 512x512 baseline 4:2:0 q=90 JPEG through stbi_load_from_memory, the call a user of the reference
+    makes -- bitstream in host memory -> malloc'ed pixels in host memory, per call: header parse, Huffman walk (on the GPU from
+    this size up), kernels, D2H.  Median wall time of 200 calls from one host thread, next to the CPU checker on the same thread."""
+    L = ica.lib()
+    data = ica.stbi_write_jpg_to_memory(ica.synth_rgb(512, 512, 1), 90)
+    x, y, c = C.c_int(), C.c_int(), C.c_int()
+    L.stbi_image_free.argtypes = [C.c_void_p]
+
+    def call():
+        t0 = time.perf_counter()
+        p = L.stbi_load_from_memory(data, len(data), C.byref(x), C.byref(y), C.byref(c), 3)
+        dt = time.perf_counter() - t0
+        assert p, "stbi_load_from_memory failed: %s" % ica.stbi_failure_reason()
+        return p, dt
+
+    p, _ = call()
+    got = np.ctypeslib.as_array(p, shape=(512 * 512 * 3,)).copy()
+    L.stbi_image_free(p)
+    Lc, kind = checker
+    want = cpu_decode(Lc, kind, data)
+    assert np.array_equal(got, want), "config 1: pixels differ from the CPU checker's"
+    for _ in range(20):
+        L.stbi_image_free(call()[0])
+    ts = []
+    for _ in range(200):
+        p, dt = call()
+        ts.append(dt)
+        L.stbi_image_free(p)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        cpu_decode(Lc, kind, data)
+    cpu_ms = (time.perf_counter() - t0) / 20 * 1e3
+    ms = float(np.median(ts)) * 1e3
+    return {"workload": "one 512x512 baseline 4:2:0 q=90 JPEG (%d bytes) per stbi_load_from_memory call, host memory in, host memory out" % len(data),
+            "ms_per_call_median": round(ms, 4), "ms_per_call_p90": round(float(np.percentile(ts, 90)) * 1e3, 4), "mpix_s": round(512 * 512 / ms / 1e3, 1),
+            "cpu_checker_ms_per_call": round(cpu_ms, 4), "cpu_checker": kind, "parity": True,
+            "note": "latency of the drop-in call, not a throughput figure: one image per call leaves the GPU idle (batch front ends: end_to_end)"}
+
+
 def leg_two_pass(ica, ctx, datas, args, checker):
     """The two-pass family (k_idct_planes, then k_resample_fast compiled per resampler) on 256 x 1080p: the headline 4:2:0
     images forced off the fused kernel, and two layouts that only have this path (4:4:0, Adobe CMYK).  ms = both passes of
@@ -668,6 +709,7 @@ def main():
         run_leg("config5", lambda: leg_config5(ica, ctx, args, checker))
         run_leg("h2v1", lambda: leg_h2v1(ica, ctx, args, checker))
         run_leg("two_pass", lambda: leg_two_pass(ica, ctx, datas, args, checker))
+        run_leg("config1", lambda: leg_config1(ica, checker))
     if solo and not args.no_e2e:
         try:
             e2e = end_to_end(ica, ctx, datas, distinct, n_img, src_hash, cbytes, obytes, args)

@@ -89,16 +89,27 @@ __device__ __forceinline__ constexpr uint32_t pk16(int lo, int hi) { return (uin
 /* a.lo*b.lo + a.hi*b.hi + acc in wrapping 32-bit: the three-address VOP3P form of v_dot2_i32_i16
  * (the compiler only picks the tied v_dot2c form, which costs a v_mov per accumulator seed).
  * The constant operand lives in a VGPR (see vreg). */
+/* MIJ_KSGPR: the constant operand (matrix entries, weights, selectors) is a scalar register the compiler materialises where
+ * it needs it (s_mov is not a VALU instruction) instead of one of ~30 vector registers pinned for the whole kernel; one
+ * scalar source per VOP3 instruction, so accumulator constants stay in vector registers.  A/B knob, see DESIGN.md 3.1. */
+#ifndef MIJ_KSGPR
+#define MIJ_KSGPR 0
+#endif
+#if MIJ_KSGPR
+#define MIJ_KC "s"
+#else
+#define MIJ_KC "v"
+#endif
 __device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int acc)
 {
 	int d;
-	asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(acc));
+	asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), MIJ_KC(b), "v"(acc));
 	return d;
 }
 __device__ __forceinline__ int dot2z(uint32_t a, uint32_t b)
 {
 	int d;
-	asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
+	asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(d) : "v"(a), MIJ_KC(b));
 	return d;
 }
 /* a loop-invariant constant pinned in a vector register */
@@ -106,6 +117,15 @@ __device__ __forceinline__ uint32_t vreg(uint32_t c)
 {
 	asm("" : "+v"(c));
 	return c;
+}
+/* the constant operand of a v_dot2 / v_dot4 / v_perm / v_and_or (not an accumulator) */
+__device__ __forceinline__ uint32_t kconst(uint32_t c)
+{
+#if MIJ_KSGPR
+	return c;
+#else
+	return vreg(c);
+#endif
 }
 /* sum of four u8*u8 products + acc (v_dot4_u32_u8) */
 __device__ __forceinline__ uint32_t dot4(uint32_t a, uint32_t b, uint32_t acc) { return __builtin_amdgcn_udot4(a, b, acc, false); }
@@ -118,7 +138,7 @@ __device__ __forceinline__ uint32_t pkmul(uint32_t a, uint32_t b)
 __device__ __forceinline__ uint32_t and_or(uint32_t x, uint32_t m, uint32_t o)
 {
 	uint32_t d;
-	asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(m), "v"(o));
+	asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(m), MIJ_KC(o));
 	return d;
 }
 
@@ -186,20 +206,20 @@ struct IdctK {
 	int bias1, bias2;
 	__device__ __forceinline__ void init()
 	{
-		e0 = vreg(pk16(4096, 4096));
-		e1 = vreg(pk16(4096, -4096));
-		x0 = vreg(pk16(5352, 2217));
-		x3 = vreg(pk16(-5352, -2217));
-		x1 = vreg(pk16(2217, -5350));
-		x2 = vreg(pk16(-2217, 5350));
-		t3a = vreg(pk16(5683, 4816));
-		t3b = vreg(pk16(3219, 1131));
-		t2a = vreg(pk16(4816, -1129));
-		t2b = vreg(pk16(-5681, -3218));
-		t1a = vreg(pk16(3219, -5681));
-		t1b = vreg(pk16(1132, 4816));
-		t0a = vreg(pk16(1131, -3218));
-		t0b = vreg(pk16(4816, -5680));
+		e0 = kconst(pk16(4096, 4096));
+		e1 = kconst(pk16(4096, -4096));
+		x0 = kconst(pk16(5352, 2217));
+		x3 = kconst(pk16(-5352, -2217));
+		x1 = kconst(pk16(2217, -5350));
+		x2 = kconst(pk16(-2217, 5350));
+		t3a = kconst(pk16(5683, 4816));
+		t3b = kconst(pk16(3219, 1131));
+		t2a = kconst(pk16(4816, -1129));
+		t2b = kconst(pk16(-5681, -3218));
+		t1a = kconst(pk16(3219, -5681));
+		t1b = kconst(pk16(1132, 4816));
+		t0a = kconst(pk16(1131, -3218));
+		t0b = kconst(pk16(4816, -5680));
 		bias1 = (int)vreg(512);                       /* codec/jpeg.c:639 */
 		bias2 = (int)vreg(65536 + (128 << 17));       /* codec/jpeg.c:664 */
 	}
@@ -885,29 +905,29 @@ struct ColorK {
 	uint32_t v0, v1, v2, p0, p1, p2, p3;
 	__device__ __forceinline__ void init()
 	{
-		r = vreg(pk16(5743, 4096));
-		b = vreg(pk16(7258, 4096));
-		t = vreg(pk16(-1410, 0));
-		g = vreg(pk16(-2925, 4096));
+		r = kconst(pk16(5743, 4096));
+		b = kconst(pk16(7258, 4096));
+		t = kconst(pk16(-1410, 0));
+		g = kconst(pk16(-2925, 4096));
 		mask = vreg(0xffffff00u);
-		o80 = vreg(0x80u);
+		o80 = kconst(0x80u);
 		w128 = vreg(128u);
 		kr = (int)vreg((uint32_t)(2048 - 128 * 5743));
 		kb = (int)vreg((uint32_t)(2048 - 128 * 7258));
 		kt = (int)vreg((uint32_t)(128 * 1410 + 0x5BE00));
 		/* h2v2 weights x16, byte order of the operand is (B_k, A_k, B_k+1, A_k+1) */
-		wBk = vreg(0x10303090u);  /* near = B, centre = k   : 9B_k + 3A_k + 3B_k1 +  A_k1 */
-		wBk1 = vreg(0x30901030u); /* near = B, centre = k+1 : 3B_k +  A_k + 9B_k1 + 3A_k1 */
-		wAk = vreg(0x30109030u);  /* near = A, centre = k   : 3B_k + 9A_k +  B_k1 + 3A_k1 */
-		wAk1 = vreg(0x90303010u); /* near = A, centre = k+1 :  B_k + 3A_k + 3B_k1 + 9A_k1 */
+		wBk = kconst(0x10303090u);  /* near = B, centre = k   : 9B_k + 3A_k + 3B_k1 +  A_k1 */
+		wBk1 = kconst(0x30901030u); /* near = B, centre = k+1 : 3B_k +  A_k + 9B_k1 + 3A_k1 */
+		wAk = kconst(0x30109030u);  /* near = A, centre = k   : 3B_k + 9A_k +  B_k1 + 3A_k1 */
+		wAk1 = kconst(0x90303010u); /* near = A, centre = k+1 :  B_k + 3A_k + 3B_k1 + 9A_k1 */
 		/* v_perm selectors: V_k = (B[k], A[k], B[k+1], A[k+1]); (chroma byte 1 | luma byte j << 16) */
-		v0 = vreg(0x05010400u);
-		v1 = vreg(0x06020501u);
-		v2 = vreg(0x07030602u);
-		p0 = vreg(0x0c000c05u);
-		p1 = vreg(0x0c010c05u);
-		p2 = vreg(0x0c020c05u);
-		p3 = vreg(0x0c030c05u);
+		v0 = kconst(0x05010400u);
+		v1 = kconst(0x06020501u);
+		v2 = kconst(0x07030602u);
+		p0 = kconst(0x0c000c05u);
+		p1 = kconst(0x0c010c05u);
+		p2 = kconst(0x0c020c05u);
+		p3 = kconst(0x0c030c05u);
 	}
 };
 
@@ -973,6 +993,9 @@ __device__ __forceinline__ void strip_row(const ColorK &K, uint32_t wk, uint32_t
 #endif
 #ifndef MIJ_F420_ATTR
 #define MIJ_F420_ATTR
+#endif
+#ifndef MIJ_F420_WAVES /* waves per SIMD the kernel's register count allows (the band planner counts co-resident workgroups with it) */
+#define MIJ_F420_WAVES 4
 #endif
 template <int NOUT, bool WIDE, bool B8 = false>
 __global__ __launch_bounds__(MIJ_F420_NT) MIJ_F420_ATTR void k_fused420(const DevImage *__restrict__ imgs, const WorkBand *__restrict__ work, const uint8_t *__restrict__ coef,

@@ -742,7 +742,7 @@ extern "C" int mij_batch_upload(mij_batch *b)
 	int auto_nb = 1;
 	if (n_fused) {
 		size_t per_cu = lds_max ? (size_t)b->ctx->max_dyn_lds / lds_max : 1;
-		const size_t by_waves = 16 / (MIJ_F420_NT / 64); /* four waves per SIMD by registers */
+		const size_t by_waves = 4 * MIJ_F420_WAVES / (MIJ_F420_NT / 64); /* waves per SIMD by registers x four SIMDs */
 		per_cu = per_cu < 1 ? 1 : (per_cu > by_waves ? by_waves : per_cu);
 		const size_t slots = (size_t)cu * per_cu;
 		const double avg_rows = (double)mcu_rows_sum / (double)n_fused;
