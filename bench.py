@@ -52,6 +52,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before torch / HIP initialise: one hardware queue per batch stream
 
 W, H = 1920, 1080
 ALGO_BYTES_PER_IMAGE = 2 * 64 * 48960 + 3 * W * H  # 6 266 880 + 6 220 800
@@ -581,6 +582,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the (untimed-region) end-to-end measurement")
     ap.add_argument("--no-legs", action="store_true", help="skip the secondary legs (int16 planes, harsh batch, configs 4 and 5, 4:2:2)")
+    ap.add_argument("--legs", default="", help="comma-separated subset of the secondary legs to run (default: all)")
     ap.add_argument("--e2e-images", type=int, default=512)
     ap.add_argument("--config4-images", type=int, default=32)
     ap.add_argument("--h2v1-images", type=int, default=512)
@@ -671,6 +673,8 @@ def main():
     legs, e2e = {}, None
 
     def run_leg(name, fn):
+        if args.legs and name not in args.legs.split(","):
+            return
         t0 = time.time()
         try:
             legs[name] = fn()

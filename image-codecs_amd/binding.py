@@ -11,6 +11,9 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+# eight hardware queues instead of HIP's default four, unless the user chose (see mij_hip_defaults in mij_runtime.hip): must be in
+# the environment before the HIP runtime initialises, i.e. before anything in this process touches the GPU
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 LIB_PATH = os.environ.get("MIJ_LIB") or os.path.join(_HERE, "lib", "libimagecodecs_mi355x.so")  # MIJ_LIB: A/B builds
 
 MIJ_FLAG_WIDE_IDCT = 1

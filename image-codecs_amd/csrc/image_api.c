@@ -142,7 +142,9 @@ static void vertical_flip(void *image, int w, int h, int bytes_per_pixel)
 static size_t gpu_walk_min_pixels(void)
 {
 	const char *e = getenv("MIJ_GPU_WALK_MIN_PIXELS");
-	return e ? (size_t)strtoull(e, NULL, 10) : (size_t)512 * 512;
+	/* measured per call on an MI355X box (tools/bench_single.py, profiles/r02v_single_call.json): the host walk costs 1.9 ms per
+	 * megapixel, the GPU walk of a one-picture batch 1.5-2.2 ms + 0.2 ms per megapixel: they cross between 1 and 1.3 megapixels */
+	return e ? (size_t)strtoull(e, NULL, 10) : (size_t)1280 * 1024;
 }
 
 /* One image through the GPU Huffman walk: NULL when the file is not a layout the walk takes, when the walk reports the
@@ -230,8 +232,8 @@ static unsigned char *load_main(mjh_reader *r, int *x, int *y, int *comp, int re
 	}
 	/* Large pictures from memory: the Huffman walk itself on the GPU (mij.h, "GPU entropy stage") when the file is a layout
 	 * it takes; whatever it does not take, or reports back, is walked below exactly as before, so failure reasons and
-	 * the treatment of damaged streams stay the reference's.  Small pictures are quicker on the host (the GPU walk is a
-	 * dozen launches); callback and FILE sources are walked as they arrive. */
+	 * the treatment of damaged streams stay the reference's.  Small pictures are quicker on the host (the GPU walk is some
+	 * thirty launches and two waits); callback and FILE sources are walked as they arrive. */
 	if (r->io.read == NULL && mjh_gpu_walk_default() && (size_t)desc.width * (size_t)desc.height >= gpu_walk_min_pixels()) {
 		unsigned char *px = load_gpu_walk(ctx, r->orig, (int)(r->orig_end - r->orig), req_comp, &desc);
 		if (px) {

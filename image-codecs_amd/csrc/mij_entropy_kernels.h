@@ -43,6 +43,12 @@ namespace mij {
 #ifndef MIJ_ES_BITS
 #define MIJ_ES_BITS 4096u
 #endif
+/* A batch of one picture (stbi_load_from_memory) is a latency problem, not a throughput problem: every pass lasts as long as ONE lane
+ * needs for its subsequence (0.4 ms for 4096 bits) and a 1080p stream is only 900 of them.  Such batches cut the stream into
+ * MIJ_ES_BITS_SINGLE bits per lane and pay with more (cheap) synchronisation rounds; the length is a field of DevScan. */
+#ifndef MIJ_ES_BITS_SINGLE
+#define MIJ_ES_BITS_SINGLE 1024u
+#endif
 #define MIJ_ES_DEAD 127u  /* z of a state whose decode hit an invalid code */
 
 struct DevHuff { /* stbi__huffman without the code[] array (codec/jpeg.c:21-32) */
@@ -67,6 +73,7 @@ struct DevScan {
 	uint8_t blk_comp[12], blk_dx[12], blk_dy[12]; /* block-in-MCU -> component and position inside the MCU */
 	uint8_t dc_tab[4], ac_tab[4];                 /* component -> table index (0..3 DC, 4..7 AC) of this scan's eight tables */
 	uint32_t tab_off;    /* first of the eight DevHuff of this scan */
+	uint32_t sub_bits;   /* bits per subsequence (MIJ_ES_BITS, or less for a batch that cannot fill the GPU otherwise) */
 	uint16_t qz[4][64];  /* quantisation tables, zigzag order, per component (L1 bound only) */
 };
 
@@ -425,11 +432,11 @@ __global__ __launch_bounds__(256) void k_es_cold(const DevScan *__restrict__ sca
 	if (i >= sc.nsub)
 		return;
 	EsState s;
-	s.p = i * MIJ_ES_BITS;
+	s.p = i * sc.sub_bits;
 	s.z = 0;
 	s.c = 0;
 	start[sc.sub_off + i] = es_pack(s);
-	const uint32_t pe = min((i + 1u) * MIJ_ES_BITS, sc.nbits);
+	const uint32_t pe = min((i + 1u) * sc.sub_bits, sc.nbits);
 	cnt[sc.sub_off + i] = es_decode<false>(sc, loc, tabs, streams + sc.stream_off, s, pe, nullptr, nullptr);
 	end[sc.sub_off + i] = es_pack(s);
 }
@@ -464,7 +471,7 @@ __global__ __launch_bounds__(256) void k_es_sync(const DevScan *__restrict__ sca
 		return;
 	start[slot] = want;
 	EsState s = es_unpack(want);
-	const uint32_t pe = min((i + 1u) * MIJ_ES_BITS, sc.nbits);
+	const uint32_t pe = min((i + 1u) * sc.sub_bits, sc.nbits);
 	cnt[slot] = es_decode<false>(sc, loc, tabs, streams + sc.stream_off, s, pe, nullptr, nullptr);
 	end_out[slot] = es_pack(s);
 	atomicAdd(&changed[wk.scan], 1u);
@@ -558,7 +565,7 @@ __global__ __launch_bounds__(256) void k_es_write(const DevScan *__restrict__ sc
 		wr.mx = m - wr.my * sc.mcu_x;
 		wr.locate(s.c);
 	}
-	const uint32_t pe = min((i + 1u) * MIJ_ES_BITS, sc.nbits);
+	const uint32_t pe = min((i + 1u) * sc.sub_bits, sc.nbits);
 	es_decode<true>(sc, loc, tabs, streams + sc.stream_off, s, pe, &wr, &anom[wk.scan]);
 }
 

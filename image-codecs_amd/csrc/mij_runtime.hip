@@ -101,6 +101,12 @@ extern "C" int mij_ctx_create(int device, mij_ctx **out)
 	return MIJ_OK;
 }
 
+/* HIP gives a process four hardware queues by default and maps every further stream onto one of them; two batches that share
+ * a queue run their kernels one after the other.  A ring of four batches plus one idle per-thread batch of stbi_load already loses
+ * 30 % of its throughput that way (profiles/r02v_hw_queues.txt).  Unless the user chose a value, ask for eight -- this has to
+ * happen before the HIP runtime initialises, hence a constructor of this library (a process that touched HIP earlier keeps its setting). */
+__attribute__((constructor)) static void mij_hip_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 extern "C" void mij_ctx_destroy(mij_ctx *ctx) { delete ctx; }
 extern "C" int mij_ctx_device(const mij_ctx *ctx) { return ctx ? ctx->device : -1; }
 
@@ -1201,6 +1207,8 @@ struct EsArena {
 	uint64_t *d_start, *d_end[2];
 	uint32_t *d_cnt, *d_base;
 	size_t sub_cap;
+	uint32_t sub_bits; /* bits per subsequence of this arena's scans */
+	int rounds0;       /* synchronisation rounds queued before the first look at the verdicts */
 	uint64_t *d_meta; /* per block: L1 of its AC coefficients | DC difference << 32 */
 	uint8_t *d_zz; /* compact planes: the write pass's intermediate image, 64 bytes per block in zigzag order */
 	size_t blk_cap;
@@ -1267,7 +1275,17 @@ extern "C" int mij_batch_entropy_reserve(mij_batch *b, size_t stream_bytes)
 	const size_t n = (size_t)b->max_images;
 	e->stream_cap = align_up(stream_bytes + 64 * n, 256);
 	e->scan_cap = 16 * n + 1024; /* restart intervals are walked one DevScan each */
-	e->sub_cap = e->stream_cap * 8 / MIJ_ES_BITS + 2 * e->scan_cap;
+	/* one picture per batch: short subsequences (latency), see MIJ_ES_BITS_SINGLE; MIJ_ES_BITS_OVERRIDE for experiments */
+	e->sub_bits = n == 1 ? MIJ_ES_BITS_SINGLE : MIJ_ES_BITS;
+	if (const char *env = getenv("MIJ_ES_BITS_OVERRIDE")) {
+		const long v = atol(env);
+		if (v >= 256 && v <= (long)MIJ_ES_BITS && (v & 31) == 0)
+			e->sub_bits = (uint32_t)v;
+	}
+	/* shorter subsequences settle in more rounds; a round in which nothing moves costs a launch (~8 us), a look at the verdicts
+	 * a wait: measured on one-picture batches, 1024 bits with 24 rounds queued up front is the quickest (profiles/r02v_single_call.json) */
+	e->rounds0 = e->sub_bits >= 4096u ? 4 : (e->sub_bits >= 2048u ? 12 : (e->sub_bits >= 1024u ? 24 : 32));
+	e->sub_cap = e->stream_cap * 8 / e->sub_bits + 2 * e->scan_cap;
 	e->blk_cap = b->coef_cap / 128 + n;
 	e->work_cap = e->sub_cap / 256 + 2 * e->scan_cap;
 	e->pack_cap = e->blk_cap / 256 + 8 * n;
@@ -1361,7 +1379,7 @@ extern "C" int mij_batch_add_stream(mij_batch *b, const mjg_scan *scan, uint8_t 
 		const size_t off = table[2 * g], len = table[2 * g + 1];
 		if ((off & 3u) || off + len + 32 > stream_len + 32 || off + len > scan->seg_table_off)
 			return set_err(MIJ_E_ARG, "bad segment %u", g);
-		const size_t ns = (len * 8 + MIJ_ES_BITS - 1) / MIJ_ES_BITS;
+		const size_t ns = (len * 8 + e->sub_bits - 1) / e->sub_bits;
 		need_sub += ns ? ns : 1;
 		need_work += (ns ? ns : 1) / 256 + 1;
 	}
@@ -1401,7 +1419,7 @@ extern "C" int mij_batch_add_stream(mij_batch *b, const mjg_scan *scan, uint8_t 
 		const size_t k = e->scan_slot.size();
 		const size_t off = table[2 * g], len = table[2 * g + 1];
 		const uint32_t seg_mcus = scan->n_seg ? (g + 1 < nseg ? scan->restart_mcus : nmcu - first_mcu) : nmcu;
-		const size_t ns = (len * 8 + MIJ_ES_BITS - 1) / MIJ_ES_BITS;
+		const size_t ns = (len * 8 + e->sub_bits - 1) / e->sub_bits;
 		DevScan &d = e->h_scans[k];
 		memset(&d, 0, sizeof(d));
 		d.stream_off = (uint64_t)(stream - e->stage) + off;
@@ -1422,6 +1440,7 @@ extern "C" int mij_batch_add_stream(mij_batch *b, const mjg_scan *scan, uint8_t 
 		memcpy(d.dc_tab, scan->dc_tab, 4);
 		memcpy(d.ac_tab, scan->ac_tab, 4);
 		d.tab_off = (uint32_t)(8 * tab);
+		d.sub_bits = e->sub_bits;
 		memcpy(d.qz, scan->qz, sizeof(d.qz));
 		for (uint32_t f = 0; f < d.nsub; f += 256) {
 			EsWork w = {(uint32_t)k, f};
@@ -1545,7 +1564,7 @@ extern "C" int mij_batch_entropy_launch(mij_batch *b)
 	HIP_TRY(hipGetLastError());
 	e->cur = 0;
 	e->last_rounds = 0;
-	int rounds = 4; /* ordinary pictures settle in two or three; finish() adds rounds for those that have not */
+	int rounds = e->rounds0; /* 4096-bit subsequences: ordinary pictures settle in two or three of four; finish() adds rounds for those that have not */
 	if (const char *env = getenv("MIJ_ES_ROUNDS"))
 		rounds = atoi(env) > 0 && atoi(env) <= ES_MAX_ROUNDS ? atoi(env) : rounds;
 	for (int r = 0; r < rounds; ++r) {

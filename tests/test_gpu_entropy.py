@@ -304,10 +304,10 @@ def test_gpu_walk_is_the_default_front_end(ica, oracle, gpu_ctx, golden, monkeyp
 
 
 def test_stbi_load_from_memory_takes_the_gpu_walk_for_large_pictures(ica, oracle, gpu_ctx, golden, monkeypatch):
-    """>= 512x512 pixels from memory: header on the host, Huffman walk + everything else on the GPU.  With the threshold
+    """>= 1280x1024 pixels from memory (MIJ_GPU_WALK_MIN_PIXELS): header on the host, Huffman walk + everything else on the GPU.  With the threshold
     at zero every golden stream goes through the same entry: what the GPU walk does not take or reports back falls
     through to the host walk, so results and failure reasons stay the reference's."""
-    for (w, h, q) in ((512, 512, 90), (1920, 1080, 90), (800, 600, 95)):
+    for (w, h, q) in ((512, 512, 90), (1920, 1080, 90), (800, 600, 95), (1280, 1024, 90), (2048, 1536, 85)):
         data = ica.synth_jpeg(w, h, seed=w, quality=q)
         for req in (0, 3, 4, 1):
             got = ica.stbi_load_from_memory(data, req)
@@ -328,3 +328,64 @@ def test_stbi_load_from_memory_takes_the_gpu_walk_for_large_pictures(ica, oracle
                 if name == "dri_without_rst":
                     want = oracle.load(data, req)[1]
                 assert np.array_equal(got[0], want), (name, req)
+
+
+@pytest.mark.parametrize("bits", [256, 512, 1024, 2048])
+def test_gpu_walk_subsequence_lengths(ica, oracle, gpu_ctx, golden, monkeypatch, bits):
+    """The subsequence length is a property of the batch's entropy arena (DevScan.sub_bits): one-picture batches -- stbi_load_from_memory --
+    cut the stream into MIJ_ES_BITS_SINGLE = 1024 bits per lane (latency), everything else into 4096.  Every length must leave the host
+    walk's planes and the oracle's pixels, damaged streams included (mutations: accepted ones equal the oracle, the rest comes back)."""
+    monkeypatch.setenv("MIJ_ES_BITS_OVERRIDE", str(bits))
+    rng = np.random.default_rng(bits)
+    datas = [ica.synth_jpeg(w, h, i, q) for i, (w, h, q) in enumerate(((64, 48, 90), (200, 120, 90), (640, 480, 90), (1920, 1080, 90), (8, 8, 95), (1, 1, 90), (1024, 768, 30)))]
+    datas.append(ica.stbi_write_jpg_to_memory(rng.integers(0, 256, (211, 307, 3)).astype(np.uint8), 92))
+    datas.append(ica.stbi_write_jpg_to_memory(rng.integers(0, 256, (120, 160, 3)).astype(np.uint8), 100))
+    plan, du = ica.host_transform(ica.synth_rgb(250, 131, 5), 92)
+    datas.append(helpers.baseline_from_du(plan, du, restart_mcus=7))
+    b = ica.Batch(gpu_ctx, len(datas), 64 << 20, 64 << 20, 64 << 20)
+    b.entropy_reserve(16 << 20)
+    slots = []
+    for d in datas:
+        st, slot = b.add_jpeg_stream(d, 3)
+        assert st == 1, (st, b.last_reason)
+        slots.append(slot)
+    fallback = b.entropy_run()
+    # a lane that cannot finish a block inside its subsequence moves its chain one subsequence per round: noise at q=100 in 256-bit
+    # pieces may run out of rounds and come back for the host walk (which is what the fallback list is for); from 1024 bits on nothing may
+    assert fallback == [] or bits < 1024, (bits, fallback)
+    for d, s in zip(datas, slots):
+        desc, want = _host_planes(ica, d, 3)
+        if s in fallback:
+            b.fallback_prepare(s)
+            d2, _ = ica.HostDecoder.decode(d, 3, out=b.staging(s))
+            if d2.flags:
+                b.set_flags(s, d2.flags)
+            continue
+        got = b.fetch_coef(s)
+        for ci, (pg, pw) in enumerate(zip(ica.detile_coefficients(desc, got), ica.detile_coefficients(desc, want))):
+            assert np.array_equal(pg, pw), (bits, s, ci, int((pg != pw).sum()))
+    b.submit()
+    b.wait()
+    for d, s in zip(datas, slots):
+        assert np.array_equal(b.fetch(s), oracle.load(d, 3)[1]), (bits, s)
+    b.close()
+    # damaged streams through the front end
+    bases = [ica.synth_jpeg(160, 120, 1, 90), ica.synth_jpeg(97, 131, 2, 75), golden.jpg("b420_64x64_q90")]
+    part = [helpers.mutate(bases[k % 3], 5000 + bits + k, n_mut=1 + k % 4, allow_markers=(k % 3 == 0)) for k in range(45)]
+    b = ica.Batch(gpu_ctx, len(part), 16 << 20, 16 << 20, 16 << 20)
+    b.entropy_reserve(4 << 20)
+    ok, slots, reasons = b.decode_jpegs(part, 3, threads=4, gpu_entropy=True)
+    b.submit()
+    b.wait()
+    for i, d in enumerate(part):
+        kind, want, why = oracle.load(d, 3)
+        if slots[i] >= 0:
+            assert kind == "ok", (bits, i, why)
+            assert np.array_equal(b.fetch(slots[i]), want), (bits, i)
+        else:
+            assert kind == "fail" and reasons[i] == want, (bits, i, reasons[i], want)
+    b.close()
+    # and the one-picture path of the public API (its own arena, MIJ_ES_BITS_SINGLE unless overridden as here)
+    monkeypatch.setenv("MIJ_GPU_WALK_MIN_PIXELS", "0")
+    for d in datas[:4]:
+        assert np.array_equal(ica.stbi_load_from_memory(d, 3)[0], oracle.load(d, 3)[1])
