@@ -64,6 +64,12 @@ def encoder_stress(budget, rng):
     print("encoder stress ok: %d comparisons in %.0f s" % (n, budget))
 
 
+LAYOUTS = [([(1, 2), (1, 1), (1, 1)], -1), ([(4, 1), (1, 1), (1, 1)], -1), ([(4, 2), (1, 1), (1, 1)], -1), ([(2, 4), (1, 1), (1, 1)], -1),
+           ([(1, 4), (1, 1), (1, 1)], -1), ([(1, 1), (1, 1), (1, 1)], 0), ([(2, 2), (1, 1), (1, 1)], 0), ([(1, 1)] * 4, 0), ([(1, 1)] * 4, 2),
+           ([(2, 2), (1, 1), (1, 1), (2, 2)], 2), ([(2, 1), (1, 1), (1, 1), (2, 1)], 0), ([(1, 1)] * 4, 1), ([(2, 2), (1, 1), (1, 1), (1, 1)], 2),
+           ([(1, 1), (2, 2), (2, 2)], -1), ([(3, 1), (1, 1), (1, 1)], -1), ([(2, 2), (2, 1), (1, 2)], -1)]
+
+
 def main():
     if len(sys.argv) > 3 and sys.argv[3] == "enc":
         return encoder_stress(float(sys.argv[1]), np.random.default_rng(int(sys.argv[2])))
@@ -78,10 +84,12 @@ def main():
         datas = []
         for _ in range(24):
             w = int(rng.integers(1, 96)) if rng.random() < 0.3 else int(rng.integers(1, 700))
+            if rng.random() < 0.4:
+                w = (w + 3) & ~3  # multiples of four take the specialised pass 2 of the two-pass family
             h = int(rng.integers(1, 96)) if rng.random() < 0.3 else int(rng.integers(1, 500))
             q = int(rng.choice([1, 10, 35, 50, 75, 85, 90, 91, 95, 100]))
             img = picture(rng, w, h)
-            layout = int(rng.integers(0, 9))
+            layout = int(rng.integers(0, 12))
             if layout <= 1:
                 datas.append(ica.stbi_write_jpg_to_memory(img, q))
             else:
@@ -95,17 +103,20 @@ def main():
                     datas.append(helpers.progressive_grey_from_444(plan, du, script))
                 elif layout == 5:
                     datas.append(helpers.progressive_from_du(plan, du, script))
+                elif layout >= 9:  # sampling factors / colour tags that only the two-pass family takes (round 2)
+                    hv, app14 = LAYOUTS[int(rng.integers(0, len(LAYOUTS)))]
+                    datas.append(helpers.baseline_layout_from_444(plan, du, hv, app14, int(rng.choice([0, 0, 3, 40]))))
                 else:  # baseline with optimal tables and a random restart interval, in a random layout
                     lay = ["native", "422", "grey"][layout - 6]
                     dri = int(rng.choice([0, 1, 2, 5, 16, 100, 5000]))
                     datas.append(helpers.baseline_from_du(plan, du, dri, lay))
         req = int(rng.integers(0, 5))
         wants = [oracle.load(d, req) for d in datas]
-        for mode in ("fused", "generic", "gpu_walk"):
+        for mode in ("fused", "generic", "generic2", "gpu_walk"):
             b = ica.Batch(ctx, len(datas), 96 << 20, 96 << 20, 96 << 20)
             if mode == "gpu_walk":
                 b.entropy_reserve(8 << 20)
-            b.force_generic(mode == "generic")
+            b.force_generic(1 if mode == "generic" else (2 if mode == "generic2" else 0))
             ok, slots, reasons = b.decode_jpegs(datas, req, threads=4, gpu_entropy=(mode == "gpu_walk"))
             b.submit()
             b.wait()
@@ -120,6 +131,15 @@ def main():
                     raise SystemExit("MISMATCH mode=%s round=%d image=%d shape=%s req=%d path=%d" % (mode, rounds, i, want.shape, req, b.slot_path(slots[i])))
                 n_cmp += 1
             b.close()
+        # the one-picture path of the public API, Huffman walk on the GPU whatever the size (1024-bit subsequences)
+        os.environ["MIJ_GPU_WALK_MIN_PIXELS"] = "0" if rounds % 2 else "1310720"
+        for i in range(0, len(datas), 5):
+            got = ica.stbi_load_from_memory(datas[i], req)
+            kind, want, _ = wants[i]
+            if (got is None) != (kind != "ok") or (got is not None and not np.array_equal(got[0].reshape(-1), want.reshape(-1))):
+                open(os.path.join(ROOT, "gpurun_out", "stress_fail_single_%d_%d.jpg" % (rounds, i)), "wb").write(datas[i])
+                raise SystemExit("MISMATCH stbi_load_from_memory round=%d image=%d req=%d" % (rounds, i, req))
+            n_cmp += 1
         n_img += len(datas)
         if rounds % 100 == 0:
             print("  ... %d rounds, %d comparisons" % (rounds, n_cmp), flush=True)
