@@ -31,6 +31,7 @@ The one JSON line (rank 0) also carries, all OUTSIDE the timed region and only a
                         image-codecs_amd/synth.synth_rgb_edges): escaped blocks in most wavefronts
   legs.config4          BASELINE configs[3]: 32 x 4096x4096 progressive 4:4:4 (k_fused444), 9 B/px
   legs.config5          BASELINE configs[4]: 1024 x 1080p RGB -> data units (k_encode420), bytes == reference
+  legs.config5_q95_444  the same at quality 95: the writer's 4:4:4 layout, 512 images (k_encode444), 9 B/px
   legs.h2v1             512 x 1080p 4:2:2 (k_fused422), 7 B/px
   legs.config1          BASELINE configs[0]: one 512x512 4:2:0 JPEG per stbi_load_from_memory call (latency of the drop-in call)
   legs.two_pass         256 x 1080p through the two-pass family (sample planes in HBM, pass 2 compiled per resampler):
@@ -308,16 +309,19 @@ def leg_config4(ica, ctx, args, checker):
         b.close()
 
 
-def leg_config5(ica, ctx, args, checker):
-    """BASELINE configs[4]: 1024 x 1080p RGB -> quantised data units (k_encode420); the byte streams of the distinct
-    images equal the CPU checker's (the reference's own writer when its .so travelled)."""
-    n, distinct = args.images, 4
+def leg_config5(ica, ctx, args, checker, quality=90, count=None):
+    """BASELINE configs[4]: 1024 x 1080p RGB -> quantised data units (k_encode420; quality above 90: the writer's 4:4:4 layout,
+    k_encode444, 512 images); the byte streams of the distinct images equal the CPU checker's (the reference's own writer when
+    its .so travelled)."""
+    n, distinct = (count or args.images), 4
+    sub = quality <= 90  # codec/jpeg_write.c:221
+    units = 120 * 68 * 6 if sub else 240 * 135 * 3
     imgs = [ica.synth_rgb(W, H, s) for s in range(distinct)]
     pix = (W * H * 3 + 255) // 256 * 256
-    dub = (120 * 68 * 6 * 128 + 255) // 256 * 256
+    dub = (units * 128 + 255) // 256 * 256
     enc = ica.Encoder(ctx, n, pix * n, dub * n)
     try:
-        src = [enc.add(im, 90) for im in imgs]
+        src = [enc.add(im, quality) for im in imgs]
         for i in range(distinct, n):
             enc.add_clone(src[i % distinct])
         enc.upload()
@@ -329,8 +333,8 @@ def leg_config5(ica, ctx, args, checker):
         fenc.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         for k, im in enumerate(imgs):
             mine = ica.emit_jpeg(enc.plan(src[k]), enc.fetch(src[k]))
-            buf = np.zeros(W * H * 2, np.uint8)
-            nb = fenc(buf.ctypes.data, buf.size, W, H, 3, np.ascontiguousarray(im).ctypes.data, 90)
+            buf = np.zeros(W * H * 3, np.uint8)
+            nb = fenc(buf.ctypes.data, buf.size, W, H, 3, np.ascontiguousarray(im).ctypes.data, quality)
             assert nb > 0 and mine == bytes(buf[:nb]), "encoded stream %d differs from the CPU checker's" % k
         assert np.array_equal(enc.fetch(n - 1), enc.fetch(src[(n - 1) % distinct]))
         n_warm = 0
@@ -346,12 +350,14 @@ def leg_config5(ica, ctx, args, checker):
             enc.launch()
         enc.timer_end()
         ms = enc.timer_ms() / args.steps
-        algo = n * (W * H * 3 + 120 * 68 * 6 * 128)
-        res = {"workload": "%d x 1920x1080 RGB -> 4:2:0 q=90 data units, pixels resident" % n, "kernel": "mij::k_encode420",
+        algo = n * (W * H * 3 + units * 128)
+        res = {"workload": "%d x 1920x1080 RGB -> %s q=%d data units, pixels resident" % (n, "4:2:0" if sub else "4:4:4", quality),
+               "kernel": "mij::k_encode420" if sub else "mij::k_encode444",
                "kernel_ms_per_launch": round(ms, 4), "algorithmic_bytes_per_launch": algo, "mpix_s": round(n * W * H / ms / 1e3, 1),
                "frac": round(frac_of(algo, ms), 4), "parity": True, "parity_against": kind + " (byte streams of the %d distinct images)" % distinct,
                "warmup_launches_issued": n_warm}
-        add_traffic(res, "k_encode420_%d" % n)
+        if sub:
+            add_traffic(res, "k_encode420_%d" % n)
         return res
     finally:
         enc.close()
@@ -711,6 +717,7 @@ def main():
         run_leg("harsh_batch", harsh_leg)
         run_leg("config4", lambda: leg_config4(ica, ctx, args, checker))
         run_leg("config5", lambda: leg_config5(ica, ctx, args, checker))
+        run_leg("config5_q95_444", lambda: leg_config5(ica, ctx, args, checker, quality=95, count=512))
         run_leg("h2v1", lambda: leg_h2v1(ica, ctx, args, checker))
         run_leg("two_pass", lambda: leg_two_pass(ica, ctx, datas, args, checker))
         run_leg("config1", lambda: leg_config1(ica, checker))

@@ -2100,6 +2100,109 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(MIJ_ENC_WAV
 	}
 }
 
+/* ------------------------------------------------------------------ fused 4:4:4 encoder (3-component images, width % 8 == 0)
+ *
+ * The writer takes 4:4:4 for every quality above 90 (codec/jpeg_write.c:221, :283-352: MCU = one 8x8 block per component).
+ * The per-unit kernels read the pixels of such a picture three times with per-byte loads; here one workgroup (3 waves)
+ * owns a strip of 64 consecutive MCUs (MCU index order, so a strip may run over the end of an MCU row):
+ *   load     8 pixel rows x 64 MCUs x 24 B, each thread eight coalesced 8-byte loads -> LDS [8][1536]
+ *   convert  wave c = component c (Y, U, V), lane = MCU: the lane's 8 x 24 bytes from LDS, two pixel rows at a time as f2
+ *            (top, bottom) pairs straight into the row-pair form the DCT wants (enc_component<c>'s expression on f2)
+ *   DCT      every lane its own unit (all three waves carry the same load), quantised with fy (Y) or fc (U, V)
+ *   store    units staged in LDS (swizzled 16-byte chunks) over the dead pixel rows, then the strip's 64 x 384 contiguous
+ *            output bytes with coalesced 16-byte stores.
+ * Each byte is converted three times (once per component) but read from HBM once; algorithmic bytes 3 + 6 per pixel.
+ */
+#define MIJ_ENC444_STRIP 64
+#define MIJ_ENC444_PIXROW (MIJ_ENC444_STRIP * 24)
+#define MIJ_ENC444_LDS (MIJ_ENC444_STRIP * 3 * MIJ_ENC_DUPITCH) /* staged units; the pixel rows (8 x 1536 B) lie inside */
+
+template <int C>
+__device__ __forceinline__ f2 enc_component2(f2 r, f2 g, f2 b)
+{
+	if (C == 0)
+		return +0.29900f * r + 0.58700f * g + 0.11400f * b - 128.0f;
+	if (C == 1)
+		return -0.16874f * r - 0.33126f * g + 0.50000f * b;
+	return +0.50000f * r - 0.41869f * g - 0.08131f * b;
+}
+
+template <int C>
+__device__ __forceinline__ void enc444_convert(const uint8_t *src, f2 (&V)[4][8])
+{
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		const uint2 *tp = reinterpret_cast<const uint2 *>(src + (2 * k) * MIJ_ENC444_PIXROW);
+		const uint2 *bp = reinterpret_cast<const uint2 *>(src + (2 * k + 1) * MIJ_ENC444_PIXROW);
+		const uint2 t0 = tp[0], t1 = tp[1], t2 = tp[2], b0 = bp[0], b1 = bp[1], b2 = bp[2];
+		const uint32_t t[6] = {t0.x, t0.y, t1.x, t1.y, t2.x, t2.y};
+		const uint32_t b[6] = {b0.x, b0.y, b1.x, b1.y, b2.x, b2.y};
+#define MIJ_ENC_PX(XI) V[k][XI] = enc_component2<C>(enc_byte2<3 * (XI) + 0>(t, b), enc_byte2<3 * (XI) + 1>(t, b), enc_byte2<3 * (XI) + 2>(t, b));
+		MIJ_ENC_PX(0) MIJ_ENC_PX(1) MIJ_ENC_PX(2) MIJ_ENC_PX(3) MIJ_ENC_PX(4) MIJ_ENC_PX(5) MIJ_ENC_PX(6) MIJ_ENC_PX(7)
+#undef MIJ_ENC_PX
+		enc_row_fence();
+	}
+}
+
+__global__ __launch_bounds__(192) void k_encode444(const EncImage *__restrict__ imgs, const WorkIdct *__restrict__ work, const uint8_t *__restrict__ pix,
+																	int16_t *__restrict__ du)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	uint8_t *const spx = lds; /* pixel rows, later the staged data units */
+	uint8_t *const sdu = lds;
+	const WorkIdct wk = work[blockIdx.x];
+	const EncImage &im = imgs[wk.img];
+	const int tid = threadIdx.x;
+	const uint32_t nmcu = (uint32_t)(im.mcu_x * im.mcu_y);
+	const uint32_t m0 = wk.first;
+	const uint32_t cnt = min((uint32_t)MIJ_ENC444_STRIP, nmcu - m0);
+	EncPix P;
+	enc_setup(im, pix, P);
+
+	/* ---- load: thread -> fixed 8-byte column chunk of the strip (MCU tid / 3, third tid % 3), rows 0..7 */
+	{
+		const uint32_t j = (uint32_t)tid / 3u, part = (uint32_t)tid - 3u * j;
+		const uint32_t m = min(m0 + j, nmcu - 1u); /* past the last MCU: any valid pixels, the units are dropped */
+		const uint32_t my = m / (uint32_t)im.mcu_x, mx = m - my * (uint32_t)im.mcu_x;
+		const uint32_t cbase = mx * 24u + part * 8u;
+		uint2 v[8];
+#pragma unroll
+		for (int i = 0; i < 8; ++i)
+			v[i] = *reinterpret_cast<const uint2 *>(P.px + P.row_base((int)(8u * my) + i) + cbase);
+#pragma unroll
+		for (int i = 0; i < 8; ++i)
+			*reinterpret_cast<uint2 *>(spx + i * MIJ_ENC444_PIXROW + tid * 8) = v[i];
+	}
+	__syncthreads();
+
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+	f2 V[4][8];
+	const uint8_t *src = spx + lane * 24;
+	if (wave == 0)
+		enc444_convert<0>(src, V);
+	else if (wave == 1)
+		enc444_convert<1>(src, V);
+	else
+		enc444_convert<2>(src, V);
+	__syncthreads(); /* pixel rows dead */
+
+	{
+		const int u = lane * 3 + wave;
+		fdct_quant_store<0>(V, wave == 0 ? im.fy : im.fc, reinterpret_cast<int16_t *>(sdu + u * MIJ_ENC_DUPITCH), u & 7);
+	}
+	__syncthreads();
+
+	/* ---- store: cnt * 384 contiguous bytes */
+	{
+		uint8_t *out = reinterpret_cast<uint8_t *>(du) + im.du_off + (size_t)m0 * 384u;
+		const int nchunk = (int)cnt * 24;
+		for (int g = tid; g < nchunk; g += 192) {
+			const uint4 t = *reinterpret_cast<const uint4 *>(sdu + enc_du_chunk(g >> 3, g & 7));
+			__builtin_nontemporal_store((u4v){t.x, t.y, t.z, t.w}, reinterpret_cast<u4v *>(out + (size_t)g * 16u));
+		}
+	}
+}
+
 } /* namespace mij */
 
 #endif

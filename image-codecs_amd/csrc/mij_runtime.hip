@@ -1790,7 +1790,7 @@ struct mij_encoder {
 	EncImage *h_imgs, *d_imgs;
 	WorkIdct *h_work, *d_work;
 	size_t work_cap;
-	size_t n_work[5], first_work[5]; /* [sub*2 + kind]: kind 0 luma units, 1 chroma units; [4]: fused 4:2:0 strips */
+	size_t n_work[6], first_work[6]; /* [sub*2 + kind]: kind 0 luma units, 1 chroma units; [4]: fused 4:2:0 strips; [5]: fused 4:4:4 strips */
 	std::vector<EncSlot> slots;
 	bool uploaded, launched, force_generic;
 };
@@ -1959,7 +1959,7 @@ extern "C" int mij_enc_upload(mij_encoder *e)
 	const size_t n = e->slots.size();
 	if (!n)
 		return set_err(MIJ_E_STATE, "encoder batch is empty");
-	std::vector<WorkIdct> work[5];
+	std::vector<WorkIdct> work[6];
 	for (size_t i = 0; i < n; ++i) {
 		const EncSlot &s = e->slots[i];
 		const uint32_t nm = (uint32_t)(s.plan.mcu_x * s.plan.mcu_y);
@@ -1974,6 +1974,14 @@ extern "C" int mij_enc_upload(mij_encoder *e)
 			}
 			continue;
 		}
+		/* 4:4:4 (quality above 90): strips of 64 MCUs through k_encode444: whole 8-pixel columns, packed RGB, 8-byte aligned rows */
+		if (!sub && s.plan.comp == 3 && (s.plan.width & 7) == 0 && !e->force_generic) {
+			for (uint32_t f = 0; f < nm; f += MIJ_ENC444_STRIP) {
+				WorkIdct w = {(uint32_t)i, 0u, f, 0u};
+				work[5].push_back(w);
+			}
+			continue;
+		}
 		for (uint32_t f = 0; f < ny; f += 256) {
 			WorkIdct w = {(uint32_t)i, 0u, f, 0u};
 			work[sub * 2 + 0].push_back(w);
@@ -1983,14 +1991,14 @@ extern "C" int mij_enc_upload(mij_encoder *e)
 			work[sub * 2 + 1].push_back(w);
 		}
 	}
-	const size_t total = work[0].size() + work[1].size() + work[2].size() + work[3].size() + work[4].size();
+	const size_t total = work[0].size() + work[1].size() + work[2].size() + work[3].size() + work[4].size() + work[5].size();
 	if (total > e->work_cap)
 		HIP_TRY(hipStreamSynchronize(e->stream));
 	int rc = grow_pair(e->h_work, e->d_work, e->work_cap, total);
 	if (rc != MIJ_OK)
 		return rc;
 	size_t pos = 0;
-	for (int g = 0; g < 5; ++g) {
+	for (int g = 0; g < 6; ++g) {
 		e->first_work[g] = pos;
 		e->n_work[g] = work[g].size();
 		if (!work[g].empty())
@@ -2021,13 +2029,15 @@ extern "C" int mij_enc_launch(mij_encoder *e)
 	if (!e->uploaded)
 		return set_err(MIJ_E_STATE, "mij_enc_launch before mij_enc_upload");
 	HIP_TRY(hipSetDevice(e->ctx->device));
-	for (int g = 0; g < 5; ++g) {
+	for (int g = 0; g < 6; ++g) {
 		if (!e->n_work[g])
 			continue;
-		const dim3 grid((unsigned)e->n_work[g]), block(g == 4 ? 192 : 256);
+		const dim3 grid((unsigned)e->n_work[g]), block(g >= 4 ? 192 : 256);
 		const WorkIdct *wk = e->d_work + e->first_work[g];
 		if (g == 4)
 			hipLaunchKernelGGL(k_encode420, grid, block, MIJ_ENC_LDS, e->stream, e->d_imgs, wk, e->d_pix, e->d_du);
+		else if (g == 5)
+			hipLaunchKernelGGL(k_encode444, grid, block, MIJ_ENC444_LDS, e->stream, e->d_imgs, wk, e->d_pix, e->d_du);
 		else if (g == 0)
 			hipLaunchKernelGGL((k_encode_y<0>), grid, block, 0, e->stream, e->d_imgs, wk, e->d_pix, e->d_du);
 		else if (g == 1)

@@ -83,3 +83,32 @@ def test_fused_strip_kernel_and_per_unit_kernels_agree(ica, gpu_ctx):
         for s, im, q in zip(flipped, imgs, qs):
             assert np.array_equal(enc.fetch(s), ica.host_transform(im[::-1], q)[1]), (generic, im.shape)
         enc.close()
+
+
+def test_fused_444_strip_kernel_and_per_unit_kernels_agree(ica, oracle, gpu_ctx):
+    """Qualities above 90 make the writer take 4:4:4 (codec/jpeg_write.c:221).  Widths that are multiples of 8 go through the
+    fused 4:4:4 strip kernel (64 MCUs per workgroup, one wave per component, strips running over MCU-row ends, a partial last
+    strip, rows replicated below the image); the same images through the per-unit kernels and through the host transform must
+    give identical data units, and the byte streams made from them must be the oracle's (= the reference's)."""
+    rng = np.random.default_rng(29)
+    shapes = [(8, 8), (8, 1), (16, 9), (24, 40), (512, 8), (520, 33), (1024, 16), (72, 250), (1920, 1080), (8, 1100), (4096, 64), (20, 20)]
+    imgs = [rng.integers(0, 256, (h, w, 3)).astype(np.uint8) for (w, h) in shapes]
+    imgs[8] = ica.synth_rgb(1920, 1080, 3)
+    qs = [91, 100, 95, 92, 99, 91, 93, 97, 95, 91, 94, 96]
+    want = [ica.host_transform(im, q)[1] for im, q in zip(imgs, qs)]
+    for generic in (False, True):
+        enc = ica.Encoder(gpu_ctx, 2 * len(imgs), 64 << 20, 96 << 20)
+        enc.force_generic(generic)
+        slots = [enc.add(im, q) for im, q in zip(imgs, qs)]
+        flipped = [enc.add(im, q, flip=True) for im, q in zip(imgs[:5], qs[:5])]
+        enc.upload()
+        enc.launch()
+        enc.wait()
+        for s, w_, shape, im, q in zip(slots, want, shapes, imgs, qs):
+            got = enc.fetch(s)
+            assert np.array_equal(got, w_), (generic, shape, int((got != w_).sum()))
+            if shape[0] * shape[1] <= 520 * 33:
+                assert ica.emit_jpeg(enc.plan(s), got) == oracle.encode(im, q), (generic, shape)
+        for s, im, q in zip(flipped, imgs, qs):
+            assert np.array_equal(enc.fetch(s), ica.host_transform(im[::-1], q)[1]), (generic, im.shape)
+        enc.close()
