@@ -61,24 +61,70 @@ static mij_ctx *shared_ctx(void)
 typedef struct {
 	mij_batch *b;
 	size_t coef_cap, out_cap, stream_cap;
+	uint8_t *bounce; /* pinned host buffer of out_cap bytes, allocated on first need (fetch_pixels) */
 } tl_batch;
 
-static __thread tl_batch t_batch = {NULL, 0, 0, 0};
+/* The calling thread's one-picture batch lives in thread-local storage while the thread lives.  When the thread ends, the batch
+ * goes back to a process-wide pool instead of being destroyed: a pthread-key destructor runs AFTER the C++ thread_local
+ * destructors of the thread, the HIP runtime keeps its per-thread state in such objects, and calling it from there corrupts the
+ * heap (seen as "malloc_consolidate(): unaligned fastbin chunk" at process exit after a few dozen short-lived threads had each
+ * made stbi_load calls).  A new thread takes a pooled batch before it creates one -- which also spares thread-pool style callers
+ * the 70 MB of allocations per new thread. */
+#define MIJ_POOL_MAX 64
+static __thread tl_batch t_batch = {NULL, 0, 0, 0, NULL};
 static pthread_key_t g_batch_key;
 static pthread_once_t g_batch_key_once = PTHREAD_ONCE_INIT;
+static pthread_mutex_t g_pool_lock = PTHREAD_MUTEX_INITIALIZER;
+static tl_batch g_pool[MIJ_POOL_MAX];
+static int g_pool_n = 0;
 
 static void batch_key_dtor(void *p)
 {
-	if (p)
-		mij_batch_destroy((mij_batch *)p);
+	tl_batch *t = (tl_batch *)p;
+	if (!t)
+		return;
+	pthread_mutex_lock(&g_pool_lock);
+	if (t->b && g_pool_n < MIJ_POOL_MAX)
+		g_pool[g_pool_n++] = *t; /* no HIP call here; a pool that is full leaks the batch rather than risk one */
+	pthread_mutex_unlock(&g_pool_lock);
+	free(t);
 }
 static void batch_key_init(void) { pthread_key_create(&g_batch_key, batch_key_dtor); }
+
+/* the key's value mirrors t_batch for the destructor (heap copy: the thread's static TLS block is not ours to read then) */
+static void remember_thread_batch(void)
+{
+	tl_batch *t;
+	pthread_once(&g_batch_key_once, batch_key_init);
+	t = (tl_batch *)pthread_getspecific(g_batch_key);
+	if (!t) {
+		t = (tl_batch *)calloc(1, sizeof(*t));
+		if (!t)
+			return;
+		pthread_setspecific(g_batch_key, t);
+	}
+	*t = t_batch;
+}
 
 /* a one-image batch big enough for `d` (and, stream_bytes > 0, with an entropy arena for a file of that many bytes: the GPU
  * Huffman walk), grown geometrically and reused across calls */
 static mij_batch *thread_batch(mij_ctx *ctx, const mij_image_desc *d, size_t stream_bytes)
 {
 	size_t cb = mij_image_coef_bytes(d), ob = mij_image_out_bytes(d);
+	if (!t_batch.b) { /* a batch a finished thread left behind, the roomiest one */
+		int i, best = -1;
+		pthread_mutex_lock(&g_pool_lock);
+		for (i = 0; i < g_pool_n; ++i)
+			if (best < 0 || g_pool[i].coef_cap > g_pool[best].coef_cap)
+				best = i;
+		if (best >= 0) {
+			t_batch = g_pool[best];
+			g_pool[best] = g_pool[--g_pool_n];
+		}
+		pthread_mutex_unlock(&g_pool_lock);
+		if (t_batch.b)
+			remember_thread_batch();
+	}
 	if (t_batch.b && cb <= t_batch.coef_cap && ob <= t_batch.out_cap && stream_bytes <= t_batch.stream_cap) {
 		if (mij_batch_reset(t_batch.b) != MIJ_OK)
 			return NULL;
@@ -88,8 +134,12 @@ static mij_batch *thread_batch(mij_ctx *ctx, const mij_image_desc *d, size_t str
 		if (stream_bytes < t_batch.stream_cap)
 			stream_bytes = t_batch.stream_cap; /* keep what earlier calls needed */
 		mij_batch_destroy(t_batch.b);
+		if (t_batch.bounce)
+			mij_host_free(t_batch.bounce);
 		t_batch.b = NULL;
+		t_batch.bounce = NULL;
 		t_batch.coef_cap = t_batch.out_cap = t_batch.stream_cap = 0;
+		remember_thread_batch();
 	}
 	{
 		size_t ccap = cb + cb / 4 + 4096, ocap = ob + ob / 4 + 4096;
@@ -110,10 +160,36 @@ static mij_batch *thread_batch(mij_ctx *ctx, const mij_image_desc *d, size_t str
 		t_batch.coef_cap = ccap;
 		t_batch.out_cap = ocap;
 		t_batch.stream_cap = stream_bytes;
-		pthread_once(&g_batch_key_once, batch_key_init);
-		pthread_setspecific(g_batch_key, b);
+		remember_thread_batch();
 	}
 	return t_batch.b;
+}
+
+/* Pixels of the thread batch's one picture into the caller's malloc block.  A device-to-host copy into pageable memory goes
+ * through one staging path inside the HIP runtime: calls from several threads queue up behind each other (eight threads decoding
+ * 1080p pictures: 4 Gpix/s in all, tools/bench_threads.py).  With more than one stbi_load call in flight the pixels therefore
+ * cross PCIe into the batch's own pinned buffer and the calling thread copies them out itself. */
+static int g_calls_in_flight = 0;
+
+static int fetch_pixels(mij_batch *b, int slot, unsigned char *pixels, size_t nbytes)
+{
+	const char *env = getenv("MIJ_FETCH_BOUNCE"); /* 0: never, 1: always; default: when other calls are in flight */
+	const int bounce = env ? atoi(env) : (__atomic_load_n(&g_calls_in_flight, __ATOMIC_RELAXED) > 1);
+	if (bounce && t_batch.b == b) {
+		if (!t_batch.bounce) {
+			t_batch.bounce = (uint8_t *)mij_host_alloc(t_batch.out_cap);
+			remember_thread_batch();
+		}
+		if (t_batch.bounce && mij_batch_out_bytes(b) <= t_batch.out_cap) {
+			const size_t off = mij_batch_out_offset(b, slot);
+			if (off != (size_t)-1 && off + nbytes <= t_batch.out_cap && mij_batch_fetch_all_async(b, t_batch.bounce, t_batch.out_cap) == MIJ_OK &&
+				 mij_batch_wait(b) == MIJ_OK) {
+				memcpy(pixels, t_batch.bounce + off, nbytes);
+				return MIJ_OK;
+			}
+		}
+	}
+	return mij_batch_fetch(b, slot, pixels, nbytes);
 }
 
 /* ------------------------------------------------------------------ load */
@@ -179,7 +255,7 @@ static unsigned char *load_gpu_walk(mij_ctx *ctx, const uint8_t *buf, int len, i
 	pixels = (unsigned char *)malloc(nbytes + 1); /* codec/jpeg.c:2293: n * x * y + 1 bytes */
 	if (!pixels)
 		goto out;
-	if (mij_batch_submit(b) != MIJ_OK || mij_batch_fetch(b, slot, pixels, nbytes) != MIJ_OK) {
+	if (mij_batch_submit(b) != MIJ_OK || fetch_pixels(b, slot, pixels, nbytes) != MIJ_OK) {
 		free(pixels);
 		pixels = NULL;
 	}
@@ -189,7 +265,7 @@ out:
 }
 
 /* stbi__load_main (image_api.c:3-56) + stbi__jpeg_load / load_jpeg_image (codec/jpeg.c:2224-2452) */
-static unsigned char *load_main(mjh_reader *r, int *x, int *y, int *comp, int req_comp)
+static unsigned char *load_main_counted(mjh_reader *r, int *x, int *y, int *comp, int req_comp)
 {
 	mjh_decoder *d;
 	mij_image_desc desc;
@@ -285,7 +361,7 @@ static unsigned char *load_main(mjh_reader *r, int *x, int *y, int *comp, int re
 		free(d);
 		return fail_ptr("outofmem");
 	}
-	if (mij_batch_submit(b) != MIJ_OK || mij_batch_fetch(b, slot, pixels, nbytes) != MIJ_OK) {
+	if (mij_batch_submit(b) != MIJ_OK || fetch_pixels(b, slot, pixels, nbytes) != MIJ_OK) {
 		free(pixels);
 		free(d);
 		return fail_ptr("gpu decode failed");
@@ -296,6 +372,15 @@ static unsigned char *load_main(mjh_reader *r, int *x, int *y, int *comp, int re
 		*comp = d->img_n >= 3 ? 3 : 1;
 	free(d);
 	return pixels;
+}
+
+static unsigned char *load_main(mjh_reader *r, int *x, int *y, int *comp, int req_comp)
+{
+	unsigned char *p;
+	__atomic_add_fetch(&g_calls_in_flight, 1, __ATOMIC_RELAXED);
+	p = load_main_counted(r, x, y, comp, req_comp);
+	__atomic_sub_fetch(&g_calls_in_flight, 1, __ATOMIC_RELAXED);
+	return p;
 }
 
 /* convert.c:78-104 */

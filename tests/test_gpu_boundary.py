@@ -126,3 +126,40 @@ def test_late_markers_through_every_front_end(ica, oracle, gpu_ctx, g2):
     for name, s in zip(g2.late_names, slots):
         assert np.array_equal(b.fetch(s), g2.late(name, 3)[2]), name
     b.close()
+
+
+def test_stbi_load_from_many_host_threads(golden, ica, oracle, gpu_ctx):
+    """The reference is re-entrant apart from its global reason string (threading): a drop-in may be called from many
+    host threads at once, one picture each.  Eight threads decode interleaved lists -- small pictures (host walk), pictures above the
+    GPU-walk threshold, damaged and rejected streams -- through stbi_load_from_memory; every result equals the oracle's and every
+    failure reason is the one of the calling thread's own last call (thread-local), whatever the other threads were doing."""
+    import threading
+    good = [ica.synth_jpeg(w, h, seed=w + h, quality=q) for (w, h, q) in ((64, 48, 90), (640, 360, 75), (1920, 1080, 90), (1280, 1024, 92), (333, 211, 95), (2048, 1536, 85))]
+    bad = [golden.jpg("garbage"), golden.jpg("b420_64x64_q90")[:200], b"\xff\xd8\xff\xdb\x00\x02"]
+    datas = good + bad
+    wants = [oracle.load(d, 3) for d in datas]
+    errors = []
+
+    def worker(t):
+        try:
+            for rep in range(6):
+                for k in range(len(datas)):
+                    i = (k * 5 + t + rep) % len(datas)
+                    got = ica.stbi_load_from_memory(datas[i], 3)
+                    kind, want, _ = wants[i]
+                    if kind == "ok":
+                        if got is None or not np.array_equal(got[0], want):
+                            errors.append((t, rep, i, "pixels"))
+                    else:
+                        why = ica.stbi_failure_reason()
+                        if got is not None or why != want:
+                            errors.append((t, rep, i, why, want))
+        except Exception as exc:  # noqa: BLE001
+            errors.append((t, repr(exc)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:5]
