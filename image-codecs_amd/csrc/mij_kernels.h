@@ -867,7 +867,7 @@ struct Fused420Lds {
 	int YP, CP;
 };
 
-__device__ __forceinline__ size_t fused420_lds_bytes(int mcu_x) { return (size_t)mcu_x * (16 * 16 + 2 * 8 * 8 + 2 * 16 + 4 * 8); }
+__device__ __forceinline__ size_t fused420_lds_bytes(int mcu_x) { return (size_t)mcu_x * (16 * 16 + 2 * 8 * 8 + 2 * 16 + 4 * 8); } /* 4:4:0: 16 * 8 + 128 + 2 * 8 + 32 */
 
 template <int NOUT>
 __device__ __forceinline__ void store_rgb_px(uint8_t *__restrict__ p, int r, int g, int b)
@@ -881,10 +881,17 @@ __device__ __forceinline__ void store_rgb_px(uint8_t *__restrict__ p, int r, int
 
 /* careful per-pixel path for the image's left/right edge strips and unaligned widths:
  * the same closed form as upsample_strip's hv_2 case with the chroma rows already resolved */
-template <int NOUT>
+template <int NOUT, bool H2 = true>
 __device__ __forceinline__ void fused420_pixel(const uint8_t *yrow, const uint8_t *cbA, const uint8_t *cbB, const uint8_t *crA, const uint8_t *crB, int nearIsB,
 															  int wc, int x, uint8_t *__restrict__ dst)
 {
+	if (!H2) { /* v_2: (3 near + far + 2) >> 2 on the pixel's own column (codec/jpeg.c:1774-1782) */
+		const int cb = (3 * (nearIsB ? cbB : cbA)[x] + (nearIsB ? cbA : cbB)[x] + 2) >> 2, cr = (3 * (nearIsB ? crB : crA)[x] + (nearIsB ? crA : crB)[x] + 2) >> 2;
+		int r, g, b;
+		ycbcr_to_rgb(yrow[x], cb, cr, r, g, b);
+		store_rgb_px<NOUT>(dst + (size_t)x * NOUT, r, g, b);
+		return;
+	}
 	int i = x >> 1;
 	int j = (x & 1) ? min(i + 1, wc - 1) : max(i - 1, 0);
 	const uint8_t *cbN = nearIsB ? cbB : cbA, *cbF = nearIsB ? cbA : cbB;
@@ -987,6 +994,27 @@ __device__ __forceinline__ void strip_row(const ColorK &K, uint32_t wk, uint32_t
 	store_px4<NOUT>(dst, p0, p1, p2, p3);
 }
 
+/* (3 n + f + 2) >> 2 on the four bytes of n and f (even and odd bytes in 16-bit lanes: 3*255 + 255 + 2 < 2^16) */
+__device__ __forceinline__ uint32_t rs_v2(uint32_t n, uint32_t f)
+{
+	const uint32_t m = 0x00ff00ffu;
+	const uint32_t te = (n & m) * 3u + (f & m) + 0x00020002u, to = ((n >> 8) & m) * 3u + ((f >> 8) & m) + 0x00020002u;
+	return ((te >> 2) & m) | (((to >> 2) & m) << 8);
+}
+
+/* one output row of a 4-pixel strip whose chroma is already up-sampled and packed: four samples per dword */
+template <int NOUT>
+__device__ __forceinline__ void strip_row_packed(const ColorK &K, uint32_t cb4, uint32_t cr4, uint32_t yv, uint8_t *__restrict__ dst)
+{
+	Rgb12 p[4];
+#pragma unroll
+	for (int j = 0; j < 4; ++j) {
+		const uint32_t sel = 0x0c000c04u + (uint32_t)j * 0x00010001u; /* (chroma byte j | luma byte j << 16) */
+		p[j] = color_px(K, __builtin_amdgcn_perm(cr4, yv, sel), __builtin_amdgcn_perm(cb4, yv, sel));
+	}
+	store_px4<NOUT>(dst, p[0], p[1], p[2], p[3]);
+}
+
 /* threads per workgroup of k_fused420 (A/B knob: 256 = three workgroups of four waves per CU at 1080p, 512 = two of eight) */
 #ifndef MIJ_F420_NT
 #define MIJ_F420_NT 256
@@ -997,9 +1025,13 @@ __device__ __forceinline__ void strip_row(const ColorK &K, uint32_t wk, uint32_t
 #ifndef MIJ_F420_WAVES /* waves per SIMD the kernel's register count allows (the band planner counts co-resident workgroups with it) */
 #define MIJ_F420_WAVES 4
 #endif
-template <int NOUT, bool WIDE, bool B8 = false>
-__global__ __launch_bounds__(MIJ_F420_NT) MIJ_F420_ATTR void k_fused420(const DevImage *__restrict__ imgs, const WorkBand *__restrict__ work, const uint8_t *__restrict__ coef,
-																  uint8_t *__restrict__ outbase)
+/* H2 = false: the same band kernel for h1v2 (4:4:0) files -- MCU = 8 x 16 pixels, two luma blocks one above the other, chroma at
+ * full width and half height (resample_row_v_2, codec/jpeg.c:1774-1782).  Vertically nothing changes (row pairs (2C-1, 2C) on chroma
+ * rows C-1 and C, saved rows, halo block rows at the band edges); horizontally there is no neighbourhood: a strip's chroma is one
+ * dword per row and (3 near + far + 2) >> 2 runs on four samples at once in 16-bit lanes (rs_v2). */
+template <int NOUT, bool WIDE, bool B8, bool H2>
+__device__ __forceinline__ void fused_band(const DevImage *__restrict__ imgs, const WorkBand *__restrict__ work, const uint8_t *__restrict__ coef,
+														 uint8_t *__restrict__ outbase)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 	const WorkBand wk = work[blockIdx.x];
@@ -1009,10 +1041,10 @@ __global__ __launch_bounds__(MIJ_F420_NT) MIJ_F420_ATTR void k_fused420(const De
 
 	const int mcu_x = im.mcu_x;
 	const int W = im.width, H = im.height;
-	const int YP = 16 * mcu_x, CP = 8 * mcu_x;
-	const int wc = (W + 1) >> 1;    /* w_lores of the chroma planes, codec/jpeg.c:2276 */
+	const int YP = (H2 ? 16 : 8) * mcu_x, CP = 8 * mcu_x;
+	const int wc = H2 ? (W + 1) >> 1 : W; /* w_lores of the chroma planes, codec/jpeg.c:2276 */
 	const int hc = im.comp[1].y;    /* effective chroma rows */
-	const int bwY = 2 * mcu_x, bwC = mcu_x;
+	const int bwY = (H2 ? 2 : 1) * mcu_x, bwC = mcu_x;
 
 	uint8_t *const sY = lds;
 	uint8_t *const sCb = sY + 16 * YP;
@@ -1027,7 +1059,7 @@ __global__ __launch_bounds__(MIJ_F420_NT) MIJ_F420_ATTR void k_fused420(const De
 
 	const int m0 = (int)wk.m0, m1 = (int)wk.m1;
 	const int row_lo = 16 * m0, row_hi = min(16 * m1, H); /* rows this band emits */
-	const int nYw = (4 * mcu_x + 63) >> 6, nCw = (mcu_x + 63) >> 6;
+	const int nYw = (2 * bwY + 63) >> 6, nCw = (mcu_x + 63) >> 6;
 	const int nstrip = (W + 3) >> 2;
 	/* fast strips need dword-aligned rows (RGB: W % 4 == 0) and an output that fits 32-bit offsets */
 	const bool aligned = ((NOUT == 4) || ((W & 3) == 0)) && ((uint64_t)opitch * (uint32_t)H < 0xfffffff0ull);
@@ -1067,6 +1099,16 @@ __global__ __launch_bounds__(MIJ_F420_NT) MIJ_F420_ATTR void k_fused420(const De
 			uint32_t bA0, bA1, bB0, bB1, rA0, rA1, rB0, rB1, yA, yB;
 		};
 		auto load_strip = [&](int s, StripIn &in) {
+			if (!H2) { /* 4:4:0: the strip's four chroma samples are one dword of each row */
+				in.bA0 = reinterpret_cast<const uint32_t *>(cbA)[s];
+				in.bB0 = reinterpret_cast<const uint32_t *>(cbB)[s];
+				in.rA0 = reinterpret_cast<const uint32_t *>(crA)[s];
+				in.rB0 = reinterpret_cast<const uint32_t *>(crB)[s];
+				in.bA1 = in.bB1 = in.rA1 = in.rB1 = 0;
+				in.yA = *reinterpret_cast<const uint32_t *>(yA + 4 * s);
+				in.yB = *reinterpret_cast<const uint32_t *>(yB + 4 * s);
+				return;
+			}
 			const int d0 = (2 * s - 1) >> 2; /* strip 0 reads the dword in front of the row (inside LDS); the edge fix discards it */
 			const uint32_t *pbA = reinterpret_cast<const uint32_t *>(cbA) + d0, *pbB = reinterpret_cast<const uint32_t *>(cbB) + d0;
 			const uint32_t *prA = reinterpret_cast<const uint32_t *>(crA) + d0, *prB = reinterpret_cast<const uint32_t *>(crB) + d0;
@@ -1082,6 +1124,14 @@ __global__ __launch_bounds__(MIJ_F420_NT) MIJ_F420_ATTR void k_fused420(const De
 			in.yB = *reinterpret_cast<const uint32_t *>(yB + 4 * s);
 		};
 		auto do_strip = [&](int s, const StripIn &in) {
+			if (!H2) {
+				const uint32_t xo = (uint32_t)(4 * s) * NOUT;
+				if (doB)
+					strip_row_packed<NOUT>(KC, rs_v2(in.bB0, in.bA0), rs_v2(in.rB0, in.rA0), in.yB, out + (offB + xo));
+				if (doA)
+					strip_row_packed<NOUT>(KC, rs_v2(in.bA0, in.bB0), rs_v2(in.rA0, in.rB0), in.yA, out + (offA + xo));
+				return;
+			}
 			const int x0 = 4 * s, i0 = 2 * s;
 			/* bytes (c[i0-1], c[i0], c[i0+1], c[i0+2]) of each chroma row: two dwords + a byte funnel shift */
 			const uint32_t sh = (uint32_t)(i0 - 1) & 3u;
@@ -1132,9 +1182,9 @@ __global__ __launch_bounds__(MIJ_F420_NT) MIJ_F420_ATTR void k_fused420(const De
 			const int x0 = 4 * s, xe = min(x0 + 4, W);
 			for (int x = x0; x < xe; ++x) {
 				if (doA)
-					fused420_pixel<NOUT>(yA, cbA, cbB, crA, crB, 0, wc, x, out + (size_t)ra * opitch);
+					fused420_pixel<NOUT, H2>(yA, cbA, cbB, crA, crB, 0, wc, x, out + (size_t)ra * opitch);
 				if (doB)
-					fused420_pixel<NOUT>(yB, cbA, cbB, crA, crB, 1, wc, x, out + (size_t)rb * opitch);
+					fused420_pixel<NOUT, H2>(yB, cbA, cbB, crA, crB, 1, wc, x, out + (size_t)rb * opitch);
 			}
 		}
 	};
@@ -1228,6 +1278,21 @@ __global__ __launch_bounds__(MIJ_F420_NT) MIJ_F420_ATTR void k_fused420(const De
 			emit_pair(C, cbA, cbB, crA, crB, saveY + sv * YP, saveY + sv * YP);
 		}
 	}
+}
+
+template <int NOUT, bool WIDE, bool B8 = false>
+__global__ __launch_bounds__(MIJ_F420_NT) MIJ_F420_ATTR void k_fused420(const DevImage *__restrict__ imgs, const WorkBand *__restrict__ work, const uint8_t *__restrict__ coef,
+																  uint8_t *__restrict__ outbase)
+{
+	fused_band<NOUT, WIDE, B8, true>(imgs, work, coef, outbase);
+}
+
+/* h1v2 (4:4:0): see fused_band, H2 = false.  LDS 304 * mcu_x bytes. */
+template <int NOUT, bool WIDE, bool B8 = false>
+__global__ __launch_bounds__(MIJ_F420_NT) void k_fused440(const DevImage *__restrict__ imgs, const WorkBand *__restrict__ work, const uint8_t *__restrict__ coef,
+																			 uint8_t *__restrict__ outbase)
+{
+	fused_band<NOUT, WIDE, B8, false>(imgs, work, coef, outbase);
 }
 
 /* ------------------------------------------------------------------ fused h2v1 (4:2:2) YCbCr kernel
@@ -1480,14 +1545,6 @@ __device__ __forceinline__ uint32_t rs_window(const uint8_t *__restrict__ row, i
 	const int d0 = (i0 - 1) >> 2;
 	const uint32_t lo = p[max(d0, 0)], hi = p[min(d0 + 1, last_dword)];
 	return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(i0 - 1) & 3u);
-}
-
-/* (3 n + f + 2) >> 2 on the four bytes of n and f (even and odd bytes in 16-bit lanes: 3*255 + 255 + 2 < 2^16) */
-__device__ __forceinline__ uint32_t rs_v2(uint32_t n, uint32_t f)
-{
-	const uint32_t m = 0x00ff00ffu;
-	const uint32_t te = (n & m) * 3u + (f & m) + 0x00020002u, to = ((n >> 8) & m) * 3u + ((f >> 8) & m) + 0x00020002u;
-	return ((te >> 2) & m) | (((to >> 2) & m) << 8);
 }
 
 template <int KIND, bool YCC, int NOUT>

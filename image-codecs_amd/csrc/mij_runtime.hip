@@ -92,6 +92,7 @@ extern "C" int mij_ctx_create(int device, mij_ctx **out)
 	MIJ_LDS_ATTR((K<3, false, false>)); MIJ_LDS_ATTR((K<3, true, false>)); MIJ_LDS_ATTR((K<4, false, false>)); MIJ_LDS_ATTR((K<4, true, false>)); \
 	MIJ_LDS_ATTR((K<3, false, true>)); MIJ_LDS_ATTR((K<3, true, true>)); MIJ_LDS_ATTR((K<4, false, true>)); MIJ_LDS_ATTR((K<4, true, true>))
 	MIJ_LDS_ATTR8(k_fused420);
+	MIJ_LDS_ATTR8(k_fused440);
 	MIJ_LDS_ATTR8(k_fused422);
 #undef MIJ_LDS_ATTR8
 #undef MIJ_LDS_ATTR
@@ -137,12 +138,12 @@ struct Slot {
 	int dev_coef;      /* 1: the GPU entropy stage wrote the coefficient planes in HBM; nothing to upload */
 	int es_index;      /* index into the entropy arena's scan list, or -1 */
 	int coef_bytes_fmt; /* 1: compact planes in HBM (low bytes + escapes + DC array), 0: int16 tile layout */
-	int path;          /* 0 none, 1 fused 4:2:0, 2 two-pass, 3 fused 4:4:4, 4 fused 4:2:2, 5 fused grey */
+	int path;          /* 0 none, 1 fused 4:2:0, 2 two-pass, 3 fused 4:4:4, 4 fused 4:2:2, 5 fused grey, 6 fused 4:4:0 */
 };
 
 /* kernel families of a launch plan, in launch order */
 /* MK_RS_FAST + RS_*: pass 2 compiled per resampler (k_resample_fast); list index [n_out == 4][YCbCr colour][0] */
-enum { MK_PLANES = 0, MK_RESAMPLE, MK_RS_FAST, MK_420 = MK_RS_FAST + RS_KINDS, MK_422, MK_444, MK_GREY, MK_KINDS };
+enum { MK_PLANES = 0, MK_RESAMPLE, MK_RS_FAST, MK_420 = MK_RS_FAST + RS_KINDS, MK_422, MK_444, MK_GREY, MK_440, MK_KINDS };
 struct Work4 { /* WorkBand and WorkIdct are both four u32 */
 	uint32_t a, b, c, d;
 };
@@ -557,6 +558,22 @@ static bool fused420_ok(const mij_batch *b, const mij_image_desc &d)
 }
 
 /* single-component images: IDCT straight into the pixel buffer */
+/* h1v2 (4:4:0): luma 1x2, chroma 1x1 -- the band kernel with H2 = false, 304 * mcu_x bytes of LDS */
+static size_t fused440_lds(const mij_image_desc &d) { return (size_t)d.mcu_x * (16 * 8 + 2 * 8 * 8 + 2 * 8 + 4 * 8); }
+static bool fused440_ok(const mij_batch *b, const mij_image_desc &d)
+{
+	if (b->force_generic || (d.flags & MIJ_FLAG_SKIP))
+		return false;
+	if (d.ncomp != 3 || d.color != MIJ_COLOR_YCBCR || (d.n_out != 3 && d.n_out != 4))
+		return false;
+	if (d.comp[0].h != 1 || d.comp[0].v != 2)
+		return false;
+	for (int c = 1; c < 3; ++c)
+		if (d.comp[c].h != 1 || d.comp[c].v != 1)
+			return false;
+	return fused440_lds(d) <= (size_t)b->ctx->max_dyn_lds;
+}
+
 static bool fused_grey_ok(const mij_batch *b, const mij_image_desc &d)
 {
 	if (b->force_generic || (d.flags & MIJ_FLAG_SKIP))
@@ -736,34 +753,38 @@ extern "C" int mij_batch_upload(mij_batch *b)
 	 * band re-does two chroma block rows of IDCT as halo.  Pick the bands-per-image (1..16) that
 	 * minimises  rounds x (1 + halo share)  per unit of work; measured on MI355X: 1024 x 1080p ->
 	 * 6 bands (6144 workgroups = 8.0 rounds of 768) beats 4 (5.33 rounds) by ~1.5 %. */
-	size_t n_fused = 0, mcu_rows_sum = 0, lds_max = 0;
-	for (size_t i = 0; i < n; ++i)
-		if (fused420_ok(b, b->slots[i].desc)) {
-			const mij_image_desc &d = b->slots[i].desc;
-			++n_fused;
-			mcu_rows_sum += (size_t)d.mcu_y;
-			if (fused420_lds(d) > lds_max)
-				lds_max = fused420_lds(d);
-		}
-	int auto_nb = 1;
-	if (n_fused) {
-		size_t per_cu = lds_max ? (size_t)b->ctx->max_dyn_lds / lds_max : 1;
-		const size_t by_waves = 4 * MIJ_F420_WAVES / (MIJ_F420_NT / 64); /* waves per SIMD by registers x four SIMDs */
-		per_cu = per_cu < 1 ? 1 : (per_cu > by_waves ? by_waves : per_cu);
-		const size_t slots = (size_t)cu * per_cu;
-		const double avg_rows = (double)mcu_rows_sum / (double)n_fused;
-		double best = 1e30;
-		for (int nb = 1; nb <= 16 && nb <= (int)avg_rows; ++nb) {
-			const size_t wgs = n_fused * (size_t)nb;
-			const size_t rounds = (wgs + slots - 1) / slots;
-			const double halo = 1.0 + 0.5 * 2.0 * (nb - 1) / (6.0 * avg_rows); /* IDCT ~ half the work */
-			const double cost = (double)rounds * (avg_rows / nb) * halo;        /* time ~ rounds x band length */
-			if (cost < best * 0.999) {
-				best = cost;
-				auto_nb = nb;
+	auto auto_bands = [&](bool (*ok)(const mij_batch *, const mij_image_desc &), size_t (*lds_of)(const mij_image_desc &)) -> int {
+		size_t n_fused = 0, mcu_rows_sum = 0, lds_max = 0;
+		for (size_t i = 0; i < n; ++i)
+			if (ok(b, b->slots[i].desc)) {
+				const mij_image_desc &d = b->slots[i].desc;
+				++n_fused;
+				mcu_rows_sum += (size_t)d.mcu_y;
+				if (lds_of(d) > lds_max)
+					lds_max = lds_of(d);
+			}
+		int nb_best = 1;
+		if (n_fused) {
+			size_t per_cu = lds_max ? (size_t)b->ctx->max_dyn_lds / lds_max : 1;
+			const size_t by_waves = 4 * MIJ_F420_WAVES / (MIJ_F420_NT / 64); /* waves per SIMD by registers x four SIMDs */
+			per_cu = per_cu < 1 ? 1 : (per_cu > by_waves ? by_waves : per_cu);
+			const size_t slots = (size_t)cu * per_cu;
+			const double avg_rows = (double)mcu_rows_sum / (double)n_fused;
+			double best = 1e30;
+			for (int nb = 1; nb <= 16 && nb <= (int)avg_rows; ++nb) {
+				const size_t wgs = n_fused * (size_t)nb;
+				const size_t rounds = (wgs + slots - 1) / slots;
+				const double halo = 1.0 + 0.5 * 2.0 * (nb - 1) / (6.0 * avg_rows); /* IDCT ~ half the work */
+				const double cost = (double)rounds * (avg_rows / nb) * halo;        /* time ~ rounds x band length */
+				if (cost < best * 0.999) {
+					best = cost;
+					nb_best = nb;
+				}
 			}
 		}
-	}
+		return nb_best;
+	};
+	const int auto_nb = auto_bands(fused420_ok, fused420_lds), auto_nb440 = auto_bands(fused440_ok, fused440_lds);
 
 	for (size_t i = 0; i < n; ++i) {
 		Slot &s = b->slots[i];
@@ -805,6 +826,15 @@ extern "C" int mij_batch_upload(mij_batch *b)
 			const int nb = (d.mcu_y + 7) / 8;
 			for (int k = 0; k < nb; ++k)
 				lists[MK_422][o4][wide][b8].push_back(Work4{(uint32_t)i, (uint32_t)((long)d.mcu_y * k / nb), (uint32_t)((long)d.mcu_y * (k + 1) / nb), 0u});
+		} else if (fused440_ok(b, d)) {
+			s.path = 6;
+			size_t &l = lds_need[MK_440][o4][wide][b8];
+			l = fused440_lds(d) > l ? fused440_lds(d) : l;
+			/* band count by rounds of co-resident workgroups, as for 4:2:0 */
+			int nb = b->band_rows > 0 ? (d.mcu_y + b->band_rows - 1) / b->band_rows : auto_nb440;
+			nb = nb > d.mcu_y ? d.mcu_y : (nb < 1 ? 1 : nb);
+			for (int k = 0; k < nb; ++k)
+				lists[MK_440][o4][wide][b8].push_back(Work4{(uint32_t)i, (uint32_t)((long)d.mcu_y * k / nb), (uint32_t)((long)d.mcu_y * (k + 1) / nb), 0u});
 		} else if (fused444_ok(b, d)) {
 			s.path = 3;
 			per_blocks(lists[MK_444][o4][wide][b8], 0);
@@ -959,7 +989,7 @@ extern "C" int mij_batch_launch(mij_batch *b)
 		return set_err(MIJ_E_STATE, "mij_batch_launch before mij_batch_upload");
 	HIP_TRY(hipSetDevice(b->ctx->device));
 	for (const auto &L : b->launches) { /* in family order: pass 2 of the two-pass family runs behind every pass-1 launch */
-		const dim3 grid((unsigned)L.count), block(L.kind == MK_420 ? MIJ_F420_NT : 256);
+		const dim3 grid((unsigned)L.count), block((L.kind == MK_420 || L.kind == MK_440) ? MIJ_F420_NT : 256);
 		const Work4 *wk = b->d_work + L.first;
 		switch (L.kind) {
 		case MK_420:
@@ -967,6 +997,9 @@ extern "C" int mij_batch_launch(mij_batch *b)
 			break;
 		case MK_422:
 			MIJ_LAUNCH_NWB(k_fused422, WorkBand, MIJ_COEF_OUT);
+			break;
+		case MK_440:
+			MIJ_LAUNCH_NWB(k_fused440, WorkBand, MIJ_COEF_OUT);
 			break;
 		case MK_444:
 			MIJ_LAUNCH_NWB(k_fused444, WorkIdct, MIJ_COEF_OUT);

@@ -214,7 +214,7 @@ int mij_batch_hash_out(mij_batch *b, int slot, uint64_t *hash);
 int mij_batch_diff_slots(mij_batch *b, const int *sa, const int *sb, int n, uint64_t *ndiff);
 
 /* which kernel family the last upload chose for a slot: 0 none (skipped), 1 fused 4:2:0, 2 generic two-pass,
- * 3 fused 4:4:4, 4 fused 4:2:2, 5 fused grey */
+ * 3 fused 4:4:4, 4 fused 4:2:2, 5 fused grey, 6 fused 4:4:0 */
 int mij_batch_slot_path(const mij_batch *b, int slot);
 /* parity tests compare the kernel families: on = 1 sends every image of the batch down the two-pass path (IDCT to sample
  * planes, then resampling + colour; its pass 2 compiled per resampler where the layout allows), on = 2 also insists on

@@ -439,3 +439,34 @@ def test_two_pass_layouts_specialised_and_general_pass2(ica, oracle, gpu_ctx):
     for i, s in enumerate(slots):
         assert np.array_equal(b.fetch(s), oracle.load(datas[i], 3)[1]), i
     b.close()
+
+
+def test_fused_440_kernel_vs_oracle_and_two_pass(ica, oracle, gpu_ctx, monkeypatch):
+    """h1v2 (4:4:0) streams through the band kernel's H2 = false form (k_fused440: vertical filter only, codec/jpeg.c:1774-1782) and
+    through both pass-2 forms of the two-pass family: all equal to the oracle -- odd widths and heights, one-MCU images, every band
+    height (1 / 2 / 3 MCU rows per workgroup / whole image: halo rows, saved rows, the last odd row), 3 and 4 output channels."""
+    datas = []
+    for i, (w, h) in enumerate(((8, 16), (9, 17), (1, 1), (2, 2), (4, 4), (33, 7), (64, 64), (250, 131), (640, 480), (1920, 1080), (36, 20), (18, 40), (52, 33))):
+        plan, du = ica.host_transform(ica.synth_rgb(w, h, 60 + i), 93)
+        datas.append(helpers.baseline_layout_from_444(plan, du, [(1, 2), (1, 1), (1, 1)], -1, restart_mcus=(5 if i % 4 == 1 else 0)))
+    for req in (3, 4):
+        wants = [oracle.load(d, req)[1] for d in datas]
+        for generic in (0, 1, 2):
+            b, slots = _batch_for(ica, gpu_ctx, datas, req)
+            b.force_generic(generic)
+            b.submit()
+            for s, want in zip(slots, wants):
+                assert b.slot_path(s) == (2 if generic else 6)
+                got = b.fetch(s)
+                assert np.array_equal(got, want), (s, req, generic, want.shape, int((got != want).sum()))
+            b.close()
+    wants = [oracle.load(d, 3)[1] for d in datas]
+    for rows in ("1", "2", "3", "1000"):
+        monkeypatch.setenv("MIJ_BAND_ROWS", rows)
+        b, slots = _batch_for(ica, gpu_ctx, datas, 3)
+        b.submit()
+        b.wait()
+        for s, want in zip(slots, wants):
+            assert b.slot_path(s) == 6
+            assert np.array_equal(b.fetch(s), want), (rows, s)
+        b.close()

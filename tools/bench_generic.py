@@ -55,6 +55,8 @@ def main():
     for name, hv, app14 in (("440", [(1, 2), (1, 1), (1, 1)], -1), ("411", [(4, 1), (1, 1), (1, 1)], -1), ("cmyk", [(1, 1)] * 4, 0), ("ycck_420", [(2, 2), (1, 1), (1, 1), (2, 2)], 2)):
         data = helpers.baseline_layout_from_444(plan, du, hv, app14)
         want = oracle.load(data, 3)[1]
+        if name == "440":
+            out["440_fused"] = run(ctx, data, n, 0, want)
         out[name + "_specialised"] = run(ctx, data, n, 1, want)
         out[name + "_general"] = run(ctx, data, n, 2, want)
     print(json.dumps(out))
