@@ -529,10 +529,14 @@ def end_to_end(ica, ctx, datas, distinct, n_img, src_hash, cbytes, obytes, args)
         # per CU), so several walks in flight on their own streams is what fills the GPU, and the host parses the next
         # headers meanwhile
 
+        gpins = []  # filled for the D2H variant below: one pinned buffer per ring batch
+
         def finish(side, pjob, plo, plen):
             ok, slots, reasons = ebs[side].decode_jpegs_gpu_end(pjob)
             assert ok == plen, reasons
             ebs[side].submit()
+            if gpins:
+                ebs[side].fetch_all_async(gpins[side].ptr, gpins[side].nbytes)
             last[side] = (plo + plen - 1, slots[plen - 1])
 
         def one_pass():
@@ -561,6 +565,17 @@ def end_to_end(ica, ctx, datas, distinct, n_img, src_hash, cbytes, obytes, args)
         e2e["gpu_entropy_chunk_images"] = gchunk
         e2e["gpu_entropy_batches_in_flight"] = depth
         e2e["gpu_entropy_passes_mpix_s"] = [round(n_g * W * H / t / 1e6, 1) for t in passes]
+        # the same ring with every chunk's pixels copied to pinned host memory behind its kernels (3 B/px over PCIe: the
+        # link, not the GPU, sets this figure)
+        gpins.extend(ica.PinnedBuffer(obytes * gchunk) for _ in range(depth))
+        t_gd = sorted(one_pass() for _ in range(3))[1]
+        for side, (img, slot) in last.items():
+            off = ebs[side].out_offset(slot)
+            assert np.array_equal(gpins[side].array[off:off + W * H * 3], ebs[side].fetch(slot).reshape(-1)), "D2H copy of a GPU-walked image differs"
+        e2e["value_gpu_entropy_with_d2h"] = round(n_g * W * H / t_gd / 1e6, 1)
+        e2e["d2h_gb_s"] = round(n_g * W * H * 3 / t_gd / 1e9, 1)
+        for pb in gpins:
+            pb.close()
     except ica.MijError as exc:
         e2e["value_gpu_entropy"] = None
         e2e["gpu_entropy_error"] = str(exc)
