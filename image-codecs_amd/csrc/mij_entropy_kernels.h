@@ -132,11 +132,35 @@ struct EsTab {
 	__attribute__((aligned(16))) int32_t delta[8];
 };
 
+/* The passes that only track the decoder's state (k_es_cold, k_es_sync) do not need coefficient values: what an AC symbol
+ * does to the state is "so many bits, so many positions, or end of block".  For the two AC tables a scan normally uses, a
+ * second table indexed by the next MIJ_ES_PAIR_BITS bits of the stream folds TWO consecutive AC symbols (code + extra bits of the
+ * first, code + extra bits of the second) into one 16-bit entry whenever both lie inside the window -- at the benchmark's
+ * 1.8 bit/px that is most pairs -- so the serial chain lookup -> shift -> lookup runs half as often:
+ *   0                          no entry (long code, or the first symbol alone leaves the window): the ordinary path
+ *   bit 15 clear               one symbol:  bits [0:4) = code + extra bits, [4:11) = positions (64 = EOB)
+ *   bit 15 set                 two symbols: bits [0:4) = bits of both, [4:9) = positions of the first, [9:14) of the second,
+ *                              bit 14 = the second is an EOB
+ * A pair is only taken when the first symbol leaves the block open and the second starts before the subsequence ends, i.e.
+ * exactly when the one-symbol loop would decode both: the hand-over states between subsequences do not change. */
+#define MIJ_ES_PAIR_BITS 12u
+#ifndef MIJ_ES_PAIR /* A/B switch: 0 = the state-only passes decode one symbol per iteration like the write pass */
+#define MIJ_ES_PAIR 1
+#endif
+struct EsPair {
+	uint16_t t2[2][1u << MIJ_ES_PAIR_BITS];
+	uint8_t slot[8]; /* table index 0..7 -> 0 / 1 (its pair table) or 255 (none: a DC table, or a third AC table) */
+};
+
 /* codec/jpeg.c:193-243: returns the symbol and its code length, or -1 */
+__device__ __forceinline__ int es_symbol_e(const EsTab &h, uint64_t win, uint32_t e, uint32_t &len); /* the same with the fast-table entry already fetched */
 __device__ __forceinline__ int es_symbol(const EsTab &h, uint64_t win, uint32_t &len)
 {
+	return es_symbol_e(h, win, h.fast16[(uint32_t)(win >> 55)], len);
+}
+__device__ __forceinline__ int es_symbol_e(const EsTab &h, uint64_t win, uint32_t e, uint32_t &len)
+{
 	const uint32_t top16 = (uint32_t)(win >> 48);
-	const uint32_t e = h.fast16[top16 >> 7];
 	if (e != 0xffffu) {
 		len = e >> 8;
 		return (int)(e & 255u);
@@ -281,15 +305,21 @@ struct EsWriter { /* where the blocks of the write pass go */
  * WRITE = false: only the state and the number of completed blocks.  WRITE = true: coefficients are stored,
  * decoding stops at block ordinal sc.nblocks, malformed input sets *anom.
  */
-template <bool WRITE>
+template <bool WRITE, bool PAIR = false>
 __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &loc, const EsTab *__restrict__ tabs, const uint8_t *__restrict__ stream, EsState &s,
-															 uint32_t p_end, EsWriter *wr, uint32_t *anom)
+															 uint32_t p_end, EsWriter *wr, uint32_t *anom, const EsPair *__restrict__ pr = nullptr)
 {
+	static_assert(!(WRITE && PAIR), "the pair table only serves the state-only passes");
 	uint32_t done = 0, guard = 0;
 	const uint32_t limit = sc.nbits + 64u; /* the arena is zero padded: never read far past the data */
 	EsBits br;
 	br.start(stream, s.p);
 	uint32_t tb = loc.tabs[s.c]; /* the current block's component and tables; changes with s.c only */
+	const uint16_t *t2cur = nullptr; /* the pair table of the block's AC table (state-only passes), off the per-symbol chain */
+	if (PAIR) {
+		const uint32_t slot = pr->slot[tb >> 16];
+		t2cur = slot < 2u ? pr->t2[slot] : nullptr;
+	}
 	/* ONE symbol per iteration whatever it is: the lanes of a wave sit at DC terms, AC runs and block ends all the time,
 	 * so a loop with a DC branch and an AC branch executes both on almost every iteration (each at a fraction of the
 	 * lanes).  Here the table is chosen by data and the state update is a handful of selects. */
@@ -302,8 +332,46 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &
 			break;
 		const uint64_t win = br.win;
 		const bool isdc = s.z == 0;
+		bool paired = false;
+		/* both lookups leave together (one LDS round trip on the serial chain, not two): the ordinary fast-table entry of the
+		 * table this symbol uses, and -- state-only passes -- the pair entry of the block's AC table */
+		const EsTab &htab = tabs[isdc ? (tb >> 8) & 255u : tb >> 16];
+		const uint32_t e9 = htab.fast16[(uint32_t)(win >> 55)];
+		if (PAIR) {
+			/* State-only pass: what this iteration consumes (bits) and where it leaves the block (znew) come out of selects over the
+			 * three sources -- pair entry, one-symbol entry, ordinary fast-table entry -- and ONE window update follows; only a code
+			 * longer than nine bits or a non-code leaves this path (the ordinary code below).  The lanes of a wave sit in all three
+			 * cases all the time, so three branches would each run on every iteration. */
+			const uint32_t e = (t2cur && !isdc) ? t2cur[(uint32_t)(win >> (64u - MIJ_ES_PAIR_BITS))] : 0u;
+			const uint32_t a1 = (e >> 4) & 31u;
+			const bool two = (e & 0x8000u) && s.z + a1 < 64u && s.p + (e & 15u) <= p_end;
+			const bool one = e && !(e & 0x8000u);
+			uint32_t len9 = e9 >> 8, sym9 = e9 & 255u;
+			bool fast = e9 != 0xffffu;
+			if (!two && !one && !fast) { /* a code longer than nine bits outside the pair table: the reference's slow path, then the same update */
+				const int sl = es_symbol_e(htab, win, e9, len9);
+				sym9 = (uint32_t)sl & 255u;
+				fast = sl >= 0;
+			}
+			const uint32_t n9 = isdc ? sym9 : (sym9 & 15u), r9 = sym9 >> 4;
+			fast = fast && len9 && !(isdc && sym9 > 11u);
+			if (two || one || fast) {
+				const uint32_t z9 = isdc ? 1u : (n9 ? s.z + r9 + 1u : (r9 == 15u ? s.z + 16u : 64u));
+				const uint32_t bits = two ? (e & 15u) : (one ? (e & 15u) : len9 + n9);
+				const uint32_t znew = two ? ((e & 0x4000u) ? 64u : s.z + a1 + ((e >> 9) & 31u)) : (one ? s.z + ((e >> 4) & 127u) : z9);
+				s.p += bits;
+				br.take(bits);
+				s.z = znew;
+				paired = true;
+			} else { /* a guessed start ran into a non-code: slip one bit and keep looking for the true sequence */
+				s.p += 1;
+				br.take(1);
+				continue;
+			}
+		}
+		if (!PAIR && !paired) {
 		uint32_t len = 0;
-		const int sym = es_symbol(tabs[isdc ? (tb >> 8) & 255u : tb >> 16], win, len);
+		const int sym = es_symbol_e(htab, win, e9, len);
 		/* DC: the reference takes categories up to 16; nothing a conforming stream uses beyond 11 */
 		if (sym < 0 || len == 0 || (isdc && sym > 11)) {
 			if (!WRITE) { /* a guessed start ran into a non-code: slip one bit and keep looking for the true sequence */
@@ -344,6 +412,7 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &
 				s.z = k + 1;
 			}
 		}
+		} /* !paired */
 		if (s.z >= 64u) { /* block complete (ZRL past the end ends it too: same as the host loop's k < 64 test) */
 			s.z = 0;
 			++done;
@@ -372,6 +441,10 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &
 				}
 			}
 			tb = loc.tabs[s.c];
+			if (PAIR) {
+				const uint32_t slot = pr->slot[tb >> 16];
+				t2cur = slot < 2u ? pr->t2[slot] : nullptr;
+			}
 			if (WRITE && !sc.fmt && wr->ord < sc.nblocks)
 				wr->locate(s.c);
 		}
@@ -391,7 +464,7 @@ struct EsWork {
 };
 
 /* the scan's eight Huffman tables and its EsLocal into LDS (im == nullptr: no block placement needed); ends in a barrier */
-__device__ __forceinline__ void es_load_tables(const DevScan &sc, const DevImage *im, const DevHuff *__restrict__ g, EsTab *l, EsLocal *loc)
+__device__ __forceinline__ void es_load_tables(const DevScan &sc, const DevImage *im, const DevHuff *__restrict__ g, EsTab *l, EsLocal *loc, EsPair *pr = nullptr)
 {
 	for (uint32_t i = threadIdx.x; i < 8u * 512u; i += blockDim.x) {
 		const DevHuff &h = g[i >> 9];
@@ -418,6 +491,45 @@ __device__ __forceinline__ void es_load_tables(const DevScan &sc, const DevImage
 	}
 	loc->qz[threadIdx.x >> 6][threadIdx.x & 63u] = sc.qz[threadIdx.x >> 6][threadIdx.x & 63u];
 	__syncthreads();
+	if (pr) {
+		/* the (at most two) AC tables of the scan's components, in order of first use; a third one keeps the ordinary path */
+		uint32_t used[2] = {255u, 255u}, nused = 0;
+		for (uint32_t c = 0; c < 4u; ++c) {
+			const uint32_t t = sc.ac_tab[c] & 7u;
+			if (t != used[0] && t != used[1] && nused < 2u)
+				used[nused++] = t;
+		}
+		if (threadIdx.x < 8u)
+			pr->slot[threadIdx.x] = threadIdx.x == used[0] ? 0 : (threadIdx.x == used[1] ? 1 : 255);
+		for (uint32_t i = threadIdx.x; i < 2u << MIJ_ES_PAIR_BITS; i += blockDim.x) {
+			const uint32_t k = i >> MIJ_ES_PAIR_BITS, w = i & ((1u << MIJ_ES_PAIR_BITS) - 1u);
+			uint32_t e = 0;
+			if (used[k] != 255u) {
+				/* full decode (long codes included) of the window padded with zeros: a symbol counts only if its code and its
+				 * extra bits lie inside the bits the window really holds */
+				const EsTab &h = l[used[k]];
+				uint32_t len1 = 0;
+				const int s1 = es_symbol(h, (uint64_t)w << (64u - MIJ_ES_PAIR_BITS), len1);
+				const uint32_t n1 = (uint32_t)s1 & 15u, r1 = ((uint32_t)s1 >> 4) & 15u, bits1 = len1 + n1;
+				if (s1 >= 0 && len1 && bits1 <= MIJ_ES_PAIR_BITS) {
+					const uint32_t adv1 = n1 ? r1 + 1u : (r1 == 15u ? 16u : 64u);
+					e = bits1 | adv1 << 4;
+					const uint32_t rem = MIJ_ES_PAIR_BITS - bits1;
+					if (adv1 != 64u && rem) {
+						uint32_t len2 = 0;
+						const int s2 = es_symbol(h, (uint64_t)w << (64u - MIJ_ES_PAIR_BITS + bits1), len2);
+						const uint32_t n2 = (uint32_t)s2 & 15u, r2 = ((uint32_t)s2 >> 4) & 15u;
+						if (s2 >= 0 && len2 && len2 + n2 <= rem) {
+							const uint32_t eob2 = (!n2 && r2 != 15u) ? 1u : 0u, adv2 = eob2 ? 0u : (n2 ? r2 + 1u : 16u);
+							e = 0x8000u | (bits1 + len2 + n2) | adv1 << 4 | adv2 << 9 | eob2 << 14;
+						}
+					}
+				}
+			}
+			pr->t2[k][w] = (uint16_t)e;
+		}
+		__syncthreads();
+	}
 }
 
 __global__ __launch_bounds__(256) void k_es_cold(const DevScan *__restrict__ scans, const EsWork *__restrict__ work, const DevHuff *__restrict__ huff,
@@ -425,9 +537,10 @@ __global__ __launch_bounds__(256) void k_es_cold(const DevScan *__restrict__ sca
 {
 	__shared__ EsTab tabs[8];
 	__shared__ EsLocal loc;
+	__shared__ EsPair pair;
 	const EsWork wk = work[blockIdx.x];
 	const DevScan &sc = scans[wk.scan];
-	es_load_tables(sc, nullptr, huff + sc.tab_off, tabs, &loc);
+	es_load_tables(sc, nullptr, huff + sc.tab_off, tabs, &loc, MIJ_ES_PAIR ? &pair : nullptr);
 	const uint32_t i = wk.first + threadIdx.x;
 	if (i >= sc.nsub)
 		return;
@@ -437,7 +550,7 @@ __global__ __launch_bounds__(256) void k_es_cold(const DevScan *__restrict__ sca
 	s.c = 0;
 	start[sc.sub_off + i] = es_pack(s);
 	const uint32_t pe = min((i + 1u) * sc.sub_bits, sc.nbits);
-	cnt[sc.sub_off + i] = es_decode<false>(sc, loc, tabs, streams + sc.stream_off, s, pe, nullptr, nullptr);
+	cnt[sc.sub_off + i] = es_decode<false, MIJ_ES_PAIR != 0>(sc, loc, tabs, streams + sc.stream_off, s, pe, nullptr, nullptr, &pair);
 	end[sc.sub_off + i] = es_pack(s);
 }
 
@@ -448,6 +561,7 @@ __global__ __launch_bounds__(256) void k_es_sync(const DevScan *__restrict__ sca
 {
 	__shared__ EsTab tabs[8];
 	__shared__ EsLocal loc;
+	__shared__ EsPair pair;
 	const EsWork wk = work[blockIdx.x];
 	const DevScan &sc = scans[wk.scan];
 	const uint32_t i = wk.first + threadIdx.x;
@@ -466,13 +580,13 @@ __global__ __launch_bounds__(256) void k_es_sync(const DevScan *__restrict__ sca
 	}
 	if (!__syncthreads_or(redo ? 1 : 0))
 		return;
-	es_load_tables(sc, nullptr, huff + sc.tab_off, tabs, &loc);
+	es_load_tables(sc, nullptr, huff + sc.tab_off, tabs, &loc, MIJ_ES_PAIR ? &pair : nullptr);
 	if (!redo)
 		return;
 	start[slot] = want;
 	EsState s = es_unpack(want);
 	const uint32_t pe = min((i + 1u) * sc.sub_bits, sc.nbits);
-	cnt[slot] = es_decode<false>(sc, loc, tabs, streams + sc.stream_off, s, pe, nullptr, nullptr);
+	cnt[slot] = es_decode<false, MIJ_ES_PAIR != 0>(sc, loc, tabs, streams + sc.stream_off, s, pe, nullptr, nullptr, &pair);
 	end_out[slot] = es_pack(s);
 	atomicAdd(&changed[wk.scan], 1u);
 }
