@@ -305,18 +305,18 @@ struct EsWriter { /* where the blocks of the write pass go */
  * WRITE = false: only the state and the number of completed blocks.  WRITE = true: coefficients are stored,
  * decoding stops at block ordinal sc.nblocks, malformed input sets *anom.
  */
-template <bool WRITE, bool PAIR = false>
+template <bool WRITE, bool PAIR = false, bool PAIRW = false>
 __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &loc, const EsTab *__restrict__ tabs, const uint8_t *__restrict__ stream, EsState &s,
 															 uint32_t p_end, EsWriter *wr, uint32_t *anom, const EsPair *__restrict__ pr = nullptr)
 {
-	static_assert(!(WRITE && PAIR), "the pair table only serves the state-only passes");
+	static_assert(!(WRITE && PAIR) && !(PAIRW && !WRITE), "PAIR: the state-only passes' pair table; PAIRW: the write pass's");
 	uint32_t done = 0, guard = 0;
 	const uint32_t limit = sc.nbits + 64u; /* the arena is zero padded: never read far past the data */
 	EsBits br;
 	br.start(stream, s.p);
 	uint32_t tb = loc.tabs[s.c]; /* the current block's component and tables; changes with s.c only */
 	const uint16_t *t2cur = nullptr; /* the pair table of the block's AC table (state-only passes), off the per-symbol chain */
-	if (PAIR) {
+	if (PAIR || PAIRW) {
 		const uint32_t slot = pr->slot[tb >> 16];
 		t2cur = slot < 2u ? pr->t2[slot] : nullptr;
 	}
@@ -337,6 +337,7 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &
 		 * table this symbol uses, and -- state-only passes -- the pair entry of the block's AC table */
 		const EsTab &htab = tabs[isdc ? (tb >> 8) & 255u : tb >> 16];
 		const uint32_t e9 = htab.fast16[(uint32_t)(win >> 55)];
+		const uint32_t e2w = (PAIRW && t2cur && !isdc) ? t2cur[(uint32_t)(win >> (64u - MIJ_ES_PAIR_BITS))] : 0u;
 		if (PAIR) {
 			/* State-only pass: what this iteration consumes (bits) and where it leaves the block (znew) come out of selects over the
 			 * three sources -- pair entry, one-symbol entry, ordinary fast-table entry -- and ONE window update follows; only a code
@@ -412,6 +413,33 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &
 				s.z = k + 1;
 			}
 		}
+		/* Write pass: the second AC symbol of the pair the window started with, when the first one left the block open and the
+		 * second starts inside this subsequence -- the same symbol the next iteration would decode, without its lookup, its
+		 * checks and its trip round the loop. */
+		if (PAIRW && e2w && s.z < 64u && s.p < p_end) {
+			const uint32_t len2 = e2w >> 12, n2 = (e2w >> 4) & 15u, r2 = (e2w >> 8) & 15u;
+			const int v2 = n2 ? es_extend(br.win, len2, n2) : 0;
+			s.p += len2 + n2;
+			br.take(len2 + n2);
+			if (n2 == 0) {
+				s.z = r2 == 15u ? s.z + 16u : 64u;
+			} else {
+				const uint32_t k2 = s.z + r2;
+				if (k2 > 63u) {
+					atomicOr(anom, 1u);
+					s.z = 64;
+				} else {
+					if (!wr->skip) {
+						wr->put(k2, v2, s.c);
+						if (!sc.fmt) {
+							const int dq = (int)(int16_t)((uint32_t)v2 * loc.qz[tb & 255u][k2]);
+							wr->acc += (uint32_t)(dq < 0 ? -dq : dq);
+						}
+					}
+					s.z = k2 + 1;
+				}
+			}
+		}
 		} /* !paired */
 		if (s.z >= 64u) { /* block complete (ZRL past the end ends it too: same as the host loop's k < 64 test) */
 			s.z = 0;
@@ -441,7 +469,7 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &
 				}
 			}
 			tb = loc.tabs[s.c];
-			if (PAIR) {
+			if (PAIR || PAIRW) {
 				const uint32_t slot = pr->slot[tb >> 16];
 				t2cur = slot < 2u ? pr->t2[slot] : nullptr;
 			}
@@ -464,7 +492,10 @@ struct EsWork {
 };
 
 /* the scan's eight Huffman tables and its EsLocal into LDS (im == nullptr: no block placement needed); ends in a barrier */
-__device__ __forceinline__ void es_load_tables(const DevScan &sc, const DevImage *im, const DevHuff *__restrict__ g, EsTab *l, EsLocal *loc, EsPair *pr = nullptr)
+/* pr != nullptr: also the pair tables (EsPair); for_write: in the write pass's format -- the SECOND symbol behind the one the
+ * window starts with, as code length << 12 | symbol << 4 | bits of the first symbol (0: no second symbol inside the window) */
+__device__ __forceinline__ void es_load_tables(const DevScan &sc, const DevImage *im, const DevHuff *__restrict__ g, EsTab *l, EsLocal *loc, EsPair *pr = nullptr,
+																bool for_write = false)
 {
 	for (uint32_t i = threadIdx.x; i < 8u * 512u; i += blockDim.x) {
 		const DevHuff &h = g[i >> 9];
@@ -513,7 +544,7 @@ __device__ __forceinline__ void es_load_tables(const DevScan &sc, const DevImage
 				const uint32_t n1 = (uint32_t)s1 & 15u, r1 = ((uint32_t)s1 >> 4) & 15u, bits1 = len1 + n1;
 				if (s1 >= 0 && len1 && bits1 <= MIJ_ES_PAIR_BITS) {
 					const uint32_t adv1 = n1 ? r1 + 1u : (r1 == 15u ? 16u : 64u);
-					e = bits1 | adv1 << 4;
+					e = for_write ? 0u : (bits1 | adv1 << 4);
 					const uint32_t rem = MIJ_ES_PAIR_BITS - bits1;
 					if (adv1 != 64u && rem) {
 						uint32_t len2 = 0;
@@ -521,7 +552,7 @@ __device__ __forceinline__ void es_load_tables(const DevScan &sc, const DevImage
 						const uint32_t n2 = (uint32_t)s2 & 15u, r2 = ((uint32_t)s2 >> 4) & 15u;
 						if (s2 >= 0 && len2 && len2 + n2 <= rem) {
 							const uint32_t eob2 = (!n2 && r2 != 15u) ? 1u : 0u, adv2 = eob2 ? 0u : (n2 ? r2 + 1u : 16u);
-							e = 0x8000u | (bits1 + len2 + n2) | adv1 << 4 | adv2 << 9 | eob2 << 14;
+							e = for_write ? (len2 << 12 | ((uint32_t)s2 & 255u) << 4 | bits1) : (0x8000u | (bits1 + len2 + n2) | adv1 << 4 | adv2 << 9 | eob2 << 14);
 						}
 					}
 				}
@@ -631,6 +662,7 @@ __global__ __launch_bounds__(256) void k_es_write(const DevScan *__restrict__ sc
 {
 	__shared__ EsTab tabs[8];
 	__shared__ EsLocal loc;
+	__shared__ EsPair pair;
 	__shared__ uint8_t zpos[64];
 	__shared__ uint16_t toff[64];
 	const EsWork wk = work[blockIdx.x];
@@ -640,7 +672,7 @@ __global__ __launch_bounds__(256) void k_es_write(const DevScan *__restrict__ sc
 		zpos[threadIdx.x] = (uint8_t)P;
 		toff[threadIdx.x] = (uint16_t)(((P >> 3) << 9) + (P & 7u));
 	}
-	es_load_tables(sc, &imgs[sc.img], huff + sc.tab_off, tabs, &loc);
+	es_load_tables(sc, &imgs[sc.img], huff + sc.tab_off, tabs, &loc, MIJ_ES_PAIR ? &pair : nullptr, true);
 	const uint32_t i = wk.first + threadIdx.x;
 	if (i >= sc.nsub)
 		return;
@@ -680,7 +712,7 @@ __global__ __launch_bounds__(256) void k_es_write(const DevScan *__restrict__ sc
 		wr.locate(s.c);
 	}
 	const uint32_t pe = min((i + 1u) * sc.sub_bits, sc.nbits);
-	es_decode<true>(sc, loc, tabs, streams + sc.stream_off, s, pe, &wr, &anom[wk.scan]);
+	es_decode<true, false, MIJ_ES_PAIR != 0>(sc, loc, tabs, streams + sc.stream_off, s, pe, &wr, &anom[wk.scan], &pair);
 }
 
 /* the rest of every block that began in the previous subsequence: single coefficients into the block that the
