@@ -335,7 +335,14 @@ def leg_config5(ica, ctx, args, checker, quality=90, count=None):
             mine = ica.emit_jpeg(enc.plan(src[k]), enc.fetch(src[k]))
             buf = np.zeros(W * H * 3, np.uint8)
             nb = fenc(buf.ctypes.data, buf.size, W, H, 3, np.ascontiguousarray(im).ctypes.data, quality)
-            assert nb > 0 and mine == bytes(buf[:nb]), "encoded stream %d differs from the CPU checker's" % k
+            if not (nb > 0 and mine == bytes(buf[:nb])):
+                # say which side moved: the GPU's data units against the library's own host transform, and the checker against itself
+                host_units = ica.host_transform(im, quality)[1]
+                gpu_ok = bool(np.array_equal(enc.fetch(src[k]), host_units))
+                buf2 = np.zeros(W * H * 3, np.uint8)
+                nb2 = fenc(buf2.ctypes.data, buf2.size, W, H, 3, np.ascontiguousarray(im).ctypes.data, quality)
+                raise AssertionError("encoded stream %d differs from the CPU checker's (checker bytes %d, ours %d; GPU data units == host transform: %s; "
+                                     "checker repeatable: %s)" % (k, nb, len(mine), gpu_ok, nb2 == nb and bytes(buf2[:max(nb2, 0)]) == bytes(buf[:max(nb, 0)])))
         assert np.array_equal(enc.fetch(n - 1), enc.fetch(src[(n - 1) % distinct]))
         n_warm = 0
         t_w = time.perf_counter()
@@ -425,19 +432,22 @@ def leg_config1(ica, checker):
 
 def leg_two_pass(ica, ctx, datas, args, checker):
     """The two-pass family (k_idct_planes, then k_resample_fast compiled per resampler) on 256 x 1080p: the headline 4:2:0
-    images forced off the fused kernel, and two layouts that only have this path (4:4:0, Adobe CMYK).  ms = both passes of
+    images forced off the fused kernel, 4:4:0 (default choice: the fused k_fused440; and forced onto the two-pass family) and
+    Adobe CMYK, which only has this path.  ms = both passes of
     one launch; algorithmic bytes as for the fused kernels (2 B x coefficients + 3 x W x H)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import helpers
     n = 256
     plan, du = ica.host_transform(ica.synth_rgb(W, H, 2), 92)
-    cases = (("h2v2_forced", datas[0], 1), ("h1v2_440", helpers.baseline_layout_from_444(plan, du, [(1, 2), (1, 1), (1, 1)], -1), 0),
-             ("cmyk_adobe", helpers.baseline_layout_from_444(plan, du, [(1, 1)] * 4, 0), 0))
-    out = {"images": n, "kernels": "mij::k_idct_planes<false,true> + mij::k_resample_fast<RS_HV2 | RS_V2 | RS_ROW1, ...>", "parity_against": checker[1]}
-    for name, data, generic in cases:
+    d440 = helpers.baseline_layout_from_444(plan, du, [(1, 2), (1, 1), (1, 1)], -1)
+    cases = (("h2v2_forced", datas[0], 1, 2), ("h1v2_440", d440, 0, 6), ("h1v2_440_forced", d440, 1, 2),
+             ("cmyk_adobe", helpers.baseline_layout_from_444(plan, du, [(1, 1)] * 4, 0), 0, 2))
+    out = {"images": n, "kernels": "mij::k_idct_planes<false,true> + mij::k_resample_fast<RS_HV2 | RS_V2 | RS_ROW1, ...>; h1v2_440 (default choice): mij::k_fused440<3,false,true>",
+           "parity_against": checker[1]}
+    for name, data, generic, path in cases:
         d = ica.HostDecoder.probe(data, 3)
         cb, ob = ica.Batch.coef_bytes(d), ica.Batch.out_bytes(d)
-        res, _ = leg_decode_1080p(ica, ctx, [data], n, "compact", cb, ob, args, expect_path=2, checker=checker, generic=generic)
+        res, _ = leg_decode_1080p(ica, ctx, [data], n, "compact", cb, ob, args, expect_path=path, checker=checker, generic=generic)
         algo = n * (128 * sum(d.comp[c].bw * d.comp[c].bh for c in range(d.ncomp)) + 3 * W * H)
         ms = res["kernel_ms_per_launch"]
         out[name] = {"ms_per_launch": round(ms, 4), "mpix_s": round(n * W * H / ms / 1e3, 1), "algorithmic_bytes_per_launch": algo,

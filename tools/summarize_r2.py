@@ -35,6 +35,9 @@ LEGS = [  # (traffic key, kernel substring, which dispatches, algorithmic bytes,
     ("k_fused444_compact_32", "k_fused444<3, false, true>", "last", legs.get("config4", {}).get("algorithmic_bytes_per_launch"), legs.get("config4", {}).get("kernel_ms_per_launch")),
     ("k_encode420_%d" % n_main, "k_encode420", "last", legs.get("config5", {}).get("algorithmic_bytes_per_launch"), legs.get("config5", {}).get("kernel_ms_per_launch")),
     ("k_fused422_compact_512", "k_fused422<3, false, true>", "last", legs.get("h2v1", {}).get("algorithmic_bytes_per_launch"), legs.get("h2v1", {}).get("kernel_ms_per_launch")),
+    ("k_encode444_512", "k_encode444", "last", legs.get("config5_q95_444", {}).get("algorithmic_bytes_per_launch"), legs.get("config5_q95_444", {}).get("kernel_ms_per_launch")),
+    ("k_fused440_compact_256", "k_fused440<3, false, true>", "last", legs.get("two_pass", {}).get("h1v2_440", {}).get("algorithmic_bytes_per_launch"),
+     legs.get("two_pass", {}).get("h1v2_440", {}).get("ms_per_launch")),
 ]
 
 
@@ -102,7 +105,7 @@ for key, kern, which, algo, bms in LEGS:
 json.dump(tj, open(tpath, "w"), indent=1)
 lines.append("")
 lines += ["## 3. issue counters of the timed launches (mean per launch)", "", "| leg | SQ_INSTS_VALU | lane-ops / px | SQ_WAVE_CYCLES | SQ_BUSY_CYCLES | SQ_WAIT_ANY / SQ_WAVE_CYCLES | SQ_INSTS_LDS |", "|---|---|---|---|---|---|---|"]
-px = {"k_fused444_compact_32": 32 * 4096 * 4096, "k_fused422_compact_512": 512 * 1920 * 1080}
+px = {"k_fused444_compact_32": 32 * 4096 * 4096, "k_fused422_compact_512": 512 * 1920 * 1080, "k_encode444_512": 512 * 1920 * 1080, "k_fused440_compact_256": 256 * 1920 * 1080}
 for key, kern, which, algo, bms in LEGS:
     v = {c: leg_counter(sq, kern, which, c) for c in ("SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_LDS")}
     if v["SQ_INSTS_VALU"] is None:
