@@ -521,10 +521,11 @@ def end_to_end(ica, ctx, datas, distinct, n_img, src_hash, cbytes, obytes, args)
     try:
         for eb in ebs:
             eb.close()
-        n_g = max(2048, 4 * n_e)  # this leg is fast: enough chunks for the pipeline to reach its steady state (the images cycle)
+        n_g = max(4096, 8 * n_e)  # this leg is fast: enough chunks for the pipeline to reach its steady state (the images cycle)
         jg = [datas[i % distinct] for i in range(n_g)]
         depth = max(2, int(os.environ.get("MIJ_BENCH_GPU_DEPTH", "4")))  # batches in the ring = walks in flight
-        gchunk = max(1, min(int(os.environ.get("MIJ_BENCH_GPU_CHUNK", "128")), n_g // depth))
+        # chunks of 256 pictures, four batches: measured against 128 / 512 and three / six batches (tools/bench_gpu_walk.py)
+        gchunk = max(1, min(int(os.environ.get("MIJ_BENCH_GPU_CHUNK", "256")), n_g // depth))
         # no coefficient staging to speak of: it is only needed for images the GPU walk hands back
         ebs = [ica.Batch(ctx, gchunk, cbytes * 4, cbytes * gchunk, obytes * gchunk) for _ in range(depth)]
         for eb in ebs:
