@@ -774,8 +774,12 @@ extern "C" int mij_batch_upload(mij_batch *b)
 			for (int nb = 1; nb <= 16 && nb <= (int)avg_rows; ++nb) {
 				const size_t wgs = n_fused * (size_t)nb;
 				const size_t rounds = (wgs + slots - 1) / slots;
-				const double halo = 1.0 + 0.5 * 2.0 * (nb - 1) / (6.0 * avg_rows); /* IDCT ~ half the work */
-				const double cost = (double)rounds * (avg_rows / nb) * halo;        /* time ~ rounds x band length */
+				/* every inner band edge re-transforms two chroma block rows (4 of an MCU row's 6 blocks' worth), the IDCT being ~45 %
+				 * of the work; a launch also pays about 0.3 band lengths of ramp-up and tail whatever its shape -- without that term
+				 * the model took 3 bands for 1024 x 1080p where 6 measure 1.5 % faster, and 3 for 256 images where 12 measure 4 % faster
+				 * (interleaved runs, profiles/r02z_band_count.txt) */
+				const double halo = 1.0 + 0.45 * 4.0 * (nb - 1) / (6.0 * avg_rows);
+				const double cost = ((double)rounds + 0.3) * (avg_rows / nb) * halo; /* time ~ (rounds + ramp) x band length */
 				if (cost < best * 0.999) {
 					best = cost;
 					nb_best = nb;
