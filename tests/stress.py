@@ -38,7 +38,7 @@ def encoder_stress(budget, rng):
     while time.time() < t_end:
         imgs, qs, flips = [], [], []
         for _ in range(16):
-            w = int(rng.integers(1, 40)) * 16 if rng.random() < 0.5 else int(rng.integers(1, 500))
+            w = int(rng.integers(1, 80)) * 8 if rng.random() < 0.6 else int(rng.integers(1, 500))  # multiples of 8 / 16: the fused strip kernels
             h = int(rng.integers(1, 400))
             c = int(rng.choice([1, 3, 3, 3, 4]))
             img = picture(rng, w, h)
