@@ -1,5 +1,7 @@
+"""Host-side timeline of the GPU-walk ring (reset / begin / end / submit per chunk; DEPTH, SLACK, VERBOSE in the environment): what DESIGN.md 4b's
+remark about the ring that keeps one batch draining was measured with."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import image_codecs_amd as ica
 W, H = 1920, 1080
 ctx = ica.Context()

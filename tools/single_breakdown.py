@@ -1,6 +1,7 @@
+"""Where the time of one stbi_load-style call goes on a one-picture batch: extract + add, the GPU walk, the fused kernel, the copy back."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import image_codecs_amd as ica
 ctx = ica.Context()
 for (w, h) in ((1920, 1080), (4096, 4096)):
