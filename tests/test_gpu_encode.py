@@ -112,3 +112,30 @@ def test_fused_444_strip_kernel_and_per_unit_kernels_agree(ica, oracle, gpu_ctx)
         for s, im, q in zip(flipped, imgs, qs):
             assert np.array_equal(enc.fetch(s), ica.host_transform(im[::-1], q)[1]), (generic, im.shape)
         enc.close()
+
+
+def test_gpu_writer_entry_reuses_encoders_across_sizes_and_threads(ica, oracle, gpu_ctx):
+    """mij_write_jpg_to_func keeps its encoders in a pool between calls: growing and shrinking pictures, both layouts (quality <= 90:
+    4:2:0, above: 4:4:4), one to four channels, and four host threads writing at once -- every byte stream equals the oracle's."""
+    import threading
+    rng = np.random.default_rng(31)
+    cases = []
+    for (w, h, c, q) in ((64, 48, 3, 90), (640, 480, 3, 95), (16, 16, 3, 50), (1920, 1080, 3, 90), (333, 211, 3, 92), (200, 100, 1, 75), (128, 64, 4, 91), (72, 40, 2, 90), (1024, 768, 3, 100)):
+        img = rng.integers(0, 256, (h, w, c)).astype(np.uint8) if c != 3 else ica.synth_rgb(w, h, w + h)
+        cases.append((img, q, oracle.encode(img, q)))
+    for img, q, want in cases + cases[::-1]:
+        assert ica.mij_write_jpg_to_memory(img, q) == want, (img.shape, q)
+    errors = []
+
+    def worker(t):
+        for k in range(len(cases) * 2):
+            img, q, want = cases[(k * 3 + t) % len(cases)]
+            if ica.mij_write_jpg_to_memory(img, q) != want:
+                errors.append((t, img.shape, q))
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errors, errors[:4]
