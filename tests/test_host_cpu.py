@@ -355,3 +355,23 @@ def test_host_stage_is_clean_under_sanitizers(golden, ica, tmp_path):
     assert run.returncode == 0, run.stderr[-2000:]
     assert "runtime error" not in run.stderr and "AddressSanitizer" not in run.stderr, run.stderr[-2000:]
     assert "decoded ok" in run.stdout
+
+
+@pytest.mark.skipif(not helpers.Reference.available(), reason="oracle/_ref not built (reference absent on this box)")
+def test_host_writer_vs_live_reference_seeded(ica):
+    """stbi_write_jpg_to_func (SSE transform: four 1-D passes per instruction in the reference's operation order; Huffman emission
+    through a 64-bit accumulator) against the reference's writer itself: one to four channels, qualities on both sides of the 4:2:0 /
+    4:4:4 switch, noise (many 0xFF bytes to stuff), flat and gradient pictures, sizes that are not multiples of the MCU."""
+    ref = helpers.Reference()
+    rng = np.random.default_rng(77)
+    for i in range(150):
+        w, h = int(rng.integers(1, 160)), int(rng.integers(1, 120))
+        c = int(rng.choice([1, 2, 3, 4]))
+        q = int(rng.choice([1, 10, 50, 75, 90, 91, 95, 100]))
+        if i % 3 == 0:
+            img = rng.integers(0, 256, (h, w, c)).astype(np.uint8)
+        elif i % 3 == 1:
+            img = np.full((h, w, c), int(rng.integers(0, 256)), np.uint8)
+        else:
+            img = np.clip(np.linspace(0, 255, w)[None, :, None] + rng.normal(0, 30, (h, w, c)), 0, 255).astype(np.uint8)
+        assert ica.stbi_write_jpg_to_memory(img, q) == ref.encode(img, q), (w, h, c, q, i % 3)
