@@ -304,9 +304,33 @@ def leg_config4(ica, ctx, args, checker):
                "parity": True, "parity_against": kind, "warmup_launches_issued": n_warm,
                "host_progressive_stage_mpix_s_single_thread": round(size * size / host_s / 1e6, 1), "setup_s": round(time.time() - t0, 1)}
         add_traffic(res, "k_fused444_compact_%d" % n)
+        # end to end for this layout: 16 streams in host RAM -> pixels in HBM, every scan walked on the host threads (progressive
+        # scans cannot take the GPU walk: AC refinement does not re-synchronise), planes re-staged, packed, transformed
+        b.close()
+        b = None
+        threads, ne = usable_cores(), 16
+        eb = ica.Batch(ctx, ne, cb * ne, cb * ne, ob * ne)
+        try:
+            eb.decode_jpegs([data] * 2, 3, threads, gpu_entropy=False)  # page in the staging, start the pool
+            eb.submit()
+            eb.wait()
+            eb.reset()
+            te = time.perf_counter()
+            ok, slots, reasons = eb.decode_jpegs([data] * ne, 3, threads, gpu_entropy=False)
+            th = time.perf_counter() - te
+            eb.submit()
+            eb.wait()
+            te = time.perf_counter() - te
+            assert ok == ne, reasons
+            res["end_to_end"] = {"mpix_s": round(ne * size * size / te / 1e6, 1), "images": ne, "host_threads": threads,
+                                 "host_stage_only_mpix_s": round(ne * size * size / th / 1e6, 1),
+                                 "note": "ten scans per picture on the host threads (the reference's scan structure, codec/jpeg.c:372-558); bound by that stage"}
+        finally:
+            eb.close()
         return res
     finally:
-        b.close()
+        if b is not None:
+            b.close()
 
 
 def leg_config5(ica, ctx, args, checker, quality=90, count=None):
