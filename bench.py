@@ -389,9 +389,48 @@ def leg_config5(ica, ctx, args, checker, quality=90, count=None):
                "warmup_launches_issued": n_warm}
         if sub:
             add_traffic(res, "k_encode420_%d" % n)
+            enc.close()
+            enc = None
+            res["end_to_end"] = encode_end_to_end(ica, imgs, quality, kind, fenc)
         return res
     finally:
-        enc.close()
+        if enc is not None:
+            enc.close()
+
+
+def encode_end_to_end(ica, imgs, quality, kind, fenc):
+    """256 x 1080p RGB pictures in host memory -> 256 JPEG byte streams in host memory through mij_write_jpg_batch (staging copies and
+    Huffman emission on the host threads around one GPU launch), timed around the C call; next to the CPU checker's writer on one thread."""
+    L = ica.lib()
+    n, threads = 256, usable_cores()
+    arrs = [np.ascontiguousarray(imgs[i % len(imgs)]) for i in range(n)]
+    L.mij_write_jpg_batch.restype = C.c_int
+    L.mij_write_jpg_batch.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int,
+                                      C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    px = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+    xs, ys, cs = (C.c_int * n)(*[W] * n), (C.c_int * n)(*[H] * n), (C.c_int * n)(*[3] * n)
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    best, first = None, None
+    for rep in range(3):
+        out, lens = (C.c_void_p * n)(), (C.c_size_t * n)()
+        t0 = time.perf_counter()
+        rc = L.mij_write_jpg_batch(px, xs, ys, cs, n, quality, threads, out, lens)
+        dt = time.perf_counter() - t0
+        assert rc == n, "mij_write_jpg_batch wrote %d of %d streams" % (rc, n)
+        if first is None:
+            first = C.string_at(out[0], lens[0])
+        for i in range(n):
+            libc.free(out[i])
+        best = dt if best is None or dt < best else best
+    buf = np.zeros(W * H * 3, np.uint8)
+    t0 = time.perf_counter()
+    nb = fenc(buf.ctypes.data, buf.size, W, H, 3, arrs[0].ctypes.data, quality)
+    cpu_ms = (time.perf_counter() - t0) * 1e3
+    assert nb > 0 and first == bytes(buf[:nb]), "batch writer's stream 0 differs from the CPU checker's"
+    return {"mpix_s": round(n * W * H / best / 1e6, 1), "images": n, "host_threads": threads, "ms_per_batch": round(best * 1e3, 2),
+            "cpu_checker_ms_per_picture_one_thread": round(cpu_ms, 2), "cpu_checker": kind,
+            "includes": "pixels in host RAM -> pinned staging (host threads) -> H2D -> k_encode420 -> D2H of the data units -> Huffman emission (host threads) -> byte streams in host RAM"}
 
 
 def leg_h2v1(ica, ctx, args, checker):

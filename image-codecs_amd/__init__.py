@@ -25,6 +25,7 @@ from .binding import (  # noqa: F401
     host_transform,
     emit_jpeg,
     mij_write_jpg_to_memory,
+    mij_write_jpg_batch,
     HostDecoder,
     lib,
     build_library,

@@ -807,6 +807,38 @@ def mij_write_jpg_to_memory(pixels, quality=90):
     return b"".join(chunks) if ok else None
 
 
+def mij_write_jpg_batch(images, quality=90, threads=16):
+    """mij_write_jpg_batch: a list of uint8 pictures [h, w, comp] (or [h, w]) -> list of byte streams (None where the picture was refused)."""
+    L = lib()
+    arrs = []
+    for im in images:
+        a = np.ascontiguousarray(im, dtype=np.uint8)
+        arrs.append(a[:, :, None] if a.ndim == 2 else a)
+    n = len(arrs)
+    L.mij_write_jpg_batch.restype = C.c_int
+    L.mij_write_jpg_batch.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int,
+                                      C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    px = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+    xs = (C.c_int * n)(*[a.shape[1] for a in arrs])
+    ys = (C.c_int * n)(*[a.shape[0] for a in arrs])
+    cs = (C.c_int * n)(*[a.shape[2] for a in arrs])
+    out = (C.c_void_p * n)()
+    lens = (C.c_size_t * n)()
+    rc = L.mij_write_jpg_batch(px, xs, ys, cs, n, int(quality), int(threads), out, lens)
+    if rc < 0:
+        raise MijError("mij_write_jpg_batch: error %d" % rc)
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    res = []
+    for i in range(n):
+        if out[i]:
+            res.append(C.string_at(out[i], lens[i]))
+            libc.free(out[i])
+        else:
+            res.append(None)
+    return res
+
+
 class Encoder:
     """mij_encoder: batch colour + subsample + fDCT + quantiser on the GPU."""
 

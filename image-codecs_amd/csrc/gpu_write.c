@@ -5,6 +5,7 @@
  */
 #include <pthread.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "mij.h"
 #include "mij_host.h"
@@ -36,16 +37,17 @@ static mij_ctx *writer_ctx(void)
 typedef struct {
 	mij_encoder *enc;
 	size_t pix_cap, du_cap;
+	int max_images;
 } pooled_enc;
 static pooled_enc g_pool[MJW_POOL_MAX];
 static int g_pool_n = 0;
 
-static int pool_take(mij_ctx *ctx, size_t pix, size_t dub, pooled_enc *out)
+static int pool_take(mij_ctx *ctx, int images, size_t pix, size_t dub, pooled_enc *out)
 {
 	int i, best = -1;
 	pthread_mutex_lock(&g_lock);
 	for (i = 0; i < g_pool_n; ++i)
-		if (g_pool[i].pix_cap >= pix && g_pool[i].du_cap >= dub && (best < 0 || g_pool[i].pix_cap < g_pool[best].pix_cap))
+		if (g_pool[i].max_images >= images && g_pool[i].pix_cap >= pix && g_pool[i].du_cap >= dub && (best < 0 || g_pool[i].pix_cap < g_pool[best].pix_cap))
 			best = i;
 	if (best >= 0) {
 		*out = g_pool[best];
@@ -59,11 +61,12 @@ static int pool_take(mij_ctx *ctx, size_t pix, size_t dub, pooled_enc *out)
 	}
 	out->pix_cap = pix + pix / 4 + 4096;
 	out->du_cap = dub + dub / 4 + 4096;
+	out->max_images = images;
 	out->enc = NULL;
-	if (mij_enc_create(ctx, 1, out->pix_cap, out->du_cap, &out->enc) != MIJ_OK) {
+	if (mij_enc_create(ctx, images, out->pix_cap, out->du_cap, &out->enc) != MIJ_OK) {
 		out->pix_cap = pix + 256;
 		out->du_cap = dub + 256;
-		if (mij_enc_create(ctx, 1, out->pix_cap, out->du_cap, &out->enc) != MIJ_OK)
+		if (mij_enc_create(ctx, images, out->pix_cap, out->du_cap, &out->enc) != MIJ_OK)
 			return 0;
 	}
 	return 1;
@@ -106,7 +109,7 @@ int mij_write_jpg_to_func(mjw_write_func *func, void *context, int x, int y, int
 		return 0; /* no gpu device: this entry point has no host fallback */
 	elems = mjw_plan_du_count(&plan) * 64;
 	pix = (size_t)x * (size_t)y * (size_t)comp;
-	if (!pool_take(ctx, pix + 256, elems * 2 + 256, &pe))
+	if (!pool_take(ctx, 1, pix + 256, elems * 2 + 256, &pe))
 		return 0;
 	du = (int16_t *)malloc(elems * sizeof(int16_t));
 	slot = du ? mij_enc_add(pe.enc, data, x, y, comp, quality, mjw_flip_on_write()) : -1;
@@ -115,4 +118,148 @@ int mij_write_jpg_to_func(mjw_write_func *func, void *context, int x, int y, int
 	free(du);
 	pool_give(&pe);
 	return ok;
+}
+
+/* ------------------------------------------------------------------ a batch of pictures (BASELINE config 5 end to end)
+ *
+ * stbi_write_jpg_to_func once per picture spends its time in the transform (host) or in per-call traffic (GPU).  Here the
+ * staging copies of all pictures run on `threads` host threads, ONE launch transforms them, one copy brings every data unit
+ * back to pinned memory and the threads emit the streams (codec/jpeg_write.c:120-169) side by side. */
+typedef struct {
+	mij_encoder *enc;
+	const void *const *pixels;
+	const int *x, *y, *comp, *slot;
+	unsigned char **out;
+	size_t *out_len;
+	int n, next, phase, ok;
+	pthread_mutex_t lock;
+} wb_job;
+
+static void *wb_worker(void *arg)
+{
+	wb_job *j = (wb_job *)arg;
+	int good = 0;
+	for (;;) {
+		int i;
+		pthread_mutex_lock(&j->lock);
+		i = j->next++;
+		pthread_mutex_unlock(&j->lock);
+		if (i >= j->n)
+			break;
+		if (j->slot[i] < 0)
+			continue;
+		if (j->phase == 0) { /* pixels -> the slot's pinned staging */
+			void *dst = mij_enc_staging(j->enc, j->slot[i]);
+			if (dst)
+				memcpy(dst, j->pixels[i], (size_t)j->x[i] * (size_t)j->y[i] * (size_t)j->comp[i]);
+		} else { /* data units -> byte stream */
+			mjw_plan plan;
+			const int16_t *du = mij_enc_units(j->enc, j->slot[i]);
+			if (du && mij_enc_plan(j->enc, j->slot[i], &plan) == MIJ_OK) {
+				/* a coefficient takes at most 27 bits and every output byte may be a stuffed 0xFF: under 7 bytes each (untouched pages cost nothing) */
+				const size_t cap = 2048 + mjw_plan_du_count(&plan) * 64 * 7;
+				unsigned char *buf = (unsigned char *)malloc(cap);
+				const size_t len = buf ? mjw_emit_to_memory(&plan, du, buf, cap) : 0;
+				if (len) {
+					unsigned char *fit = (unsigned char *)realloc(buf, len);
+					j->out[i] = fit ? fit : buf;
+					j->out_len[i] = len;
+					++good;
+				} else
+					free(buf);
+			}
+		}
+	}
+	pthread_mutex_lock(&j->lock);
+	j->ok += good;
+	pthread_mutex_unlock(&j->lock);
+	return NULL;
+}
+
+static void wb_run(wb_job *j, int phase, int threads)
+{
+	pthread_t th[64];
+	int t, started = 0;
+	j->phase = phase;
+	j->next = 0;
+	if (threads > 64)
+		threads = 64;
+	for (t = 1; t < threads; ++t)
+		if (pthread_create(&th[started], NULL, wb_worker, j) == 0)
+			++started;
+	wb_worker(j);
+	for (t = 0; t < started; ++t)
+		pthread_join(th[t], NULL);
+}
+
+int mij_write_jpg_batch(const void *const *pixels, const int *x, const int *y, const int *comp, int n, int quality, int threads,
+								unsigned char **out, size_t *out_len)
+{
+	mij_ctx *ctx;
+	pooled_enc pe;
+	wb_job j;
+	size_t pix = 0, dub = 0;
+	int i, *slot, rc = MIJ_OK;
+	if (!pixels || !x || !y || !comp || !out || !out_len || n < 0)
+		return MIJ_E_ARG;
+	for (i = 0; i < n; ++i) {
+		out[i] = NULL;
+		out_len[i] = 0;
+	}
+	if (n == 0)
+		return 0;
+	ctx = writer_ctx();
+	if (!ctx)
+		return MIJ_E_NODEVICE;
+	slot = (int *)malloc(sizeof(int) * (size_t)n);
+	if (!slot)
+		return MIJ_E_NOMEM;
+	for (i = 0; i < n; ++i) {
+		mjw_plan plan;
+		slot[i] = -1;
+		if (pixels[i] && mjw_plan_init(&plan, x[i], y[i], comp[i], quality)) {
+			pix += ((size_t)x[i] * (size_t)y[i] * (size_t)comp[i] + 255) / 256 * 256;
+			dub += (mjw_plan_du_count(&plan) * 128 + 255) / 256 * 256;
+			slot[i] = 0;
+		}
+	}
+	if (!pool_take(ctx, n, pix + 256, dub + 256, &pe)) {
+		free(slot);
+		return MIJ_E_NOMEM;
+	}
+	for (i = 0; i < n && rc == MIJ_OK; ++i)
+		if (slot[i] == 0) {
+			slot[i] = mij_enc_add_uncopied(pe.enc, x[i], y[i], comp[i], quality, mjw_flip_on_write());
+			if (slot[i] < 0)
+				rc = slot[i];
+		}
+	memset(&j, 0, sizeof j);
+	j.enc = pe.enc;
+	j.pixels = pixels;
+	j.x = x;
+	j.y = y;
+	j.comp = comp;
+	j.slot = slot;
+	j.out = out;
+	j.out_len = out_len;
+	j.n = n;
+	pthread_mutex_init(&j.lock, NULL);
+	if (threads < 1)
+		threads = 1;
+	if (rc == MIJ_OK) {
+		wb_run(&j, 0, threads);
+		rc = mij_enc_upload(pe.enc);
+	}
+	if (rc == MIJ_OK)
+		rc = mij_enc_launch(pe.enc);
+	if (rc == MIJ_OK)
+		rc = mij_enc_fetch_all(pe.enc);
+	if (rc == MIJ_OK) {
+		j.ok = 0;
+		wb_run(&j, 1, threads);
+	}
+	pthread_mutex_destroy(&j.lock);
+	pool_give(&pe);
+	free(slot);
+	return rc == MIJ_OK ? j.ok : rc;
 }

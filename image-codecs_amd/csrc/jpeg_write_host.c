@@ -512,6 +512,35 @@ int mjw_emit(const mjw_plan *p, const int16_t *du, mjw_write_func *func, void *c
 	return 1;
 }
 
+typedef struct {
+	unsigned char *out;
+	size_t cap, len;
+	int overflow;
+} mem_sink;
+static void mem_sink_write(void *context, void *data, int size)
+{
+	mem_sink *m = (mem_sink *)context;
+	if (m->len + (size_t)size > m->cap) {
+		m->overflow = 1;
+		return;
+	}
+	memcpy(m->out + m->len, data, (size_t)size);
+	m->len += (size_t)size;
+}
+size_t mjw_emit_to_memory(const mjw_plan *p, const int16_t *du, unsigned char *out, size_t cap)
+{
+	mem_sink m;
+	if (!p || !du || !out)
+		return 0;
+	m.out = out;
+	m.cap = cap;
+	m.len = 0;
+	m.overflow = 0;
+	if (!mjw_emit(p, du, mem_sink_write, &m) || m.overflow)
+		return 0;
+	return m.len;
+}
+
 int stbi_write_jpg_to_func(stbi_write_func *func, void *context, int x, int y, int comp, const void *data, int quality)
 {
 	mjw_plan plan;

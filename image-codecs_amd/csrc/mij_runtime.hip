@@ -1945,7 +1945,8 @@ static int enc_add_common(mij_encoder *e, const mjw_plan &plan, const void *pixe
 		if (e->stage_used + s.pix_bytes > e->stage_cap)
 			return set_err(MIJ_E_NOMEM, "pixel staging exhausted");
 		s.stage_off = e->stage_used;
-		memcpy(e->stage + s.stage_off, pixels, (size_t)plan.width * plan.height * plan.comp);
+		if (pixels) /* mij_enc_add_uncopied: the caller fills mij_enc_staging(slot) itself (several threads at once) */
+			memcpy(e->stage + s.stage_off, pixels, (size_t)plan.width * plan.height * plan.comp);
 		e->stage_used += s.pix_bytes;
 	} else {
 		s.stage_off = e->slots[(size_t)clone_of].stage_off;
@@ -1977,6 +1978,46 @@ extern "C" int mij_enc_add(mij_encoder *e, const void *pixels, int width, int he
 	if (!mjw_plan_init(&plan, width, height, comp, quality))
 		return set_err(MIJ_E_ARG, "bad image arguments (%dx%dx%d)", width, height, comp);
 	return enc_add_common(e, plan, pixels, flip_vertically ? 1 : 0, -1);
+}
+
+extern "C" int mij_enc_add_uncopied(mij_encoder *e, int width, int height, int comp, int quality, int flip_vertically)
+{
+	if (!e)
+		return set_err(MIJ_E_ARG, "bad argument");
+	mjw_plan plan;
+	if (!mjw_plan_init(&plan, width, height, comp, quality))
+		return set_err(MIJ_E_ARG, "bad image arguments (%dx%dx%d)", width, height, comp);
+	return enc_add_common(e, plan, nullptr, flip_vertically ? 1 : 0, -1);
+}
+
+extern "C" void *mij_enc_staging(mij_encoder *e, int slot)
+{
+	if (!e || slot < 0 || slot >= (int)e->slots.size() || e->slots[(size_t)slot].clone_of >= 0)
+		return nullptr;
+	return e->stage + e->slots[(size_t)slot].stage_off;
+}
+
+/* every slot's data units into the encoder's pinned mirror in one copy; mij_enc_units(slot) then points at a slot's units */
+extern "C" int mij_enc_fetch_all(mij_encoder *e)
+{
+	if (!e)
+		return set_err(MIJ_E_ARG, "encoder is NULL");
+	if (!e->launched)
+		return set_err(MIJ_E_STATE, "mij_enc_fetch_all before launch");
+	HIP_TRY(hipSetDevice(e->ctx->device));
+	if (!e->h_du)
+		HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->h_du), e->du_cap, hipHostMallocDefault));
+	if (e->du_used)
+		HIP_TRY(hipMemcpyAsync(e->h_du, e->d_du, e->du_used, hipMemcpyDeviceToHost, e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	return MIJ_OK;
+}
+
+extern "C" const int16_t *mij_enc_units(const mij_encoder *e, int slot)
+{
+	if (!e || !e->h_du || slot < 0 || slot >= (int)e->slots.size())
+		return nullptr;
+	return reinterpret_cast<const int16_t *>(reinterpret_cast<const uint8_t *>(e->h_du) + e->slots[(size_t)slot].dev.du_off);
 }
 
 extern "C" int mij_enc_add_clone(mij_encoder *e, int src_slot)

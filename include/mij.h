@@ -294,6 +294,14 @@ int mij_enc_reset(mij_encoder *e);
 /* copies the pixels into pinned staging; quality and 4:2:0/4:4:4 choice as stbi_write_jpg; returns the slot */
 int mij_enc_add(mij_encoder *e, const void *pixels, int width, int height, int comp, int quality, int flip_vertically);
 int mij_enc_add_clone(mij_encoder *e, int src_slot); /* own device buffers, same pixels (benchmarks) */
+/* the same slot bookkeeping without the copy: the caller writes width*height*comp bytes to mij_enc_staging(slot) before
+ * mij_enc_upload (batch front ends fill the slots from several host threads at once, mij_write_jpg_batch) */
+int mij_enc_add_uncopied(mij_encoder *e, int width, int height, int comp, int quality, int flip_vertically);
+void *mij_enc_staging(mij_encoder *e, int slot);
+/* every slot's data units into the encoder's pinned mirror with one device-to-host copy (waits for it); mij_enc_units(slot)
+ * points into that mirror until the next mij_enc_fetch_all / mij_enc_destroy */
+int mij_enc_fetch_all(mij_encoder *e);
+const int16_t *mij_enc_units(const mij_encoder *e, int slot);
 int mij_enc_upload(mij_encoder *e);
 int mij_enc_launch(mij_encoder *e);
 int mij_enc_wait(mij_encoder *e);

@@ -139,3 +139,20 @@ def test_gpu_writer_entry_reuses_encoders_across_sizes_and_threads(ica, oracle, 
     for th in ths:
         th.join()
     assert not errors, errors[:4]
+
+
+def test_batch_writer_front_end(ica, oracle, gpu_ctx):
+    """mij_write_jpg_batch: a mixed batch (sizes, channel counts, both layouts by quality) staged and emitted on several host threads
+    around one GPU launch; every stream equals the oracle's for that picture; a refused picture (zero width) leaves the others alone."""
+    rng = np.random.default_rng(41)
+    for q in (90, 95, 30):
+        imgs = []
+        for (w, h, c) in ((64, 48, 3), (640, 480, 3), (16, 16, 3), (1920, 1080, 3), (333, 211, 3), (200, 100, 1), (128, 64, 4), (72, 40, 2), (8, 8, 3), (1, 1, 3)):
+            imgs.append(rng.integers(0, 256, (h, w, c)).astype(np.uint8) if c != 3 or w < 100 else ica.synth_rgb(w, h, w + h + q))
+        for threads in (1, 5):
+            got = ica.mij_write_jpg_batch(imgs, q, threads)
+            for im, g in zip(imgs, got):
+                assert g == oracle.encode(im, q), (im.shape, q, threads)
+    # the clones of one picture: identical streams
+    got = ica.mij_write_jpg_batch([imgs[3]] * 12, 90, 4)
+    assert len(set(got)) == 1 and got[0] == oracle.encode(imgs[3], 90)
