@@ -131,7 +131,7 @@ typedef struct {
 	const int *x, *y, *comp, *slot;
 	unsigned char **out;
 	size_t *out_len;
-	int n, next, phase, ok;
+	int lo, hi, next, phase, ok;
 	pthread_mutex_t lock;
 } wb_job;
 
@@ -144,7 +144,7 @@ static void *wb_worker(void *arg)
 		pthread_mutex_lock(&j->lock);
 		i = j->next++;
 		pthread_mutex_unlock(&j->lock);
-		if (i >= j->n)
+		if (i >= j->hi)
 			break;
 		if (j->slot[i] < 0)
 			continue;
@@ -176,14 +176,20 @@ static void *wb_worker(void *arg)
 	return NULL;
 }
 
-static void wb_run(wb_job *j, int phase, int threads)
+/* phase 0 (staging) or 1 (emission) of pictures lo .. hi-1 on `threads` threads, the caller's included */
+static void wb_run(wb_job *j, mij_encoder *enc, int phase, int lo, int hi, int threads)
 {
 	pthread_t th[64];
 	int t, started = 0;
+	j->enc = enc;
 	j->phase = phase;
-	j->next = 0;
+	j->lo = lo;
+	j->hi = hi;
+	j->next = lo;
 	if (threads > 64)
 		threads = 64;
+	if (threads > hi - lo)
+		threads = hi - lo;
 	for (t = 1; t < threads; ++t)
 		if (pthread_create(&th[started], NULL, wb_worker, j) == 0)
 			++started;
@@ -192,14 +198,17 @@ static void wb_run(wb_job *j, int phase, int threads)
 		pthread_join(th[t], NULL);
 }
 
+/* Chunks of pictures go through two encoders in turn: while the GPU and the PCIe link work on chunk c (upload, one launch, the copy
+ * back -- all queued without a wait), the host threads emit chunk c-1 and stage chunk c+1. */
+#define WB_CHUNK_BYTES ((size_t)200 << 20)
 int mij_write_jpg_batch(const void *const *pixels, const int *x, const int *y, const int *comp, int n, int quality, int threads,
 								unsigned char **out, size_t *out_len)
 {
 	mij_ctx *ctx;
-	pooled_enc pe;
+	pooled_enc pe[2];
 	wb_job j;
-	size_t pix = 0, dub = 0;
-	int i, *slot, rc = MIJ_OK;
+	size_t pix_max = 0, dub_max = 0;
+	int i, *slot, *cend, nchunk = 0, rc = MIJ_OK, have[2] = {0, 0}, img_max = 0, c;
 	if (!pixels || !x || !y || !comp || !out || !out_len || n < 0)
 		return MIJ_E_ARG;
 	for (i = 0; i < n; ++i) {
@@ -212,29 +221,42 @@ int mij_write_jpg_batch(const void *const *pixels, const int *x, const int *y, c
 	if (!ctx)
 		return MIJ_E_NODEVICE;
 	slot = (int *)malloc(sizeof(int) * (size_t)n);
-	if (!slot)
-		return MIJ_E_NOMEM;
-	for (i = 0; i < n; ++i) {
-		mjw_plan plan;
-		slot[i] = -1;
-		if (pixels[i] && mjw_plan_init(&plan, x[i], y[i], comp[i], quality)) {
-			pix += ((size_t)x[i] * (size_t)y[i] * (size_t)comp[i] + 255) / 256 * 256;
-			dub += (mjw_plan_du_count(&plan) * 128 + 255) / 256 * 256;
-			slot[i] = 0;
-		}
-	}
-	if (!pool_take(ctx, n, pix + 256, dub + 256, &pe)) {
+	cend = (int *)malloc(sizeof(int) * (size_t)n);
+	if (!slot || !cend) {
 		free(slot);
+		free(cend);
 		return MIJ_E_NOMEM;
 	}
-	for (i = 0; i < n && rc == MIJ_OK; ++i)
-		if (slot[i] == 0) {
-			slot[i] = mij_enc_add_uncopied(pe.enc, x[i], y[i], comp[i], quality, mjw_flip_on_write());
-			if (slot[i] < 0)
-				rc = slot[i];
+	/* chunk boundaries: about WB_CHUNK_BYTES of pixels each; the encoders are sized for the largest chunk */
+	{
+		size_t pix = 0, dub = 0;
+		int first = 0;
+		for (i = 0; i < n; ++i) {
+			mjw_plan plan;
+			slot[i] = -1;
+			if (pixels[i] && mjw_plan_init(&plan, x[i], y[i], comp[i], quality)) {
+				pix += ((size_t)x[i] * (size_t)y[i] * (size_t)comp[i] + 255) / 256 * 256;
+				dub += (mjw_plan_du_count(&plan) * 128 + 255) / 256 * 256;
+				slot[i] = 0;
+			}
+			if (pix >= WB_CHUNK_BYTES || i == n - 1) {
+				cend[nchunk++] = i + 1;
+				pix_max = pix > pix_max ? pix : pix_max;
+				dub_max = dub > dub_max ? dub : dub_max;
+				img_max = i + 1 - first > img_max ? i + 1 - first : img_max;
+				first = i + 1;
+				pix = dub = 0;
+			}
 		}
+	}
+	for (c = 0; c < (nchunk > 1 ? 2 : 1); ++c) {
+		if (!pool_take(ctx, img_max, pix_max + 256, dub_max + 256, &pe[c])) {
+			rc = MIJ_E_NOMEM;
+			break;
+		}
+		have[c] = 1;
+	}
 	memset(&j, 0, sizeof j);
-	j.enc = pe.enc;
 	j.pixels = pixels;
 	j.x = x;
 	j.y = y;
@@ -242,24 +264,43 @@ int mij_write_jpg_batch(const void *const *pixels, const int *x, const int *y, c
 	j.slot = slot;
 	j.out = out;
 	j.out_len = out_len;
-	j.n = n;
 	pthread_mutex_init(&j.lock, NULL);
 	if (threads < 1)
 		threads = 1;
-	if (rc == MIJ_OK) {
-		wb_run(&j, 0, threads);
-		rc = mij_enc_upload(pe.enc);
-	}
-	if (rc == MIJ_OK)
-		rc = mij_enc_launch(pe.enc);
-	if (rc == MIJ_OK)
-		rc = mij_enc_fetch_all(pe.enc);
-	if (rc == MIJ_OK) {
-		j.ok = 0;
-		wb_run(&j, 1, threads);
+	for (c = 0; c <= nchunk && rc == MIJ_OK; ++c) {
+		mij_encoder *cur = c < nchunk ? pe[c & 1].enc : NULL, *prev = c > 0 ? pe[(c - 1) & 1].enc : NULL;
+		const int lo = c < nchunk ? (c ? cend[c - 1] : 0) : 0, hi = c < nchunk ? cend[c] : 0;
+		if (cur) { /* stage chunk c and queue its GPU work */
+			if (c >= 2)
+				rc = mij_enc_reset(cur); /* its previous chunk was emitted in the last round */
+			for (i = lo; i < hi && rc == MIJ_OK; ++i)
+				if (slot[i] == 0) {
+					slot[i] = mij_enc_add_uncopied(cur, x[i], y[i], comp[i], quality, mjw_flip_on_write());
+					if (slot[i] < 0)
+						rc = slot[i];
+				}
+			if (rc == MIJ_OK) {
+				wb_run(&j, cur, 0, lo, hi, threads);
+				rc = mij_enc_upload(cur);
+			}
+			if (rc == MIJ_OK)
+				rc = mij_enc_launch(cur);
+			if (rc == MIJ_OK)
+				rc = mij_enc_fetch_all_async(cur);
+		}
+		if (prev && rc == MIJ_OK) { /* emit chunk c-1 while chunk c is in flight */
+			rc = mij_enc_wait(prev);
+			if (rc == MIJ_OK)
+				wb_run(&j, prev, 1, c > 1 ? cend[c - 2] : 0, cend[c - 1], threads);
+		}
 	}
 	pthread_mutex_destroy(&j.lock);
-	pool_give(&pe);
+	for (c = 0; c < 2; ++c)
+		if (have[c]) {
+			(void)mij_enc_wait(pe[c].enc);
+			pool_give(&pe[c]);
+		}
 	free(slot);
+	free(cend);
 	return rc == MIJ_OK ? j.ok : rc;
 }

@@ -2013,6 +2013,21 @@ extern "C" int mij_enc_fetch_all(mij_encoder *e)
 	return MIJ_OK;
 }
 
+/* the same without the wait: mij_enc_wait before mij_enc_units is read */
+extern "C" int mij_enc_fetch_all_async(mij_encoder *e)
+{
+	if (!e)
+		return set_err(MIJ_E_ARG, "encoder is NULL");
+	if (!e->launched)
+		return set_err(MIJ_E_STATE, "mij_enc_fetch_all_async before launch");
+	HIP_TRY(hipSetDevice(e->ctx->device));
+	if (!e->h_du)
+		HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->h_du), e->du_cap, hipHostMallocDefault));
+	if (e->du_used)
+		HIP_TRY(hipMemcpyAsync(e->h_du, e->d_du, e->du_used, hipMemcpyDeviceToHost, e->stream));
+	return MIJ_OK;
+}
+
 extern "C" const int16_t *mij_enc_units(const mij_encoder *e, int slot)
 {
 	if (!e || !e->h_du || slot < 0 || slot >= (int)e->slots.size())

@@ -301,6 +301,7 @@ void *mij_enc_staging(mij_encoder *e, int slot);
 /* every slot's data units into the encoder's pinned mirror with one device-to-host copy (waits for it); mij_enc_units(slot)
  * points into that mirror until the next mij_enc_fetch_all / mij_enc_destroy */
 int mij_enc_fetch_all(mij_encoder *e);
+int mij_enc_fetch_all_async(mij_encoder *e); /* queued behind the launch, no wait: mij_enc_wait before reading mij_enc_units */
 const int16_t *mij_enc_units(const mij_encoder *e, int slot);
 int mij_enc_upload(mij_encoder *e);
 int mij_enc_launch(mij_encoder *e);

@@ -156,3 +156,13 @@ def test_batch_writer_front_end(ica, oracle, gpu_ctx):
     # the clones of one picture: identical streams
     got = ica.mij_write_jpg_batch([imgs[3]] * 12, 90, 4)
     assert len(set(got)) == 1 and got[0] == oracle.encode(imgs[3], 90)
+
+
+def test_batch_writer_pipelines_chunks_over_two_encoders(ica, oracle, gpu_ctx):
+    """More than 200 MB of pixels: mij_write_jpg_batch cuts the batch into chunks that alternate between two encoders (staging and
+    emission of neighbouring chunks overlap the GPU's work): 72 x 1080p pictures = three chunks, every stream equal to the oracle's."""
+    srcs = [ica.synth_rgb(1920, 1080, s) for s in range(3)]
+    want = [oracle.encode(im, 90) for im in srcs]
+    got = ica.mij_write_jpg_batch([srcs[i % 3] for i in range(72)], 90, 8)
+    for i, g in enumerate(got):
+        assert g == want[i % 3], i
