@@ -2034,9 +2034,42 @@ __global__ __launch_bounds__(256) void k_encode_c(const EncImage *__restrict__ i
 #define MIJ_ENC_DUPITCH 128
 #define MIJ_ENC_CPITCH 256
 #define MIJ_ENC_LDS_A (16 * MIJ_ENC_PIXROW) /* == MIJ_ENC_STRIP * 6 * MIJ_ENC_DUPITCH */
+/* MIJ_ENC_INPLACE (default): the chroma means go over pixel rows their wave has already consumed, so the workgroup needs the 24 KiB
+ * of the pixel rows only and five workgroups (15 waves) fit a CU where the separate 16 KiB stage allowed four; 0 = the round-1 layout */
+#ifndef MIJ_ENC_INPLACE
+#define MIJ_ENC_INPLACE 1
+#endif
+#if MIJ_ENC_INPLACE
+#define MIJ_ENC_LDS MIJ_ENC_LDS_A
+#else
 #define MIJ_ENC_LDS (MIJ_ENC_LDS_A + MIJ_ENC_STRIP * 2 * MIJ_ENC_CPITCH)
+#endif
 __device__ __forceinline__ int enc_du_chunk(int u, int k) { return u * MIJ_ENC_DUPITCH + ((k ^ (u & 7)) << 4); }
-__device__ __forceinline__ int enc_cf_chunk(int u, int h) { return u * MIJ_ENC_CPITCH + ((h ^ (u & 15)) << 4); }
+#if MIJ_ENC_INPLACE
+/* Chroma means of MCU j, component c, row pair rp = 2 * wave + kk of the unit, 16-byte chunk q (two columns x two rows): inside the
+ * four pixel rows luma wave `wave` read in its step kk (every lane of the wave has read them before any lane writes: one wave, program
+ * order), 256 chunks per region, eight chunks per MCU, swizzled with the MCU index so that both the 16 lanes that write one (c, q) and
+ * the 16 that read it spread over all eight 16-byte bank groups. */
+__device__ __forceinline__ int enc_cf_chunk(int j, int c, int rp, int q)
+{
+	return (4 * rp) * MIJ_ENC_PIXROW + ((j * 8 + ((c * 4 + q) ^ (j & 7))) << 4);
+}
+#else
+__device__ __forceinline__ int enc_cf_chunk(int j, int c, int rp, int q)
+{
+	const int u = 2 * j + c, h = 4 * rp + q;
+	return MIJ_ENC_LDS_A + u * MIJ_ENC_CPITCH + ((h ^ (u & 15)) << 4);
+}
+#endif
+
+/* (k.x * a.y, k.y * a.y): the high half of a register pair broadcast by the instruction's operand select.  The compiler
+ * only knows the low-half broadcast and copies a.y into a fresh pair first (one v_mov per product, 96 per luma lane). */
+__device__ __forceinline__ f2 pk_mul_bhi(f2 k, f2 a)
+{
+	f2 d;
+	asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(d) : "v"(a), "s"(k));
+	return d;
+}
 
 /* byte k of a row of dwords as float, for a (top, bottom) row pair */
 template <int K>
@@ -2045,9 +2078,10 @@ __device__ __forceinline__ f2 enc_byte2(const uint32_t *t, const uint32_t *b)
 	return (f2){enc_byte<K>(t), enc_byte<K>(b)};
 }
 
-/* three waves per SIMD (<= 168 VGPRs): measured 1.72 ms vs 1.90 ms per 512 1080p images with two */
+/* round 1: three waves per SIMD (<= 168 VGPRs; 1.72 ms vs 1.90 ms per 512 1080p images with two).  Round 2: 118 VGPRs once the
+ * quantiser table sits behind one pointer and the high-half broadcasts stopped costing copies -> four */
 #ifndef MIJ_ENC_WAVES
-#define MIJ_ENC_WAVES 3
+#define MIJ_ENC_WAVES 4
 #endif
 __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(MIJ_ENC_WAVES, MIJ_ENC_WAVES))) void k_encode420(
 	const EncImage *__restrict__ imgs, const WorkIdct *__restrict__ work, const uint8_t *__restrict__ pix, int16_t *__restrict__ du)
@@ -2055,7 +2089,7 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(MIJ_ENC_WAV
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 	uint8_t *const spx = lds;                 /* pixel rows, later the staged data units */
 	uint8_t *const sdu = lds;
-	uint8_t *const scf = lds + MIJ_ENC_LDS_A; /* chroma means as floats, [mcu*2 + c][row pair][col][row & 1] */
+	uint8_t *const scf = lds;                 /* chroma means as floats (enc_cf_chunk) */
 	const WorkIdct wk = work[blockIdx.x];
 	const EncImage &im = imgs[wk.img];
 	const int tid = threadIdx.x;
@@ -2109,7 +2143,7 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(MIJ_ENC_WAV
 		const f2 r = enc_byte2<3 * (XI) + 0>(t, b), g = enc_byte2<3 * (XI) + 1>(t, b), bl = enc_byte2<3 * (XI) + 2>(t, b);      \
 		V[k][XI] = 0.29900f * r + 0.58700f * g + 0.11400f * bl - 128.0f;                                                      \
 		Wt[XI] = KR * r.x + KG * g.x + KB * bl.x;                                                                             \
-		Wb[XI] = KR * r.y + KG * g.y + KB * bl.y;                                                                             \
+		Wb[XI] = pk_mul_bhi(KR, r) + pk_mul_bhi(KG, g) + pk_mul_bhi(KB, bl);                                                  \
 	}
 				MIJ_ENC_PX(0) MIJ_ENC_PX(1) MIJ_ENC_PX(2) MIJ_ENC_PX(3) MIJ_ENC_PX(4) MIJ_ENC_PX(5) MIJ_ENC_PX(6) MIJ_ENC_PX(7)
 #undef MIJ_ENC_PX
@@ -2119,29 +2153,35 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(MIJ_ENC_WAV
 				enc_row_fence();
 			}
 			/* sample rows 4*wave + 2*kk (+1) of the chroma unit = its row pair 2*wave + kk, columns 4*bx .. 4*bx+3 */
-			const int h0 = (2 * wave + kk) * 4 + bx * 2; /* 16-byte chunk of the unit: 4 floats = 2 columns x (row, row + 1) */
-			*reinterpret_cast<float4 *>(scf + enc_cf_chunk(2 * j, h0)) = make_float4(M[0][0].x, M[1][0].x, M[0][1].x, M[1][1].x);
-			*reinterpret_cast<float4 *>(scf + enc_cf_chunk(2 * j, h0 + 1)) = make_float4(M[0][2].x, M[1][2].x, M[0][3].x, M[1][3].x);
-			*reinterpret_cast<float4 *>(scf + enc_cf_chunk(2 * j + 1, h0)) = make_float4(M[0][0].y, M[1][0].y, M[0][1].y, M[1][1].y);
-			*reinterpret_cast<float4 *>(scf + enc_cf_chunk(2 * j + 1, h0 + 1)) = make_float4(M[0][2].y, M[1][2].y, M[0][3].y, M[1][3].y);
+			const int rp = 2 * wave + kk, q0 = bx * 2; /* 16-byte chunk: 4 floats = 2 columns x (row, row + 1) */
+			*reinterpret_cast<float4 *>(scf + enc_cf_chunk(j, 0, rp, q0)) = make_float4(M[0][0].x, M[1][0].x, M[0][1].x, M[1][1].x);
+			*reinterpret_cast<float4 *>(scf + enc_cf_chunk(j, 0, rp, q0 + 1)) = make_float4(M[0][2].x, M[1][2].x, M[0][3].x, M[1][3].x);
+			*reinterpret_cast<float4 *>(scf + enc_cf_chunk(j, 1, rp, q0)) = make_float4(M[0][0].y, M[1][0].y, M[0][1].y, M[1][1].y);
+			*reinterpret_cast<float4 *>(scf + enc_cf_chunk(j, 1, rp, q0 + 1)) = make_float4(M[0][2].y, M[1][2].y, M[0][3].y, M[1][3].y);
 		}
 	}
 	__syncthreads(); /* pixel rows dead, chroma means staged */
 
-	if (wave < 2) {
-		const int u = (lane >> 1) * 6 + 2 * wave + (lane & 1);
-		fdct_quant_store<0>(V, im.fy, reinterpret_cast<int16_t *>(sdu + u * MIJ_ENC_DUPITCH), u & 7);
-	} else {
+	if (wave == 2) {
 #pragma unroll
 		for (int k = 0; k < 4; ++k)
 #pragma unroll
 			for (int h = 0; h < 4; ++h) {
-				const float4 f = *reinterpret_cast<const float4 *>(scf + enc_cf_chunk(lane, 4 * k + h));
+				const float4 f = *reinterpret_cast<const float4 *>(scf + enc_cf_chunk(lane >> 1, lane & 1, k, h));
 				V[k][2 * h] = (f2){f.x, f.y};
 				V[k][2 * h + 1] = (f2){f.z, f.w};
 			}
-		const int u = (lane >> 1) * 6 + 4 + (lane & 1);
-		fdct_quant_store<0>(V, im.fc, reinterpret_cast<int16_t *>(sdu + u * MIJ_ENC_DUPITCH), u & 7);
+	}
+#if MIJ_ENC_INPLACE
+	__syncthreads(); /* the means are in registers: the staged units may now go over them */
+#endif
+	{
+		/* one instance of the transform for all three waves, its quantiser table behind ONE wave-uniform pointer: with a call per
+		 * branch the compiler merged the tails and carried 64 separate table addresses into them (64 scalar loads, each waited
+		 * for where it was used, and their offsets spilled to VGPR lanes) */
+		const float *fd = wave == 2 ? im.fc : im.fy;
+		const int u = (lane >> 1) * 6 + 2 * wave + (lane & 1); /* wave 2: 4 + (lane & 1) */
+		fdct_quant_store<0>(V, fd, reinterpret_cast<int16_t *>(sdu + u * MIJ_ENC_DUPITCH), u & 7);
 	}
 	__syncthreads();
 
