@@ -1748,6 +1748,24 @@ __device__ __forceinline__ void fdct8(T &d0, T &d1, T &d2, T &d3, T &d4, T &d5, 
 	d6 = o6;
 }
 
+/* copysign(0.5f, v) = (v & 0x80000000) | 0.5f in one v_bitop3_b32: the compiler's v_bfi_b32 issues at 35 T lane-ops/s, this at 53
+ * (profiles/r02s_isa_probe4.txt); truth table for S0 = 0xf0, S1 = 0xcc, S2 = 0xaa: (S0 & S1) | S2 = 0xea */
+__device__ __forceinline__ float half_signed(float v)
+{
+	float d;
+	asm("v_bitop3_b32 %0, %1, %2, 0.5 bitop3:0xea" : "=v"(d) : "v"(v), "s"(0x80000000u));
+	return d;
+}
+
+/* (int)lo | (int)hi << 16 as int16 halves, the C casts' truncation: the second conversion writes its low half straight into the upper
+ * half of the first one's result (SDWA destination select), two instructions a pair where shifts and masks made it four or five */
+__device__ __forceinline__ uint32_t cvt_pack_i16(float lo, float hi)
+{
+	uint32_t d;
+	asm("v_cvt_i32_f32_e32 %0, %1\n\tv_cvt_i32_f32_sdwa %0, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "=&v"(d) : "v"(lo), "v"(hi));
+	return d;
+}
+
 /* Rows, then columns, then quantise into zigzag order and store 128 bytes (codec/jpeg_write.c:96-118).
  * V[k][x] = samples (row 2k, row 2k+1) of column x: the row pass runs on row pairs, a 2x2 re-pairing
  * turns them into column pairs H[y][j] = (col 2j, col 2j+1) of row y for the column pass.
@@ -1772,24 +1790,24 @@ __device__ __forceinline__ void fdct_quant_store(f2 (&V)[4][8], const float *__r
 #pragma unroll
 	for (int j = 0; j < 4; ++j)
 		fdct8<f2>(H[0][j], H[1][j], H[2][j], H[3][j], H[4][j], H[5][j], H[6][j], H[7][j]);
-	int q[64];
+	float q[64]; /* rounded by the addition below, still float; zigzag order */
 #pragma unroll
 	for (int y = 0; y < 8; ++y)
 #pragma unroll
 		for (int j = 0; j < 4; ++j) {
 			f2 v = H[y][j] * (f2){fdtbl[8 * y + 2 * j], fdtbl[8 * y + 2 * j + 1]};
-			v = v + (f2){__builtin_copysignf(0.5f, v.x), __builtin_copysignf(0.5f, v.y)};
-			q[zz[8 * y + 2 * j]] = (int)v.x;
-			q[zz[8 * y + 2 * j + 1]] = (int)v.y;
+			v = v + (f2){half_signed(v.x), half_signed(v.y)};
+			q[zz[8 * y + 2 * j]] = v.x;
+			q[zz[8 * y + 2 * j + 1]] = v.y;
 		}
 	uint32_t *o = reinterpret_cast<uint32_t *>(dst);
 #pragma unroll
 	for (int k = 0; k < 8; ++k) {
 		uint4 w;
-		w.x = (uint32_t)(uint16_t)q[8 * k + 0] | ((uint32_t)(uint16_t)q[8 * k + 1] << 16);
-		w.y = (uint32_t)(uint16_t)q[8 * k + 2] | ((uint32_t)(uint16_t)q[8 * k + 3] << 16);
-		w.z = (uint32_t)(uint16_t)q[8 * k + 4] | ((uint32_t)(uint16_t)q[8 * k + 5] << 16);
-		w.w = (uint32_t)(uint16_t)q[8 * k + 6] | ((uint32_t)(uint16_t)q[8 * k + 7] << 16);
+		w.x = cvt_pack_i16(q[8 * k + 0], q[8 * k + 1]);
+		w.y = cvt_pack_i16(q[8 * k + 2], q[8 * k + 3]);
+		w.z = cvt_pack_i16(q[8 * k + 4], q[8 * k + 5]);
+		w.w = cvt_pack_i16(q[8 * k + 6], q[8 * k + 7]);
 		/* SWZ >= 0: 16-byte chunk k of the unit lands at chunk k ^ swz (LDS staging, see k_encode420) */
 		*reinterpret_cast<uint4 *>(o + 4 * (SWZ >= 0 ? (k ^ swz) : k)) = w;
 	}
