@@ -1029,7 +1029,7 @@ __device__ __forceinline__ void strip_row_packed(const ColorK &K, uint32_t cb4, 
  * full width and half height (resample_row_v_2, codec/jpeg.c:1774-1782).  Vertically nothing changes (row pairs (2C-1, 2C) on chroma
  * rows C-1 and C, saved rows, halo block rows at the band edges); horizontally there is no neighbourhood: a strip's chroma is one
  * dword per row and (3 near + far + 2) >> 2 runs on four samples at once in 16-bit lanes (rs_v2). */
-template <int NOUT, bool WIDE, bool B8, bool H2>
+template <int NOUT, bool WIDE, bool B8, bool H2, int NT>
 __device__ __forceinline__ void fused_band(const DevImage *__restrict__ imgs, const WorkBand *__restrict__ work, const uint8_t *__restrict__ coef,
 														 uint8_t *__restrict__ outbase)
 {
@@ -1072,7 +1072,7 @@ __device__ __forceinline__ void fused_band(const DevImage *__restrict__ imgs, co
 
 	/* ---- chroma-only IDCT of block row mc, keeping sample row 7 (keep != 0) or 0 in dstCb/dstCr (halo rows) */
 	auto chroma_halo = [&](int mc, int keep, uint8_t *dstCb, uint8_t *dstCr) {
-		for (int ww = wave; ww < 2 * nCw; ww += MIJ_F420_NT / 64) {
+		for (int ww = wave; ww < 2 * nCw; ww += NT / 64) {
 			const int comp = ww < nCw ? 1 : 2;
 			const int bx = (comp == 1 ? ww : ww - nCw) * 64 + lane;
 			if (bx < bwC) {
@@ -1160,15 +1160,15 @@ __device__ __forceinline__ void fused_band(const DevImage *__restrict__ imgs, co
 			if (doA)
 				strip_row<NOUT>(KC, KC.wAk, KC.wAk1, vb0, vb1, vb2, vr0, vr1, vr2, in.yA, out + (offA + xo));
 		};
-		if (MIJ_F420_NT >= 512) { /* one strip per thread and iteration: a 1080p row is 480 strips */
-			for (int sa = tid; sa < nfast; sa += MIJ_F420_NT) {
+		if (NT >= 512) { /* one strip per thread and iteration: a 1080p row is 480 strips */
+			for (int sa = tid; sa < nfast; sa += NT) {
 				StripIn ia;
 				load_strip(sa, ia);
 				do_strip(sa, ia);
 			}
 		} else
-		for (int base = 0; base < nfast; base += 2 * MIJ_F420_NT) {
-			const int sa = base + tid, sb = sa + MIJ_F420_NT;
+		for (int base = 0; base < nfast; base += 2 * NT) {
+			const int sa = base + tid, sb = sa + NT;
 			StripIn ia, ib;
 			load_strip(min(sa, nfast - 1), ia);
 			load_strip(min(sb, nfast - 1), ib);
@@ -1178,7 +1178,7 @@ __device__ __forceinline__ void fused_band(const DevImage *__restrict__ imgs, co
 				do_strip(sb, ib);
 		}
 		/* the rest (partial last strip, unaligned widths): careful per-pixel path */
-		for (int s = nfast + tid; s < nstrip; s += MIJ_F420_NT) {
+		for (int s = nfast + tid; s < nstrip; s += NT) {
 			const int x0 = 4 * s, xe = min(x0 + 4, W);
 			for (int x = x0; x < xe; ++x) {
 				if (doA)
@@ -1197,7 +1197,7 @@ __device__ __forceinline__ void fused_band(const DevImage *__restrict__ imgs, co
 	for (int m = m0; m < m1; ++m) {
 		__syncthreads(); /* previous phase B (and the prologue) done with the planes / save buffers */
 		/* ---- phase A: IDCT of MCU row m, one block per lane, component uniform per wave */
-		for (int ww = wave; ww < nYw + 2 * nCw; ww += MIJ_F420_NT / 64) {
+		for (int ww = wave; ww < nYw + 2 * nCw; ww += NT / 64) {
 			uint4 c[8];
 			uint2 rows[8];
 			if (ww < nYw) {
@@ -1252,9 +1252,9 @@ __device__ __forceinline__ void fused_band(const DevImage *__restrict__ imgs, co
 		/* keep the last rows of this MCU row for the next step (other save buffer: no extra barrier) */
 		{
 			const int nv = sv ^ 1;
-			for (int i = tid; i < YP / 4; i += MIJ_F420_NT)
+			for (int i = tid; i < YP / 4; i += NT)
 				reinterpret_cast<uint32_t *>(saveY + nv * YP)[i] = reinterpret_cast<const uint32_t *>(sY + 15 * YP)[i];
-			for (int i = tid; i < CP / 4; i += MIJ_F420_NT) {
+			for (int i = tid; i < CP / 4; i += NT) {
 				reinterpret_cast<uint32_t *>(saveCb + nv * CP)[i] = reinterpret_cast<const uint32_t *>(sCb + 7 * CP)[i];
 				reinterpret_cast<uint32_t *>(saveCr + nv * CP)[i] = reinterpret_cast<const uint32_t *>(sCr + 7 * CP)[i];
 			}
@@ -1284,15 +1284,46 @@ template <int NOUT, bool WIDE, bool B8 = false>
 __global__ __launch_bounds__(MIJ_F420_NT) MIJ_F420_ATTR void k_fused420(const DevImage *__restrict__ imgs, const WorkBand *__restrict__ work, const uint8_t *__restrict__ coef,
 																  uint8_t *__restrict__ outbase)
 {
-	fused_band<NOUT, WIDE, B8, true>(imgs, work, coef, outbase);
+	fused_band<NOUT, WIDE, B8, true, MIJ_F420_NT>(imgs, work, coef, outbase);
 }
 
-/* h1v2 (4:4:0): see fused_band, H2 = false.  LDS 304 * mcu_x bytes. */
+/* The same kernel with eight waves per workgroup, for pictures whose row of MCUs leaves room for only one or two workgroups in a CU's
+ * LDS (448 bytes per MCU column: wider than about 2100 pixels): measured per 0.53 Gpix of pictures resident in HBM, 256 -> 512 threads:
+ * 2560 x 1440 0.799 -> 0.732 ms, 3840 x 2160 0.970 -> 0.809, 5120 x 2880 0.941 -> 0.739; 1920 x 1080 and narrower lose 1-15 % and stay
+ * with four waves (tools/bench_sizes.py, profiles/r02zz_band_threads.txt). */
+#ifndef MIJ_F420W_NT
+#define MIJ_F420W_NT 512
+#endif
+template <int NOUT, bool WIDE, bool B8 = false>
+__global__ __launch_bounds__(MIJ_F420W_NT) void k_fused420w(const DevImage *__restrict__ imgs, const WorkBand *__restrict__ work, const uint8_t *__restrict__ coef,
+																				 uint8_t *__restrict__ outbase)
+{
+	fused_band<NOUT, WIDE, B8, true, MIJ_F420W_NT>(imgs, work, coef, outbase);
+}
+
+/* ... and with sixteen waves where only ONE workgroup fits (wider than about 2900 pixels: 3840 x 2160 0.806 -> 0.722 ms, 5120 x 2880
+ * 0.739 -> 0.70 against the eight-wave form; 2560 x 1440, where two fit, loses 13 % with it) */
+#define MIJ_F420X_NT 1024
+template <int NOUT, bool WIDE, bool B8 = false>
+__global__ __launch_bounds__(MIJ_F420X_NT) void k_fused420x(const DevImage *__restrict__ imgs, const WorkBand *__restrict__ work, const uint8_t *__restrict__ coef,
+																				 uint8_t *__restrict__ outbase)
+{
+	fused_band<NOUT, WIDE, B8, true, MIJ_F420X_NT>(imgs, work, coef, outbase);
+}
+
+/* h1v2 (4:4:0): see fused_band, H2 = false.  LDS 304 * mcu_x bytes: a 1080p row takes 73 KB, two workgroups per CU, and goes through the
+ * eight-wave form like the wide 4:2:0 pictures above (0.753 -> 0.654 ms per 256 images, 0.62 -> 0.71 of the roofline). */
 template <int NOUT, bool WIDE, bool B8 = false>
 __global__ __launch_bounds__(MIJ_F420_NT) void k_fused440(const DevImage *__restrict__ imgs, const WorkBand *__restrict__ work, const uint8_t *__restrict__ coef,
 																			 uint8_t *__restrict__ outbase)
 {
-	fused_band<NOUT, WIDE, B8, false>(imgs, work, coef, outbase);
+	fused_band<NOUT, WIDE, B8, false, MIJ_F420_NT>(imgs, work, coef, outbase);
+}
+template <int NOUT, bool WIDE, bool B8 = false>
+__global__ __launch_bounds__(MIJ_F420W_NT) void k_fused440w(const DevImage *__restrict__ imgs, const WorkBand *__restrict__ work, const uint8_t *__restrict__ coef,
+																				 uint8_t *__restrict__ outbase)
+{
+	fused_band<NOUT, WIDE, B8, false, MIJ_F420W_NT>(imgs, work, coef, outbase);
 }
 
 /* ------------------------------------------------------------------ fused h2v1 (4:2:2) YCbCr kernel

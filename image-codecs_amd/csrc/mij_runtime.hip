@@ -92,7 +92,10 @@ extern "C" int mij_ctx_create(int device, mij_ctx **out)
 	MIJ_LDS_ATTR((K<3, false, false>)); MIJ_LDS_ATTR((K<3, true, false>)); MIJ_LDS_ATTR((K<4, false, false>)); MIJ_LDS_ATTR((K<4, true, false>)); \
 	MIJ_LDS_ATTR((K<3, false, true>)); MIJ_LDS_ATTR((K<3, true, true>)); MIJ_LDS_ATTR((K<4, false, true>)); MIJ_LDS_ATTR((K<4, true, true>))
 	MIJ_LDS_ATTR8(k_fused420);
+	MIJ_LDS_ATTR8(k_fused420w);
+	MIJ_LDS_ATTR8(k_fused420x);
 	MIJ_LDS_ATTR8(k_fused440);
+	MIJ_LDS_ATTR8(k_fused440w);
 	MIJ_LDS_ATTR8(k_fused422);
 #undef MIJ_LDS_ATTR8
 #undef MIJ_LDS_ATTR
@@ -143,7 +146,7 @@ struct Slot {
 
 /* kernel families of a launch plan, in launch order */
 /* MK_RS_FAST + RS_*: pass 2 compiled per resampler (k_resample_fast); list index [n_out == 4][YCbCr colour][0] */
-enum { MK_PLANES = 0, MK_RESAMPLE, MK_RS_FAST, MK_420 = MK_RS_FAST + RS_KINDS, MK_422, MK_444, MK_GREY, MK_440, MK_KINDS };
+enum { MK_PLANES = 0, MK_RESAMPLE, MK_RS_FAST, MK_420 = MK_RS_FAST + RS_KINDS, MK_422, MK_444, MK_GREY, MK_440, MK_420W, MK_440W /* k_fused420w / k_fused440w: 512 threads, wide pictures */, MK_420X /* 1024 threads: one workgroup per CU */, MK_KINDS };
 struct Work4 { /* WorkBand and WorkIdct are both four u32 */
 	uint32_t a, b, c, d;
 };
@@ -711,6 +714,12 @@ static int grow_pair(T *&h, T *&d, size_t &cap, size_t need)
 }
 
 static size_t fused420_lds(const mij_image_desc &d) { return (size_t)d.mcu_x * (16 * 16 + 2 * 8 * 8 + 2 * 16 + 4 * 8); }
+/* fewer than three workgroups of the band kernel fit a CU's LDS: the eight-wave form (k_fused420w) */
+static bool fused420_one(const mij_batch *b, const mij_image_desc &d) { return fused420_ok(b, d) && 2 * fused420_lds(d) > (size_t)b->ctx->max_dyn_lds; } /* k_fused420x */
+static bool fused420_wide(const mij_batch *b, const mij_image_desc &d) { return fused420_ok(b, d) && 3 * fused420_lds(d) > (size_t)b->ctx->max_dyn_lds && !fused420_one(b, d); }
+static bool fused420_narrow(const mij_batch *b, const mij_image_desc &d) { return fused420_ok(b, d) && !fused420_wide(b, d) && !fused420_one(b, d); }
+static bool fused440_wide(const mij_batch *b, const mij_image_desc &d) { return fused440_ok(b, d) && 3 * fused440_lds(d) > (size_t)b->ctx->max_dyn_lds; }
+static bool fused440_narrow(const mij_batch *b, const mij_image_desc &d) { return fused440_ok(b, d) && !fused440_wide(b, d); }
 
 extern "C" int mij_batch_upload(mij_batch *b)
 {
@@ -753,7 +762,7 @@ extern "C" int mij_batch_upload(mij_batch *b)
 	 * band re-does two chroma block rows of IDCT as halo.  Pick the bands-per-image (1..16) that
 	 * minimises  rounds x (1 + halo share)  per unit of work; measured on MI355X: 1024 x 1080p ->
 	 * 6 bands (6144 workgroups = 8.0 rounds of 768) beats 4 (5.33 rounds) by ~1.5 %. */
-	auto auto_bands = [&](bool (*ok)(const mij_batch *, const mij_image_desc &), size_t (*lds_of)(const mij_image_desc &)) -> int {
+	auto auto_bands = [&](bool (*ok)(const mij_batch *, const mij_image_desc &), size_t (*lds_of)(const mij_image_desc &), int nt) -> int {
 		size_t n_fused = 0, mcu_rows_sum = 0, lds_max = 0;
 		for (size_t i = 0; i < n; ++i)
 			if (ok(b, b->slots[i].desc)) {
@@ -766,7 +775,7 @@ extern "C" int mij_batch_upload(mij_batch *b)
 		int nb_best = 1;
 		if (n_fused) {
 			size_t per_cu = lds_max ? (size_t)b->ctx->max_dyn_lds / lds_max : 1;
-			const size_t by_waves = 4 * MIJ_F420_WAVES / (MIJ_F420_NT / 64); /* waves per SIMD by registers x four SIMDs */
+			const size_t by_waves = 4 * MIJ_F420_WAVES / ((size_t)nt / 64); /* waves per SIMD by registers x four SIMDs */
 			per_cu = per_cu < 1 ? 1 : (per_cu > by_waves ? by_waves : per_cu);
 			const size_t slots = (size_t)cu * per_cu;
 			const double avg_rows = (double)mcu_rows_sum / (double)n_fused;
@@ -788,7 +797,9 @@ extern "C" int mij_batch_upload(mij_batch *b)
 		}
 		return nb_best;
 	};
-	const int auto_nb = auto_bands(fused420_ok, fused420_lds), auto_nb440 = auto_bands(fused440_ok, fused440_lds);
+	const int auto_nb = auto_bands(fused420_narrow, fused420_lds, MIJ_F420_NT), auto_nb440 = auto_bands(fused440_narrow, fused440_lds, MIJ_F420_NT);
+	const int auto_nbx = auto_bands(fused420_one, fused420_lds, MIJ_F420X_NT);
+	const int auto_nbw = auto_bands(fused420_wide, fused420_lds, MIJ_F420W_NT), auto_nb440w = auto_bands(fused440_wide, fused440_lds, MIJ_F420W_NT);
 
 	for (size_t i = 0; i < n; ++i) {
 		Slot &s = b->slots[i];
@@ -810,14 +821,15 @@ extern "C" int mij_batch_upload(mij_batch *b)
 		if (fused420_ok(b, d)) {
 			s.path = 1;
 			/* split mcu_y into nb equal-ish bands */
-			int nb = b->band_rows > 0 ? (d.mcu_y + b->band_rows - 1) / b->band_rows : auto_nb;
+			const int mk = fused420_one(b, d) ? MK_420X : (fused420_wide(b, d) ? MK_420W : MK_420);
+			int nb = b->band_rows > 0 ? (d.mcu_y + b->band_rows - 1) / b->band_rows : (mk == MK_420X ? auto_nbx : (mk == MK_420W ? auto_nbw : auto_nb));
 			if (nb > d.mcu_y)
 				nb = d.mcu_y;
 			if (nb < 1)
 				nb = 1;
 			for (int k = 0; k < nb; ++k)
-				lists[MK_420][o4][wide][b8].push_back(Work4{(uint32_t)i, (uint32_t)((long)d.mcu_y * k / nb), (uint32_t)((long)d.mcu_y * (k + 1) / nb), 0u});
-			size_t &l = lds_need[MK_420][o4][wide][b8];
+				lists[mk][o4][wide][b8].push_back(Work4{(uint32_t)i, (uint32_t)((long)d.mcu_y * k / nb), (uint32_t)((long)d.mcu_y * (k + 1) / nb), 0u});
+			size_t &l = lds_need[mk][o4][wide][b8];
 			l = fused420_lds(d) > l ? fused420_lds(d) : l;
 		} else if (fused_grey_ok(b, d)) {
 			s.path = 5;
@@ -832,13 +844,14 @@ extern "C" int mij_batch_upload(mij_batch *b)
 				lists[MK_422][o4][wide][b8].push_back(Work4{(uint32_t)i, (uint32_t)((long)d.mcu_y * k / nb), (uint32_t)((long)d.mcu_y * (k + 1) / nb), 0u});
 		} else if (fused440_ok(b, d)) {
 			s.path = 6;
-			size_t &l = lds_need[MK_440][o4][wide][b8];
+			const int mk = fused440_wide(b, d) ? MK_440W : MK_440;
+			size_t &l = lds_need[mk][o4][wide][b8];
 			l = fused440_lds(d) > l ? fused440_lds(d) : l;
 			/* band count by rounds of co-resident workgroups, as for 4:2:0 */
-			int nb = b->band_rows > 0 ? (d.mcu_y + b->band_rows - 1) / b->band_rows : auto_nb440;
+			int nb = b->band_rows > 0 ? (d.mcu_y + b->band_rows - 1) / b->band_rows : (mk == MK_440W ? auto_nb440w : auto_nb440);
 			nb = nb > d.mcu_y ? d.mcu_y : (nb < 1 ? 1 : nb);
 			for (int k = 0; k < nb; ++k)
-				lists[MK_440][o4][wide][b8].push_back(Work4{(uint32_t)i, (uint32_t)((long)d.mcu_y * k / nb), (uint32_t)((long)d.mcu_y * (k + 1) / nb), 0u});
+				lists[mk][o4][wide][b8].push_back(Work4{(uint32_t)i, (uint32_t)((long)d.mcu_y * k / nb), (uint32_t)((long)d.mcu_y * (k + 1) / nb), 0u});
 		} else if (fused444_ok(b, d)) {
 			s.path = 3;
 			per_blocks(lists[MK_444][o4][wide][b8], 0);
@@ -993,17 +1006,26 @@ extern "C" int mij_batch_launch(mij_batch *b)
 		return set_err(MIJ_E_STATE, "mij_batch_launch before mij_batch_upload");
 	HIP_TRY(hipSetDevice(b->ctx->device));
 	for (const auto &L : b->launches) { /* in family order: pass 2 of the two-pass family runs behind every pass-1 launch */
-		const dim3 grid((unsigned)L.count), block((L.kind == MK_420 || L.kind == MK_440) ? MIJ_F420_NT : 256);
+		const dim3 grid((unsigned)L.count), block((L.kind == MK_420 || L.kind == MK_440) ? MIJ_F420_NT : ((L.kind == MK_420W || L.kind == MK_440W) ? MIJ_F420W_NT : (L.kind == MK_420X ? MIJ_F420X_NT : 256)));
 		const Work4 *wk = b->d_work + L.first;
 		switch (L.kind) {
 		case MK_420:
 			MIJ_LAUNCH_NWB(k_fused420, WorkBand, MIJ_COEF_OUT);
+			break;
+		case MK_420W:
+			MIJ_LAUNCH_NWB(k_fused420w, WorkBand, MIJ_COEF_OUT);
+			break;
+		case MK_420X:
+			MIJ_LAUNCH_NWB(k_fused420x, WorkBand, MIJ_COEF_OUT);
 			break;
 		case MK_422:
 			MIJ_LAUNCH_NWB(k_fused422, WorkBand, MIJ_COEF_OUT);
 			break;
 		case MK_440:
 			MIJ_LAUNCH_NWB(k_fused440, WorkBand, MIJ_COEF_OUT);
+			break;
+		case MK_440W:
+			MIJ_LAUNCH_NWB(k_fused440w, WorkBand, MIJ_COEF_OUT);
 			break;
 		case MK_444:
 			MIJ_LAUNCH_NWB(k_fused444, WorkIdct, MIJ_COEF_OUT);

@@ -211,6 +211,33 @@ def test_wide_image_uses_whole_lds_or_two_pass(ica, oracle, gpu_ctx):
         b.close()
 
 
+def test_band_kernels_by_workgroups_per_cu(ica, oracle, gpu_ctx, monkeypatch):
+    """The band kernels come with four, eight or sixteen waves per workgroup, chosen by how many workgroups of a picture's width
+    fit a CU's LDS (k_fused420 / k_fused420w / k_fused420x, k_fused440 / k_fused440w): widths on both sides of each switch,
+    odd sizes, both output widths, one band and many, mixed in one batch -- all equal to the CPU checker."""
+    import helpers
+    datas = []
+    for w in (1904, 1920, 2288, 2304, 2320, 2848, 2864, 3840, 4097):  # 4:2:0: 448 B per 16 pixels; 3 x fit up to 1904, 2 x up to 2848
+        datas.append(ica.synth_jpeg(w, 70, w & 7, 90))
+    plan, du = ica.host_transform(ica.synth_rgb(2160, 64, 3), 95)  # 4:4:0 layouts: 304 B per 8 pixels; 3 x fit up to 1432, 2 x up to 2152
+    plan2, du2 = ica.host_transform(ica.synth_rgb(1424, 64, 4), 95)
+    datas.append(helpers.baseline_layout_from_444(plan, du, [(1, 2), (1, 1), (1, 1)], -1))
+    datas.append(helpers.baseline_layout_from_444(plan2, du2, [(1, 2), (1, 1), (1, 1)], -1))
+    for req in (3, 4):
+        wants = [oracle.load(d, req)[1] for d in datas]
+        for band_rows in (0, 1, 2):
+            if band_rows:
+                monkeypatch.setenv("MIJ_BAND_ROWS", str(band_rows))
+            else:
+                monkeypatch.delenv("MIJ_BAND_ROWS", raising=False)
+            b, slots = _batch_for(ica, gpu_ctx, datas, req)
+            b.submit()
+            for s, want, d in zip(slots, wants, datas):
+                assert b.slot_path(s) in (1, 6), b.slot_path(s)
+                assert np.array_equal(b.fetch(s), want), (s, req, band_rows, want.shape)
+            b.close()
+
+
 def test_progressive_and_444(ica, oracle, gpu_ctx, golden):
     """Config-4 shape at reduced size: progressive 4:4:4 (multi-scan coefficient re-staging on the
     host, register-resident 4:4:4 kernel on the GPU), plus larger libjpeg-made fixtures."""

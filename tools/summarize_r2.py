@@ -36,7 +36,7 @@ LEGS = [  # (traffic key, kernel substring, which dispatches, algorithmic bytes,
     ("k_encode420_%d" % n_main, "k_encode420", "last", legs.get("config5", {}).get("algorithmic_bytes_per_launch"), legs.get("config5", {}).get("kernel_ms_per_launch")),
     ("k_fused422_compact_512", "k_fused422<3, false, true>", "last", legs.get("h2v1", {}).get("algorithmic_bytes_per_launch"), legs.get("h2v1", {}).get("kernel_ms_per_launch")),
     ("k_encode444_512", "k_encode444", "last", legs.get("config5_q95_444", {}).get("algorithmic_bytes_per_launch"), legs.get("config5_q95_444", {}).get("kernel_ms_per_launch")),
-    ("k_fused440_compact_256", "k_fused440<3, false, true>", "last", legs.get("two_pass", {}).get("h1v2_440", {}).get("algorithmic_bytes_per_launch"),
+    ("k_fused440_compact_256", "k_fused440w<3, false, true>", "last", legs.get("two_pass", {}).get("h1v2_440", {}).get("algorithmic_bytes_per_launch"),
      legs.get("two_pass", {}).get("h1v2_440", {}).get("ms_per_launch")),
 ]
 
