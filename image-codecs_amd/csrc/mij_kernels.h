@@ -1311,6 +1311,24 @@ __global__ __launch_bounds__(MIJ_F420X_NT) void k_fused420x(const DevImage *__re
 	fused_band<NOUT, WIDE, B8, true, MIJ_F420X_NT>(imgs, work, coef, outbase);
 }
 
+/* ... and with two waves / one wave for narrow pictures, whose row of MCUs does not fill four: per 0.53 Gpix resident, 256 / 128 / 64
+ * threads: 64 x 64 0.588 / 0.448 / 0.347 ms, 256 x 256 1.18 / 0.93 / 0.76, 512 x 512 0.80 / 0.68 / 0.75, 800 x 600 0.84 / 0.79 / 0.99,
+ * 1024 x 768 0.66 / 0.72 / 0.91 (profiles/r02zz_band_threads.txt): one wave up to 24 MCU columns (384 pixels), two up to 56 (896). */
+#define MIJ_F420S_NT 128
+#define MIJ_F420T_NT 64
+template <int NOUT, bool WIDE, bool B8 = false>
+__global__ __launch_bounds__(MIJ_F420S_NT) void k_fused420s(const DevImage *__restrict__ imgs, const WorkBand *__restrict__ work, const uint8_t *__restrict__ coef,
+																				 uint8_t *__restrict__ outbase)
+{
+	fused_band<NOUT, WIDE, B8, true, MIJ_F420S_NT>(imgs, work, coef, outbase);
+}
+template <int NOUT, bool WIDE, bool B8 = false>
+__global__ __launch_bounds__(MIJ_F420T_NT) void k_fused420t(const DevImage *__restrict__ imgs, const WorkBand *__restrict__ work, const uint8_t *__restrict__ coef,
+																				 uint8_t *__restrict__ outbase)
+{
+	fused_band<NOUT, WIDE, B8, true, MIJ_F420T_NT>(imgs, work, coef, outbase);
+}
+
 /* h1v2 (4:4:0): see fused_band, H2 = false.  LDS 304 * mcu_x bytes: a 1080p row takes 73 KB, two workgroups per CU, and goes through the
  * eight-wave form like the wide 4:2:0 pictures above (0.753 -> 0.654 ms per 256 images, 0.62 -> 0.71 of the roofline). */
 template <int NOUT, bool WIDE, bool B8 = false>

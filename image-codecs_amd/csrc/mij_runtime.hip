@@ -94,6 +94,8 @@ extern "C" int mij_ctx_create(int device, mij_ctx **out)
 	MIJ_LDS_ATTR8(k_fused420);
 	MIJ_LDS_ATTR8(k_fused420w);
 	MIJ_LDS_ATTR8(k_fused420x);
+	MIJ_LDS_ATTR8(k_fused420s);
+	MIJ_LDS_ATTR8(k_fused420t);
 	MIJ_LDS_ATTR8(k_fused440);
 	MIJ_LDS_ATTR8(k_fused440w);
 	MIJ_LDS_ATTR8(k_fused422);
@@ -146,7 +148,7 @@ struct Slot {
 
 /* kernel families of a launch plan, in launch order */
 /* MK_RS_FAST + RS_*: pass 2 compiled per resampler (k_resample_fast); list index [n_out == 4][YCbCr colour][0] */
-enum { MK_PLANES = 0, MK_RESAMPLE, MK_RS_FAST, MK_420 = MK_RS_FAST + RS_KINDS, MK_422, MK_444, MK_GREY, MK_440, MK_420W, MK_440W /* k_fused420w / k_fused440w: 512 threads, wide pictures */, MK_420X /* 1024 threads: one workgroup per CU */, MK_KINDS };
+enum { MK_PLANES = 0, MK_RESAMPLE, MK_RS_FAST, MK_420 = MK_RS_FAST + RS_KINDS, MK_422, MK_444, MK_GREY, MK_440, MK_420W, MK_440W /* k_fused420w / k_fused440w: 512 threads, wide pictures */, MK_420X /* 1024 threads: one workgroup per CU */, MK_420S, MK_420T /* 128 / 64 threads: narrow pictures */, MK_KINDS };
 struct Work4 { /* WorkBand and WorkIdct are both four u32 */
 	uint32_t a, b, c, d;
 };
@@ -715,11 +717,25 @@ static int grow_pair(T *&h, T *&d, size_t &cap, size_t need)
 
 static size_t fused420_lds(const mij_image_desc &d) { return (size_t)d.mcu_x * (16 * 16 + 2 * 8 * 8 + 2 * 16 + 4 * 8); }
 /* fewer than three workgroups of the band kernel fit a CU's LDS: the eight-wave form (k_fused420w) */
-static bool fused420_one(const mij_batch *b, const mij_image_desc &d) { return fused420_ok(b, d) && 2 * fused420_lds(d) > (size_t)b->ctx->max_dyn_lds; } /* k_fused420x */
-static bool fused420_wide(const mij_batch *b, const mij_image_desc &d) { return fused420_ok(b, d) && 3 * fused420_lds(d) > (size_t)b->ctx->max_dyn_lds && !fused420_one(b, d); }
-static bool fused420_narrow(const mij_batch *b, const mij_image_desc &d) { return fused420_ok(b, d) && !fused420_wide(b, d) && !fused420_one(b, d); }
+/* which form of the band kernel a 4:2:0 picture takes (-1: none): by the workgroups of its width that fit a CU's LDS, and for narrow
+ * pictures by how many waves a row of MCUs keeps busy (mij_kernels.h, k_fused420w / x / s / t) */
+static int fused420_kind(const mij_batch *b, const mij_image_desc &d)
+{
+	if (!fused420_ok(b, d))
+		return -1;
+	const size_t lds = fused420_lds(d), cap = (size_t)b->ctx->max_dyn_lds;
+	if (2 * lds > cap)
+		return MK_420X;
+	if (3 * lds > cap)
+		return MK_420W;
+	return d.mcu_x <= 24 ? MK_420T : (d.mcu_x <= 56 ? MK_420S : MK_420);
+}
+static int band_threads(int kind)
+{
+	return kind == MK_420X ? MIJ_F420X_NT : ((kind == MK_420W || kind == MK_440W) ? MIJ_F420W_NT : (kind == MK_420S ? MIJ_F420S_NT : (kind == MK_420T ? MIJ_F420T_NT : MIJ_F420_NT)));
+}
 static bool fused440_wide(const mij_batch *b, const mij_image_desc &d) { return fused440_ok(b, d) && 3 * fused440_lds(d) > (size_t)b->ctx->max_dyn_lds; }
-static bool fused440_narrow(const mij_batch *b, const mij_image_desc &d) { return fused440_ok(b, d) && !fused440_wide(b, d); }
+static int fused440_kind(const mij_batch *b, const mij_image_desc &d) { return !fused440_ok(b, d) ? -1 : (fused440_wide(b, d) ? MK_440W : MK_440); }
 
 extern "C" int mij_batch_upload(mij_batch *b)
 {
@@ -762,10 +778,11 @@ extern "C" int mij_batch_upload(mij_batch *b)
 	 * band re-does two chroma block rows of IDCT as halo.  Pick the bands-per-image (1..16) that
 	 * minimises  rounds x (1 + halo share)  per unit of work; measured on MI355X: 1024 x 1080p ->
 	 * 6 bands (6144 workgroups = 8.0 rounds of 768) beats 4 (5.33 rounds) by ~1.5 %. */
-	auto auto_bands = [&](bool (*ok)(const mij_batch *, const mij_image_desc &), size_t (*lds_of)(const mij_image_desc &), int nt) -> int {
+	auto auto_bands = [&](int (*kind_of)(const mij_batch *, const mij_image_desc &), int kind, size_t (*lds_of)(const mij_image_desc &)) -> int {
+		const int nt = band_threads(kind);
 		size_t n_fused = 0, mcu_rows_sum = 0, lds_max = 0;
 		for (size_t i = 0; i < n; ++i)
-			if (ok(b, b->slots[i].desc)) {
+			if (kind_of(b, b->slots[i].desc) == kind) {
 				const mij_image_desc &d = b->slots[i].desc;
 				++n_fused;
 				mcu_rows_sum += (size_t)d.mcu_y;
@@ -797,9 +814,13 @@ extern "C" int mij_batch_upload(mij_batch *b)
 		}
 		return nb_best;
 	};
-	const int auto_nb = auto_bands(fused420_narrow, fused420_lds, MIJ_F420_NT), auto_nb440 = auto_bands(fused440_narrow, fused440_lds, MIJ_F420_NT);
-	const int auto_nbx = auto_bands(fused420_one, fused420_lds, MIJ_F420X_NT);
-	const int auto_nbw = auto_bands(fused420_wide, fused420_lds, MIJ_F420W_NT), auto_nb440w = auto_bands(fused440_wide, fused440_lds, MIJ_F420W_NT);
+	int auto_nb[MK_KINDS];
+	for (int k = 0; k < MK_KINDS; ++k)
+		auto_nb[k] = 1;
+	for (int k : {MK_420, MK_420W, MK_420X, MK_420S, MK_420T})
+		auto_nb[k] = auto_bands(fused420_kind, k, fused420_lds);
+	for (int k : {MK_440, MK_440W})
+		auto_nb[k] = auto_bands(fused440_kind, k, fused440_lds);
 
 	for (size_t i = 0; i < n; ++i) {
 		Slot &s = b->slots[i];
@@ -821,8 +842,8 @@ extern "C" int mij_batch_upload(mij_batch *b)
 		if (fused420_ok(b, d)) {
 			s.path = 1;
 			/* split mcu_y into nb equal-ish bands */
-			const int mk = fused420_one(b, d) ? MK_420X : (fused420_wide(b, d) ? MK_420W : MK_420);
-			int nb = b->band_rows > 0 ? (d.mcu_y + b->band_rows - 1) / b->band_rows : (mk == MK_420X ? auto_nbx : (mk == MK_420W ? auto_nbw : auto_nb));
+			const int mk = fused420_kind(b, d);
+			int nb = b->band_rows > 0 ? (d.mcu_y + b->band_rows - 1) / b->band_rows : auto_nb[mk];
 			if (nb > d.mcu_y)
 				nb = d.mcu_y;
 			if (nb < 1)
@@ -844,11 +865,11 @@ extern "C" int mij_batch_upload(mij_batch *b)
 				lists[MK_422][o4][wide][b8].push_back(Work4{(uint32_t)i, (uint32_t)((long)d.mcu_y * k / nb), (uint32_t)((long)d.mcu_y * (k + 1) / nb), 0u});
 		} else if (fused440_ok(b, d)) {
 			s.path = 6;
-			const int mk = fused440_wide(b, d) ? MK_440W : MK_440;
+			const int mk = fused440_kind(b, d);
 			size_t &l = lds_need[mk][o4][wide][b8];
 			l = fused440_lds(d) > l ? fused440_lds(d) : l;
 			/* band count by rounds of co-resident workgroups, as for 4:2:0 */
-			int nb = b->band_rows > 0 ? (d.mcu_y + b->band_rows - 1) / b->band_rows : (mk == MK_440W ? auto_nb440w : auto_nb440);
+			int nb = b->band_rows > 0 ? (d.mcu_y + b->band_rows - 1) / b->band_rows : auto_nb[mk];
 			nb = nb > d.mcu_y ? d.mcu_y : (nb < 1 ? 1 : nb);
 			for (int k = 0; k < nb; ++k)
 				lists[mk][o4][wide][b8].push_back(Work4{(uint32_t)i, (uint32_t)((long)d.mcu_y * k / nb), (uint32_t)((long)d.mcu_y * (k + 1) / nb), 0u});
@@ -1006,7 +1027,7 @@ extern "C" int mij_batch_launch(mij_batch *b)
 		return set_err(MIJ_E_STATE, "mij_batch_launch before mij_batch_upload");
 	HIP_TRY(hipSetDevice(b->ctx->device));
 	for (const auto &L : b->launches) { /* in family order: pass 2 of the two-pass family runs behind every pass-1 launch */
-		const dim3 grid((unsigned)L.count), block((L.kind == MK_420 || L.kind == MK_440) ? MIJ_F420_NT : ((L.kind == MK_420W || L.kind == MK_440W) ? MIJ_F420W_NT : (L.kind == MK_420X ? MIJ_F420X_NT : 256)));
+		const dim3 grid((unsigned)L.count), block((L.kind >= MK_420 && L.kind != MK_422 && L.kind != MK_444 && L.kind != MK_GREY) ? (unsigned)band_threads(L.kind) : 256u);
 		const Work4 *wk = b->d_work + L.first;
 		switch (L.kind) {
 		case MK_420:
@@ -1017,6 +1038,12 @@ extern "C" int mij_batch_launch(mij_batch *b)
 			break;
 		case MK_420X:
 			MIJ_LAUNCH_NWB(k_fused420x, WorkBand, MIJ_COEF_OUT);
+			break;
+		case MK_420S:
+			MIJ_LAUNCH_NWB(k_fused420s, WorkBand, MIJ_COEF_OUT);
+			break;
+		case MK_420T:
+			MIJ_LAUNCH_NWB(k_fused420t, WorkBand, MIJ_COEF_OUT);
 			break;
 		case MK_422:
 			MIJ_LAUNCH_NWB(k_fused422, WorkBand, MIJ_COEF_OUT);

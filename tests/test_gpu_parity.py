@@ -212,13 +212,15 @@ def test_wide_image_uses_whole_lds_or_two_pass(ica, oracle, gpu_ctx):
 
 
 def test_band_kernels_by_workgroups_per_cu(ica, oracle, gpu_ctx, monkeypatch):
-    """The band kernels come with four, eight or sixteen waves per workgroup, chosen by how many workgroups of a picture's width
-    fit a CU's LDS (k_fused420 / k_fused420w / k_fused420x, k_fused440 / k_fused440w): widths on both sides of each switch,
+    """The band kernels come with one, two, four, eight or sixteen waves per workgroup, chosen by the picture's width (narrow rows do
+    not fill four waves; of wide ones only two or one workgroups fit a CU's LDS: k_fused420t / s / - / w / x, k_fused440 / w): widths on both sides of each switch,
     odd sizes, both output widths, one band and many, mixed in one batch -- all equal to the CPU checker."""
     import helpers
     datas = []
     for w in (1904, 1920, 2288, 2304, 2320, 2848, 2864, 3840, 4097):  # 4:2:0: 448 B per 16 pixels; 3 x fit up to 1904, 2 x up to 2848
         datas.append(ica.synth_jpeg(w, 70, w & 7, 90))
+    for w, h in ((1, 1), (17, 9), (383, 40), (384, 33), (385, 50), (400, 16), (895, 30), (896, 47), (897, 20), (912, 64)):  # one wave up to 24 MCU columns, two up to 56
+        datas.append(ica.synth_jpeg(w, h, (w + h) & 7, 85))
     plan, du = ica.host_transform(ica.synth_rgb(2160, 64, 3), 95)  # 4:4:0 layouts: 304 B per 8 pixels; 3 x fit up to 1432, 2 x up to 2152
     plan2, du2 = ica.host_transform(ica.synth_rgb(1424, 64, 4), 95)
     datas.append(helpers.baseline_layout_from_444(plan, du, [(1, 2), (1, 1), (1, 1)], -1))

@@ -41,8 +41,9 @@ def main():
     ctx = ica.Context()
     oracle = helpers.Oracle()
     out = {}
-    for (w, h) in ((640, 480), (1280, 720), (1920, 1080), (2560, 1440), (3840, 2160), (5120, 2880), (7680, 4320)):
-        n = max(2, int(256 * 1920 * 1080 / (w * h)))
+    sizes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]] or [(640, 480), (1280, 720), (1920, 1080), (2560, 1440), (3840, 2160), (5120, 2880), (7680, 4320)]
+    for (w, h) in sizes:
+        n = min(16384, max(2, int(256 * 1920 * 1080 / (w * h))))
         data = ica.synth_jpeg(w, h, 0, 90)
         want = oracle.load(data, 3)[1]
         out["%dx%d" % (w, h)] = run(ctx, data, n, want)
