@@ -360,13 +360,28 @@ def leg_config5(ica, ctx, args, checker, quality=90, count=None):
             buf = np.zeros(W * H * 3, np.uint8)
             nb = fenc(buf.ctypes.data, buf.size, W, H, 3, np.ascontiguousarray(im).ctypes.data, quality)
             if not (nb > 0 and mine == bytes(buf[:nb])):
-                # say which side moved: the GPU's data units against the library's own host transform, and the checker against itself
-                host_units = ica.host_transform(im, quality)[1]
-                gpu_ok = bool(np.array_equal(enc.fetch(src[k]), host_units))
+                # say which side moved and whether it stays moved (this has happened twice, each time in the first process of a fresh box
+                # under rocprofv3 --kernel-trace --stats, never elsewhere: DESIGN.md section 8): the GPU's data units against the library's own
+                # host transform, the emitter on both, the checker against itself, the first byte that differs, the float rounding mode
+                # of this thread, and the whole comparison once more
+                import hashlib
+                want = bytes(buf[:max(nb, 0)])
+                plan_h, host_units = ica.host_transform(im, quality)
+                units1 = enc.fetch(src[k])
+                gpu_ok = bool(np.array_equal(units1, host_units))
+                mine_host = ica.emit_jpeg(plan_h, host_units)
+                mine_again = ica.emit_jpeg(enc.plan(src[k]), units1)
                 buf2 = np.zeros(W * H * 3, np.uint8)
                 nb2 = fenc(buf2.ctypes.data, buf2.size, W, H, 3, np.ascontiguousarray(im).ctypes.data, quality)
-                raise AssertionError("encoded stream %d differs from the CPU checker's (checker bytes %d, ours %d; GPU data units == host transform: %s; "
-                                     "checker repeatable: %s)" % (k, nb, len(mine), gpu_ok, nb2 == nb and bytes(buf2[:max(nb2, 0)]) == bytes(buf[:max(nb, 0)])))
+                first = next((i for i in range(min(len(mine), len(want))) if mine[i] != want[i]), min(len(mine), len(want)))
+                third = np.float32(1) / np.float32(3)
+                whole = ica.stbi_write_jpg_to_memory(im, quality)
+                raise AssertionError(
+                    "encoded stream %d differs from the CPU checker's (checker bytes %d, ours %d, first difference at byte %d; GPU data units == host transform: %s; "
+                    "units sha1 %s; emit(host units) == checker: %s; emit(GPU units) again == first emission: %s, == checker: %s; stbi_write_jpg_to_memory == checker: %s; "
+                    "checker repeatable: %s; float32 1/3 = %s)"
+                    % (k, nb, len(mine), first, gpu_ok, hashlib.sha1(np.ascontiguousarray(units1)).hexdigest()[:12], mine_host == want, mine_again == mine, mine_again == want,
+                       whole == want, nb2 == nb and bytes(buf2[:max(nb2, 0)]) == want, third.view(np.uint32)))
         assert np.array_equal(enc.fetch(n - 1), enc.fetch(src[(n - 1) % distinct]))
         n_warm = 0
         t_w = time.perf_counter()
