@@ -1382,8 +1382,8 @@ __device__ __forceinline__ void fused422_pixel(const uint8_t *yrow, const uint8_
 	store_rgb_px<NOUT>(dst + (size_t)x * NOUT, r, g, b);
 }
 
-template <int NOUT, bool WIDE, bool B8 = false>
-__global__ __launch_bounds__(256) void k_fused422(const DevImage *__restrict__ imgs, const WorkBand *__restrict__ work, const uint8_t *__restrict__ coef,
+template <int NOUT, bool WIDE, bool B8, int NT>
+__device__ __forceinline__ void fused422_band(const DevImage *__restrict__ imgs, const WorkBand *__restrict__ work, const uint8_t *__restrict__ coef,
 																  uint8_t *__restrict__ outbase)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -1418,7 +1418,7 @@ __global__ __launch_bounds__(256) void k_fused422(const DevImage *__restrict__ i
 	for (int m = (int)wk.m0; m < (int)wk.m1; ++m) {
 		__syncthreads(); /* previous phase B done with the planes */
 		/* ---- phase A: IDCT of MCU row m, one block per lane, component uniform per wave */
-		for (int ww = wave; ww < nYw + 2 * nCw; ww += 4) {
+		for (int ww = wave; ww < nYw + 2 * nCw; ww += NT / 64) {
 			uint4 c[8];
 			uint2 rows[8];
 			if (ww < nYw) {
@@ -1451,7 +1451,7 @@ __global__ __launch_bounds__(256) void k_fused422(const DevImage *__restrict__ i
 		for (int rr = 0; rr < rows_here; ++rr) {
 			const uint8_t *cbR = sCb + rr * CP, *crR = sCr + rr * CP, *yR = sY + rr * YP;
 			const uint32_t rowoff = (uint32_t)(8 * m + rr) * opitch;
-			for (int s0 = tid; s0 < nfast; s0 += 256) {
+			for (int s0 = tid; s0 < nfast; s0 += NT) {
 				const int i0 = 2 * s0;
 				const int d0 = (i0 - 1) >> 2; /* strip 0 reads the dword in front of the row (inside LDS); the edge fix discards it */
 				const uint32_t *pb = reinterpret_cast<const uint32_t *>(cbR) + d0, *pr = reinterpret_cast<const uint32_t *>(crR) + d0;
@@ -1480,7 +1480,7 @@ __global__ __launch_bounds__(256) void k_fused422(const DevImage *__restrict__ i
 				const Rgb12 p3 = color_px(KC, __builtin_amdgcn_perm(cr3, yv, KC.p3), __builtin_amdgcn_perm(cb3, yv, KC.p3));
 				store_px4<NOUT>(out + (rowoff + (uint32_t)(4 * s0) * NOUT), p0, p1, p2, p3);
 			}
-			for (int s0 = nfast + tid; s0 < nstrip; s0 += 256) {
+			for (int s0 = nfast + tid; s0 < nstrip; s0 += NT) {
 				const int x0 = 4 * s0, xe = min(x0 + 4, W);
 				for (int x = x0; x < xe; ++x)
 					fused422_pixel<NOUT>(yR, cbR, crR, wc, x, out + (size_t)(8 * m + rr) * opitch);
@@ -1488,6 +1488,20 @@ __global__ __launch_bounds__(256) void k_fused422(const DevImage *__restrict__ i
 		}
 	}
 }
+
+/* 256 threads where three or more workgroups of the picture's width fit a CU's LDS (256 bytes per MCU column: up to 3400 pixels), 512
+ * where two do (up to 5100), 1024 where one does -- the same ladder as the 4:2:0 band kernel (k_fused420w / x) */
+#define MIJ_BAND422(NAME, NT_)                                                                                                      \
+	template <int NOUT, bool WIDE, bool B8 = false>                                                                                  \
+	__global__ __launch_bounds__(NT_) void NAME(const DevImage *__restrict__ imgs, const WorkBand *__restrict__ work, const uint8_t *__restrict__ coef, \
+															  uint8_t *__restrict__ outbase)                                                              \
+	{                                                                                                                                \
+		fused422_band<NOUT, WIDE, B8, NT_>(imgs, work, coef, outbase);                                                                \
+	}
+MIJ_BAND422(k_fused422, 256)
+MIJ_BAND422(k_fused422w, 512)
+MIJ_BAND422(k_fused422x, 1024)
+#undef MIJ_BAND422
 
 /* ------------------------------------------------------------------ fused 1x1 (4:4:4) YCbCr kernel
  *

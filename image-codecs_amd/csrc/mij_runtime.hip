@@ -99,6 +99,8 @@ extern "C" int mij_ctx_create(int device, mij_ctx **out)
 	MIJ_LDS_ATTR8(k_fused440);
 	MIJ_LDS_ATTR8(k_fused440w);
 	MIJ_LDS_ATTR8(k_fused422);
+	MIJ_LDS_ATTR8(k_fused422w);
+	MIJ_LDS_ATTR8(k_fused422x);
 #undef MIJ_LDS_ATTR8
 #undef MIJ_LDS_ATTR
 	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_encode420), hipFuncAttributeMaxDynamicSharedMemorySize, MIJ_ENC_LDS);
@@ -148,7 +150,7 @@ struct Slot {
 
 /* kernel families of a launch plan, in launch order */
 /* MK_RS_FAST + RS_*: pass 2 compiled per resampler (k_resample_fast); list index [n_out == 4][YCbCr colour][0] */
-enum { MK_PLANES = 0, MK_RESAMPLE, MK_RS_FAST, MK_420 = MK_RS_FAST + RS_KINDS, MK_422, MK_444, MK_GREY, MK_440, MK_420W, MK_440W /* k_fused420w / k_fused440w: 512 threads, wide pictures */, MK_420X /* 1024 threads: one workgroup per CU */, MK_420S, MK_420T /* 128 / 64 threads: narrow pictures */, MK_KINDS };
+enum { MK_PLANES = 0, MK_RESAMPLE, MK_RS_FAST, MK_420 = MK_RS_FAST + RS_KINDS, MK_422, MK_444, MK_GREY, MK_440, MK_420W, MK_440W /* k_fused420w / k_fused440w: 512 threads, wide pictures */, MK_420X /* 1024 threads: one workgroup per CU */, MK_420S, MK_420T /* 128 / 64 threads: narrow pictures */, MK_422W, MK_422X /* k_fused422 with 512 / 1024 threads */, MK_KINDS };
 struct Work4 { /* WorkBand and WorkIdct are both four u32 */
 	uint32_t a, b, c, d;
 };
@@ -732,7 +734,7 @@ static int fused420_kind(const mij_batch *b, const mij_image_desc &d)
 }
 static int band_threads(int kind)
 {
-	return kind == MK_420X ? MIJ_F420X_NT : ((kind == MK_420W || kind == MK_440W) ? MIJ_F420W_NT : (kind == MK_420S ? MIJ_F420S_NT : (kind == MK_420T ? MIJ_F420T_NT : MIJ_F420_NT)));
+	return (kind == MK_420X || kind == MK_422X) ? MIJ_F420X_NT : ((kind == MK_420W || kind == MK_440W || kind == MK_422W) ? MIJ_F420W_NT : (kind == MK_420S ? MIJ_F420S_NT : (kind == MK_420T ? MIJ_F420T_NT : MIJ_F420_NT)));
 }
 static bool fused440_wide(const mij_batch *b, const mij_image_desc &d) { return fused440_ok(b, d) && 3 * fused440_lds(d) > (size_t)b->ctx->max_dyn_lds; }
 static int fused440_kind(const mij_batch *b, const mij_image_desc &d) { return !fused440_ok(b, d) ? -1 : (fused440_wide(b, d) ? MK_440W : MK_440); }
@@ -857,12 +859,14 @@ extern "C" int mij_batch_upload(mij_batch *b)
 			per_blocks(lists[MK_GREY][0][wide][b8], 0);
 		} else if (fused422_ok(b, d)) {
 			s.path = 4;
-			size_t &l = lds_need[MK_422][o4][wide][b8];
-			l = (size_t)d.mcu_x * 256 + 16 > l ? (size_t)d.mcu_x * 256 + 16 : l;
+			const size_t lds422 = (size_t)d.mcu_x * 256 + 16, cap422 = (size_t)b->ctx->max_dyn_lds;
+			const int mk422 = 2 * lds422 > cap422 ? MK_422X : (3 * lds422 > cap422 ? MK_422W : MK_422);
+			size_t &l = lds_need[mk422][o4][wide][b8];
+			l = lds422 > l ? lds422 : l;
 			/* no halo: bands of about eight MCU rows keep the grid deep without making workgroups short */
 			const int nb = (d.mcu_y + 7) / 8;
 			for (int k = 0; k < nb; ++k)
-				lists[MK_422][o4][wide][b8].push_back(Work4{(uint32_t)i, (uint32_t)((long)d.mcu_y * k / nb), (uint32_t)((long)d.mcu_y * (k + 1) / nb), 0u});
+				lists[mk422][o4][wide][b8].push_back(Work4{(uint32_t)i, (uint32_t)((long)d.mcu_y * k / nb), (uint32_t)((long)d.mcu_y * (k + 1) / nb), 0u});
 		} else if (fused440_ok(b, d)) {
 			s.path = 6;
 			const int mk = fused440_kind(b, d);
@@ -1027,7 +1031,7 @@ extern "C" int mij_batch_launch(mij_batch *b)
 		return set_err(MIJ_E_STATE, "mij_batch_launch before mij_batch_upload");
 	HIP_TRY(hipSetDevice(b->ctx->device));
 	for (const auto &L : b->launches) { /* in family order: pass 2 of the two-pass family runs behind every pass-1 launch */
-		const dim3 grid((unsigned)L.count), block((L.kind >= MK_420 && L.kind != MK_422 && L.kind != MK_444 && L.kind != MK_GREY) ? (unsigned)band_threads(L.kind) : 256u);
+		const dim3 grid((unsigned)L.count), block((L.kind >= MK_420 && L.kind != MK_444 && L.kind != MK_GREY) ? (unsigned)band_threads(L.kind) : 256u);
 		const Work4 *wk = b->d_work + L.first;
 		switch (L.kind) {
 		case MK_420:
@@ -1047,6 +1051,12 @@ extern "C" int mij_batch_launch(mij_batch *b)
 			break;
 		case MK_422:
 			MIJ_LAUNCH_NWB(k_fused422, WorkBand, MIJ_COEF_OUT);
+			break;
+		case MK_422W:
+			MIJ_LAUNCH_NWB(k_fused422w, WorkBand, MIJ_COEF_OUT);
+			break;
+		case MK_422X:
+			MIJ_LAUNCH_NWB(k_fused422x, WorkBand, MIJ_COEF_OUT);
 			break;
 		case MK_440:
 			MIJ_LAUNCH_NWB(k_fused440, WorkBand, MIJ_COEF_OUT);
