@@ -780,6 +780,9 @@ extern "C" int mij_batch_upload(mij_batch *b)
 	 * band re-does two chroma block rows of IDCT as halo.  Pick the bands-per-image (1..16) that
 	 * minimises  rounds x (1 + halo share)  per unit of work; measured on MI355X: 1024 x 1080p ->
 	 * 6 bands (6144 workgroups = 8.0 rounds of 768) beats 4 (5.33 rounds) by ~1.5 %. */
+#ifndef MIJ_BAND_CAP
+#define MIJ_BAND_CAP 64
+#endif
 	auto auto_bands = [&](int (*kind_of)(const mij_batch *, const mij_image_desc &), int kind, size_t (*lds_of)(const mij_image_desc &)) -> int {
 		const int nt = band_threads(kind);
 		size_t n_fused = 0, mcu_rows_sum = 0, lds_max = 0;
@@ -799,7 +802,11 @@ extern "C" int mij_batch_upload(mij_batch *b)
 			const size_t slots = (size_t)cu * per_cu;
 			const double avg_rows = (double)mcu_rows_sum / (double)n_fused;
 			double best = 1e30;
-			for (int nb = 1; nb <= 16 && nb <= (int)avg_rows; ++nb) {
+			/* up to 16 bands per picture; up to MIJ_BAND_CAP for 4:2:0 batches so small that sixteen bands each leave workgroup slots
+			 * empty (a lone picture from stbi_load, a handful): 16 x 1080p 0.078 -> 0.058 ms.  Not for 4:4:0, whose halo is a larger share
+			 * of a band (0.069 -> 0.093 ms), and not once the slots are full (36 x 5120 x 2880: 0.70 -> 0.73 ms with the higher cap). */
+			const int cap = (kind != MK_440 && kind != MK_440W && n_fused * 16 <= slots) ? MIJ_BAND_CAP : 16;
+			for (int nb = 1; nb <= cap && nb <= (int)avg_rows; ++nb) {
 				const size_t wgs = n_fused * (size_t)nb;
 				const size_t rounds = (wgs + slots - 1) / slots;
 				/* every inner band edge re-transforms two chroma block rows (4 of an MCU row's 6 blocks' worth), the IDCT being ~45 %
