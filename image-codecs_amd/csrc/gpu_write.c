@@ -108,7 +108,7 @@ int mij_write_jpg_to_func(mjw_write_func *func, void *context, int x, int y, int
 	if (!ctx)
 		return 0; /* no gpu device: this entry point has no host fallback */
 	elems = mjw_plan_du_count(&plan) * 64;
-	pix = (size_t)x * (size_t)y * (size_t)comp;
+	pix = mij_enc_pixel_bytes(x, y, comp, quality);
 	if (!pool_take(ctx, 1, pix + 256, elems * 2 + 256, &pe))
 		return 0;
 	du = (int16_t *)malloc(elems * sizeof(int16_t));
@@ -149,9 +149,7 @@ static void *wb_worker(void *arg)
 		if (j->slot[i] < 0)
 			continue;
 		if (j->phase == 0) { /* pixels -> the slot's pinned staging */
-			void *dst = mij_enc_staging(j->enc, j->slot[i]);
-			if (dst)
-				memcpy(dst, j->pixels[i], (size_t)j->x[i] * (size_t)j->y[i] * (size_t)j->comp[i]);
+			(void)mij_enc_stage_pixels(j->enc, j->slot[i], j->pixels[i]);
 		} else { /* data units -> byte stream */
 			mjw_plan plan;
 			const int16_t *du = mij_enc_units(j->enc, j->slot[i]);
@@ -235,7 +233,7 @@ int mij_write_jpg_batch(const void *const *pixels, const int *x, const int *y, c
 			mjw_plan plan;
 			slot[i] = -1;
 			if (pixels[i] && mjw_plan_init(&plan, x[i], y[i], comp[i], quality)) {
-				pix += ((size_t)x[i] * (size_t)y[i] * (size_t)comp[i] + 255) / 256 * 256;
+				pix += mij_enc_pixel_bytes(x[i], y[i], comp[i], quality);
 				dub += (mjw_plan_du_count(&plan) * 128 + 255) / 256 * 256;
 				slot[i] = 0;
 			}

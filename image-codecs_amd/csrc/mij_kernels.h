@@ -2091,7 +2091,7 @@ __global__ __launch_bounds__(256) void k_encode_c(const EncImage *__restrict__ i
 	}
 }
 
-/* ------------------------------------------------------------------ fused 4:2:0 encoder (3-component images, width % 16 == 0)
+/* ------------------------------------------------------------------ fused 4:2:0 encoder (3-component images; rows staged as whole MCU columns, mij_runtime.hip enc_padded_width)
  *
  * The per-unit kernels above read every pixel twice (luma pass, chroma pass) with lane-strided
  * accesses, convert every byte to float twice, and write each lane's 128-byte unit as eight 16-byte
@@ -2278,7 +2278,7 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(MIJ_ENC_WAV
 	}
 }
 
-/* ------------------------------------------------------------------ fused 4:4:4 encoder (3-component images, width % 8 == 0)
+/* ------------------------------------------------------------------ fused 4:4:4 encoder (3-component images; rows staged as whole MCU columns)
  *
  * The writer takes 4:4:4 for every quality above 90 (codec/jpeg_write.c:221, :283-352: MCU = one 8x8 block per component).
  * The per-unit kernels read the pixels of such a picture three times with per-byte loads; here one workgroup (3 waves)

@@ -1882,6 +1882,7 @@ struct EncSlot {
 	mjw_plan plan;
 	EncImage dev;
 	size_t stage_off, pix_bytes, du_bytes;
+	int pad_w; /* pixels per staged row: the width rounded up to whole MCU columns for 3-component pictures (enc_padded_width) */
 	int clone_of, flip;
 };
 
@@ -2000,6 +2001,36 @@ extern "C" int mij_enc_reset(mij_encoder *e)
 	return MIJ_OK;
 }
 
+/* 3-component pictures are staged with rows of whole MCU columns, the last pixel of a row repeated into the padding -- the reference's
+ * edge rule (codec/jpeg_write.c:294-296) applied once on the way in -- so the strip kernels (k_encode420 / k_encode444: 16-byte or
+ * 8-byte row chunks, no column clamp) take every width, not only multiples of 16 / 8; the per-unit kernels see the same rows. */
+static int enc_padded_width(int width, int comp, int subsample)
+{
+	const int unit = subsample ? 16 : 8;
+	return comp == 3 ? (width + unit - 1) / unit * unit : width;
+}
+static void enc_stage_rows(uint8_t *dst, const uint8_t *src, int width, int height, int comp, int pad_w)
+{
+	if (pad_w == width) {
+		memcpy(dst, src, (size_t)width * height * comp);
+		return;
+	}
+	const size_t in_pitch = (size_t)width * comp, out_pitch = (size_t)pad_w * comp;
+	for (int y = 0; y < height; ++y) {
+		uint8_t *d = dst + (size_t)y * out_pitch;
+		memcpy(d, src + (size_t)y * in_pitch, in_pitch);
+		for (int x = width; x < pad_w; ++x)
+			memcpy(d + (size_t)x * comp, d + (size_t)(width - 1) * comp, (size_t)comp);
+	}
+}
+extern "C" size_t mij_enc_pixel_bytes(int width, int height, int comp, int quality)
+{
+	mjw_plan plan;
+	if (!mjw_plan_init(&plan, width, height, comp, quality))
+		return 0;
+	return align_up((size_t)enc_padded_width(width, comp, plan.subsample) * height * comp, 256);
+}
+
 static int enc_add_common(mij_encoder *e, const mjw_plan &plan, const void *pixels, int flip, int clone_of)
 {
 	if ((int)e->slots.size() >= e->max_images)
@@ -2008,7 +2039,8 @@ static int enc_add_common(mij_encoder *e, const mjw_plan &plan, const void *pixe
 	s.plan = plan;
 	s.flip = flip;
 	s.clone_of = clone_of;
-	s.pix_bytes = align_up((size_t)plan.width * plan.height * plan.comp, 256);
+	s.pad_w = enc_padded_width(plan.width, plan.comp, plan.subsample);
+	s.pix_bytes = align_up((size_t)s.pad_w * plan.height * plan.comp, 256);
 	s.du_bytes = align_up(mjw_plan_du_count(&plan) * 128, 256);
 	if (e->pix_used + s.pix_bytes > e->pix_cap)
 		return set_err(MIJ_E_NOMEM, "pixel arena exhausted");
@@ -2018,14 +2050,14 @@ static int enc_add_common(mij_encoder *e, const mjw_plan &plan, const void *pixe
 		if (e->stage_used + s.pix_bytes > e->stage_cap)
 			return set_err(MIJ_E_NOMEM, "pixel staging exhausted");
 		s.stage_off = e->stage_used;
-		if (pixels) /* mij_enc_add_uncopied: the caller fills mij_enc_staging(slot) itself (several threads at once) */
-			memcpy(e->stage + s.stage_off, pixels, (size_t)plan.width * plan.height * plan.comp);
+		if (pixels) /* mij_enc_add_uncopied: the caller stages the pixels itself (mij_enc_stage_pixels, several threads at once) */
+			enc_stage_rows(e->stage + s.stage_off, static_cast<const uint8_t *>(pixels), plan.width, plan.height, plan.comp, s.pad_w);
 		e->stage_used += s.pix_bytes;
 	} else {
 		s.stage_off = e->slots[(size_t)clone_of].stage_off;
 	}
 	memset(&s.dev, 0, sizeof(s.dev));
-	s.dev.width = plan.width;
+	s.dev.width = s.pad_w; /* the device sees whole MCU columns */
 	s.dev.height = plan.height;
 	s.dev.comp = plan.comp;
 	s.dev.subsample = plan.subsample;
@@ -2061,6 +2093,15 @@ extern "C" int mij_enc_add_uncopied(mij_encoder *e, int width, int height, int c
 	if (!mjw_plan_init(&plan, width, height, comp, quality))
 		return set_err(MIJ_E_ARG, "bad image arguments (%dx%dx%d)", width, height, comp);
 	return enc_add_common(e, plan, nullptr, flip_vertically ? 1 : 0, -1);
+}
+
+extern "C" int mij_enc_stage_pixels(mij_encoder *e, int slot, const void *pixels)
+{
+	if (!e || !pixels || slot < 0 || slot >= (int)e->slots.size() || e->slots[(size_t)slot].clone_of >= 0)
+		return set_err(MIJ_E_ARG, "bad slot or pixels");
+	const EncSlot &s = e->slots[(size_t)slot];
+	enc_stage_rows(e->stage + s.stage_off, static_cast<const uint8_t *>(pixels), s.plan.width, s.plan.height, s.plan.comp, s.pad_w);
+	return MIJ_OK;
 }
 
 extern "C" void *mij_enc_staging(mij_encoder *e, int slot)
@@ -2132,8 +2173,8 @@ extern "C" int mij_enc_upload(mij_encoder *e)
 		const int sub = s.plan.subsample ? 1 : 0;
 		const uint32_t ny = nm * (sub ? 4u : 1u), nc = nm * 2u;
 		e->h_imgs[i] = s.dev;
-		/* strips of 32 MCUs through the fused kernel: whole 16-pixel columns, packed RGB, 16-byte aligned rows */
-		if (sub && s.plan.comp == 3 && (s.plan.width & 15) == 0 && !e->force_generic) {
+		/* strips of 32 MCUs through the fused kernel: whole 16-pixel columns, packed RGB, 16-byte aligned rows (every width: enc_padded_width) */
+		if (sub && s.plan.comp == 3 && !e->force_generic) {
 			for (uint32_t f = 0; f < nm; f += MIJ_ENC_STRIP) {
 				WorkIdct w = {(uint32_t)i, 0u, f, 0u};
 				work[4].push_back(w);
@@ -2141,7 +2182,7 @@ extern "C" int mij_enc_upload(mij_encoder *e)
 			continue;
 		}
 		/* 4:4:4 (quality above 90): strips of 64 MCUs through k_encode444: whole 8-pixel columns, packed RGB, 8-byte aligned rows */
-		if (!sub && s.plan.comp == 3 && (s.plan.width & 7) == 0 && !e->force_generic) {
+		if (!sub && s.plan.comp == 3 && !e->force_generic) {
 			for (uint32_t f = 0; f < nm; f += MIJ_ENC444_STRIP) {
 				WorkIdct w = {(uint32_t)i, 0u, f, 0u};
 				work[5].push_back(w);

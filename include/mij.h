@@ -294,10 +294,17 @@ int mij_enc_reset(mij_encoder *e);
 /* copies the pixels into pinned staging; quality and 4:2:0/4:4:4 choice as stbi_write_jpg; returns the slot */
 int mij_enc_add(mij_encoder *e, const void *pixels, int width, int height, int comp, int quality, int flip_vertically);
 int mij_enc_add_clone(mij_encoder *e, int src_slot); /* own device buffers, same pixels (benchmarks) */
-/* the same slot bookkeeping without the copy: the caller writes width*height*comp bytes to mij_enc_staging(slot) before
+/* the same slot bookkeeping without the copy: the caller stages the pixels with mij_enc_stage_pixels(slot) before
  * mij_enc_upload (batch front ends fill the slots from several host threads at once, mij_write_jpg_batch) */
 int mij_enc_add_uncopied(mij_encoder *e, int width, int height, int comp, int quality, int flip_vertically);
 void *mij_enc_staging(mij_encoder *e, int slot);
+/* Bytes one picture takes in the pixel arenas (pix_cap of mij_enc_create): 3-component pictures are staged with rows of whole MCU
+ * columns (width rounded up to 16, or to 8 above quality 90), the last pixel of a row repeated -- codec/jpeg_write.c:294-296 applied on
+ * the way in -- so that the strip kernels take every width; rounded up to 256. */
+size_t mij_enc_pixel_bytes(int width, int height, int comp, int quality);
+/* Copies a picture into the staging of a slot made by mij_enc_add_uncopied in that layout (callable from several threads for different
+ * slots).  mij_enc_staging() returns the same memory: its row pitch is the padded width x comp. */
+int mij_enc_stage_pixels(mij_encoder *e, int slot, const void *pixels);
 /* every slot's data units into the encoder's pinned mirror with one device-to-host copy (waits for it); mij_enc_units(slot)
  * points into that mirror until the next mij_enc_fetch_all / mij_enc_destroy */
 int mij_enc_fetch_all(mij_encoder *e);
