@@ -114,6 +114,41 @@ def test_fused_444_strip_kernel_and_per_unit_kernels_agree(ica, oracle, gpu_ctx)
         enc.close()
 
 
+def test_strip_kernels_take_every_width(ica, oracle, gpu_ctx):
+    """3-component pictures are staged with rows of whole MCU columns (the last pixel repeated: codec/jpeg_write.c:294-296 applied on
+    the way in), so widths that are NOT multiples of 16 / 8 go through the strip kernels too: data units equal to the host transform's,
+    flipped and not, both layouts; the one-call writer and the batch writer give the oracle's bytes for them (tall pictures: the
+    padded rows must fit the arenas those entry points size themselves)."""
+    rng = np.random.default_rng(37)
+    shapes = [(1, 1), (15, 33), (17, 9), (31, 16), (33, 47), (250, 131), (999, 64), (1366, 768), (1921, 40)]
+    imgs = [rng.integers(0, 256, (h, w, 3)).astype(np.uint8) for (w, h) in shapes]
+    imgs[7] = ica.synth_rgb(1366, 768, 5)
+    for quality in (90, 95):
+        want = [ica.host_transform(im, quality)[1] for im in imgs]
+        for generic in (False, True):
+            enc = ica.Encoder(gpu_ctx, 2 * len(imgs), 64 << 20, 96 << 20)
+            enc.force_generic(generic)
+            slots = [enc.add(im, quality) for im in imgs]
+            flipped = [enc.add(im, quality, flip=True) for im in imgs]
+            enc.upload()
+            enc.launch()
+            enc.wait()
+            for s, w_, shape, im in zip(slots, want, shapes, imgs):
+                got = enc.fetch(s)
+                assert np.array_equal(got, w_), (quality, generic, shape, int((got != w_).sum()))
+                if shape[0] * shape[1] <= 250 * 131:
+                    assert ica.emit_jpeg(enc.plan(s), got) == oracle.encode(im, quality), (quality, generic, shape)
+            for s, im, shape in zip(flipped, imgs, shapes):
+                assert np.array_equal(enc.fetch(s), ica.host_transform(im[::-1], quality)[1]), (quality, generic, shape)
+            enc.close()
+    tall = [ica.synth_rgb(1001, 2003, 1), ica.synth_rgb(9, 3001, 2), ica.synth_rgb(1366, 768, 3)]
+    for quality in (90, 93):
+        wants = [oracle.encode(im, quality) for im in tall]
+        for im, want_b in zip(tall, wants):
+            assert ica.mij_write_jpg_to_memory(im, quality) == want_b, (im.shape, quality)
+        assert ica.mij_write_jpg_batch(tall, quality, threads=3) == wants, quality
+
+
 def test_gpu_writer_entry_reuses_encoders_across_sizes_and_threads(ica, oracle, gpu_ctx):
     """mij_write_jpg_to_func keeps its encoders in a pool between calls: growing and shrinking pictures, both layouts (quality <= 90:
     4:2:0, above: 4:4:4), one to four channels, and four host threads writing at once -- every byte stream equals the oracle's."""
