@@ -31,6 +31,7 @@ typedef struct {
 	uint8_t *stage;
 	size_t *off, *cap, *slen;
 	int *status;      /* mjh_extract_scan's verdict per image */
+	size_t small_px;  /* default front end: pictures below this many pixels go to the host walk (0: none do) */
 	const char *todo; /* per image: 1 = the host walk has to do it */
 } pool_t;
 
@@ -124,6 +125,10 @@ int mjh_decode_batch_host(mij_batch *b, const uint8_t *const *bufs, const int *l
 
 /* ------------------------------------------------------------------ the same with the Huffman walk on the GPU */
 
+/* pictures below this many pixels take the host walk although the GPU walk could do them: set by the default front end
+ * (mjh_decode_batch) around its call, see there */
+static __thread size_t t_small_px = 0;
+
 static void *extract_worker(void *arg)
 {
 	pool_t *p = (pool_t *)arg;
@@ -135,7 +140,13 @@ static void *extract_worker(void *arg)
 		pthread_mutex_unlock(&p->lock);
 		if (i >= p->n)
 			break;
-		p->status[i] = mjh_extract_scan(p->bufs[i], p->lens[i], p->req_comp, &p->scans[i], p->stage + p->off[i], p->cap[i], &p->slen[i], &why);
+		if (p->small_px && (size_t)(p->lens[i] > 0 ? p->lens[i] : 0) < p->small_px / 4) {
+			/* a file this short is a small picture whatever its quality (a quarter of a byte per pixel and less): header only,
+			 * the host walk takes it (status 2) without the stream being unstuffed for a GPU walk that will not happen */
+			p->slen[i] = 0;
+			p->status[i] = mjh_probe_memory(p->bufs[i], p->lens[i], p->req_comp, &p->scans[i].desc, &why) ? 2 : 0;
+		} else
+			p->status[i] = mjh_extract_scan(p->bufs[i], p->lens[i], p->req_comp, &p->scans[i], p->stage + p->off[i], p->cap[i], &p->slen[i], &why);
 		p->reasons[i] = why;
 	}
 	return NULL;
@@ -280,6 +291,7 @@ mjh_gpu_job *mjh_decode_batch_gpu_begin(mij_batch *b, const uint8_t *const *bufs
 	p->slots = slots;
 	p->reasons = reasons;
 	p->stage = stage;
+	p->small_px = t_small_px; /* 0 from the explicit GPU-walk entries: they walk what they are given */
 	p->scans = (mjg_scan *)malloc(sizeof(mjg_scan) * cnt);
 	p->descs = (mij_image_desc *)malloc(sizeof(mij_image_desc) * cnt);
 	p->off = (size_t *)malloc(sizeof(size_t) * 3 * cnt);
@@ -316,6 +328,7 @@ mjh_gpu_job *mjh_decode_batch_gpu_begin(mij_batch *b, const uint8_t *const *bufs
 	pthread_mutex_destroy(&p->lock);
 	NOW_(t1_);
 	/* slots in input order */
+	const size_t small_px = p->small_px;
 	for (i = 0; i < n; ++i) {
 		p->descs[i] = p->scans[i].desc;
 		if (p->status[i] == 0) {
@@ -323,6 +336,12 @@ mjh_gpu_job *mjh_decode_batch_gpu_begin(mij_batch *b, const uint8_t *const *bufs
 			continue;
 		}
 		reasons[i] = NULL;
+		/* small pictures are quicker on the host threads: a scan of a few subsequences leaves most of the 256 lanes of its workgroup
+		 * idle in every pass of the GPU walk.  Measured per call, 16 host threads (tools/bench_batch_sizes.py): 64 x 64 0.73 against
+		 * 1.83 Gpix/s, 128 x 128 2.6 against 4.7, 256 x 256 9.9 against 5.6 -- the GPU walk's rate grows with the picture, the host's
+		 * with the threads, and they cross near 2200 pixels per thread. */
+		if (p->status[i] == 1 && (size_t)p->descs[i].width * (size_t)p->descs[i].height < small_px)
+			p->status[i] = 2;
 		if (p->status[i] == 1) {
 			slots[i] = mij_batch_add_stream(b, &p->scans[i], stage + p->off[i], p->slen[i]);
 			if (slots[i] == MIJ_E_NOMEM) /* e.g. more restart intervals than the entropy arena has scans for: host walk */
@@ -455,7 +474,14 @@ int mjh_decode_batch(mij_batch *b, const uint8_t *const *bufs, const int *lens, 
 	}
 	if (entropy_bytes_for(lens, n) > cap)
 		return mjh_decode_batch_host(b, bufs, lens, n, req_comp, threads, slots, reasons);
-	return mjh_decode_batch_gpu(b, bufs, lens, n, req_comp, threads, slots, reasons);
+	{
+		const char *small_env = getenv("MIJ_GPU_WALK_BATCH_MIN_PIXELS");
+		int rc;
+		t_small_px = small_env ? (size_t)strtoull(small_env, NULL, 10) : (size_t)2200 * (size_t)(threads < 1 ? 1 : (threads > 256 ? 256 : threads));
+		rc = mjh_decode_batch_gpu(b, bufs, lens, n, req_comp, threads, slots, reasons);
+		t_small_px = 0;
+		return rc;
+	}
 }
 
 /* ------------------------------------------------------------------ one logical batch over several devices

@@ -51,7 +51,9 @@ int mjh_extract_scan(const uint8_t *buf, int len, int req_comp, mjg_scan *scan, 
  *                        files; mjh_decode_batch_gpu below), the host walk is the fallback for every other layout and for
  *                        any stream the GPU walk reports back.  The batch gets its entropy arena on first use (sized for
  *                        that call; a later, larger call takes the host walk).  Environment MIJ_ENTROPY=host selects the
- *                        host-only front end instead (mjh_gpu_walk_default() says which is in force).
+ *                        host-only front end instead (mjh_gpu_walk_default() says which is in force).  Pictures below
+ *                        2200 pixels per host thread (MIJ_GPU_WALK_BATCH_MIN_PIXELS overrides) take the host walk in the same
+ *                        call: their few subsequences leave the GPU walk's workgroups mostly idle.
  * mjh_decode_batch_host  the host stage of every image on `threads` host threads (one image per task), straight into the
  *                        batch's pinned staging -- what north_star describes ("the C host keeps the Huffman walk"); its
  *                        end-to-end rate is bounded by the walk (about 0.25-0.5 Gpix/s per host core) and by PCIe.
