@@ -268,6 +268,33 @@ def test_progressive_and_444(ica, oracle, gpu_ctx, golden):
             b.close()
 
 
+def test_default_front_end_routes_small_pictures_to_the_host_walk(golden, ica, oracle, gpu_ctx, monkeypatch):
+    """mjh_decode_batch sends pictures below a size threshold (2200 pixels per host thread, MIJ_GPU_WALK_BATCH_MIN_PIXELS) to the
+    host walk and the rest to the GPU walk in one call: pictures on both sides of the threshold, short files that are not small
+    pictures (flat content), a rejected header and a rejected stream among them, every threshold -- same slots, reasons and pixels."""
+    datas = [ica.synth_jpeg(w, h, (w + h) & 7, q) for (w, h, q) in ((64, 64, 90), (200, 180, 50), (512, 512, 90), (33, 17, 95), (1000, 700, 75), (96, 96, 10), (640, 480, 90))]
+    datas.append(ica.stbi_write_jpg_to_memory(np.full((900, 1200, 3), 77, np.uint8), 90))  # 1 Mpix in a few KB: a short file, not a small picture
+    datas.insert(2, golden.jpg("garbage"))
+    datas.insert(5, golden.jpg("trunc_noeoi"))
+    wants = [oracle.load(d, 3) for d in datas]
+    for thr in (None, "0", "5000", "100000", "100000000"):
+        if thr is None:
+            monkeypatch.delenv("MIJ_GPU_WALK_BATCH_MIN_PIXELS", raising=False)
+        else:
+            monkeypatch.setenv("MIJ_GPU_WALK_BATCH_MIN_PIXELS", thr)
+        b = ica.Batch(gpu_ctx, len(datas), 64 << 20, 64 << 20, 64 << 20)
+        ok, slots, reasons = b.decode_jpegs(datas, 3, threads=3)
+        assert ok == len(datas) - 2, (thr, reasons)
+        assert slots[2] == -1 and reasons[2] == "unknown image type", thr
+        assert slots[5] < -1 and reasons[5] == "expected marker", (thr, slots[5], reasons[5])
+        b.submit()
+        b.wait()
+        for i, (d, want) in enumerate(zip(datas, wants)):
+            if slots[i] >= 0:
+                assert np.array_equal(b.fetch(slots[i]), want[1]), (thr, i)
+        b.close()
+
+
 def test_batch_front_end_thread_pool(golden, ica, oracle, gpu_ctx):
     """mjh_decode_batch: host stage on a thread pool; a rejected header costs no slot, a rejected
     entropy segment keeps its slot but is skipped by the launch; everything else equals the oracle."""
