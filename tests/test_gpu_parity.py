@@ -282,7 +282,7 @@ def test_default_front_end_routes_small_pictures_to_the_host_walk(golden, ica, o
             monkeypatch.delenv("MIJ_GPU_WALK_BATCH_MIN_PIXELS", raising=False)
         else:
             monkeypatch.setenv("MIJ_GPU_WALK_BATCH_MIN_PIXELS", thr)
-        b = ica.Batch(gpu_ctx, len(datas), 64 << 20, 64 << 20, 64 << 20)
+        b = ica.Batch(gpu_ctx, len(datas), 24 << 20, 24 << 20, 24 << 20)
         ok, slots, reasons = b.decode_jpegs(datas, 3, threads=3)
         assert ok == len(datas) - 2, (thr, reasons)
         assert slots[2] == -1 and reasons[2] == "unknown image type", thr
