@@ -1501,6 +1501,8 @@ __device__ __forceinline__ void fused422_band(const DevImage *__restrict__ imgs,
 MIJ_BAND422(k_fused422, 256)
 MIJ_BAND422(k_fused422w, 512)
 MIJ_BAND422(k_fused422x, 1024)
+MIJ_BAND422(k_fused422s, 128) /* narrow pictures, as k_fused420s / t */
+MIJ_BAND422(k_fused422t, 64)
 #undef MIJ_BAND422
 
 /* ------------------------------------------------------------------ fused 1x1 (4:4:4) YCbCr kernel

@@ -101,6 +101,8 @@ extern "C" int mij_ctx_create(int device, mij_ctx **out)
 	MIJ_LDS_ATTR8(k_fused422);
 	MIJ_LDS_ATTR8(k_fused422w);
 	MIJ_LDS_ATTR8(k_fused422x);
+	MIJ_LDS_ATTR8(k_fused422s);
+	MIJ_LDS_ATTR8(k_fused422t);
 #undef MIJ_LDS_ATTR8
 #undef MIJ_LDS_ATTR
 	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_encode420), hipFuncAttributeMaxDynamicSharedMemorySize, MIJ_ENC_LDS);
@@ -150,7 +152,7 @@ struct Slot {
 
 /* kernel families of a launch plan, in launch order */
 /* MK_RS_FAST + RS_*: pass 2 compiled per resampler (k_resample_fast); list index [n_out == 4][YCbCr colour][0] */
-enum { MK_PLANES = 0, MK_RESAMPLE, MK_RS_FAST, MK_420 = MK_RS_FAST + RS_KINDS, MK_422, MK_444, MK_GREY, MK_440, MK_420W, MK_440W /* k_fused420w / k_fused440w: 512 threads, wide pictures */, MK_420X /* 1024 threads: one workgroup per CU */, MK_420S, MK_420T /* 128 / 64 threads: narrow pictures */, MK_422W, MK_422X /* k_fused422 with 512 / 1024 threads */, MK_KINDS };
+enum { MK_PLANES = 0, MK_RESAMPLE, MK_RS_FAST, MK_420 = MK_RS_FAST + RS_KINDS, MK_422, MK_444, MK_GREY, MK_440, MK_420W, MK_440W /* k_fused420w / k_fused440w: 512 threads, wide pictures */, MK_420X /* 1024 threads: one workgroup per CU */, MK_420S, MK_420T /* 128 / 64 threads: narrow pictures */, MK_422W, MK_422X, MK_422S, MK_422T /* k_fused422 with 512 / 1024 / 128 / 64 threads */, MK_KINDS };
 struct Work4 { /* WorkBand and WorkIdct are both four u32 */
 	uint32_t a, b, c, d;
 };
@@ -732,9 +734,21 @@ static int fused420_kind(const mij_batch *b, const mij_image_desc &d)
 		return MK_420W;
 	return d.mcu_x <= 24 ? MK_420T : (d.mcu_x <= 56 ? MK_420S : MK_420);
 }
+#ifndef MIJ_422T_MAX /* MCU columns up to which k_fused422 runs with one / two waves (A/B: 0 switches a form off) */
+#define MIJ_422T_MAX 24
+#endif
+#ifndef MIJ_422S_MAX
+#define MIJ_422S_MAX 56
+#endif
 static int band_threads(int kind)
 {
-	return (kind == MK_420X || kind == MK_422X) ? MIJ_F420X_NT : ((kind == MK_420W || kind == MK_440W || kind == MK_422W) ? MIJ_F420W_NT : (kind == MK_420S ? MIJ_F420S_NT : (kind == MK_420T ? MIJ_F420T_NT : MIJ_F420_NT)));
+	switch (kind) {
+	case MK_420X: case MK_422X: return MIJ_F420X_NT;
+	case MK_420W: case MK_440W: case MK_422W: return MIJ_F420W_NT;
+	case MK_420S: case MK_422S: return MIJ_F420S_NT;
+	case MK_420T: case MK_422T: return MIJ_F420T_NT;
+	default: return MIJ_F420_NT;
+	}
 }
 static bool fused440_wide(const mij_batch *b, const mij_image_desc &d) { return fused440_ok(b, d) && 3 * fused440_lds(d) > (size_t)b->ctx->max_dyn_lds; }
 static int fused440_kind(const mij_batch *b, const mij_image_desc &d) { return !fused440_ok(b, d) ? -1 : (fused440_wide(b, d) ? MK_440W : MK_440); }
@@ -867,7 +881,7 @@ extern "C" int mij_batch_upload(mij_batch *b)
 		} else if (fused422_ok(b, d)) {
 			s.path = 4;
 			const size_t lds422 = (size_t)d.mcu_x * 256 + 16, cap422 = (size_t)b->ctx->max_dyn_lds;
-			const int mk422 = 2 * lds422 > cap422 ? MK_422X : (3 * lds422 > cap422 ? MK_422W : MK_422);
+			const int mk422 = 2 * lds422 > cap422 ? MK_422X : (3 * lds422 > cap422 ? MK_422W : (d.mcu_x <= MIJ_422T_MAX ? MK_422T : (d.mcu_x <= MIJ_422S_MAX ? MK_422S : MK_422)));
 			size_t &l = lds_need[mk422][o4][wide][b8];
 			l = lds422 > l ? lds422 : l;
 			/* no halo: bands of about eight MCU rows keep the grid deep without making workgroups short */
@@ -1064,6 +1078,12 @@ extern "C" int mij_batch_launch(mij_batch *b)
 			break;
 		case MK_422X:
 			MIJ_LAUNCH_NWB(k_fused422x, WorkBand, MIJ_COEF_OUT);
+			break;
+		case MK_422S:
+			MIJ_LAUNCH_NWB(k_fused422s, WorkBand, MIJ_COEF_OUT);
+			break;
+		case MK_422T:
+			MIJ_LAUNCH_NWB(k_fused422t, WorkBand, MIJ_COEF_OUT);
 			break;
 		case MK_440:
 			MIJ_LAUNCH_NWB(k_fused440, WorkBand, MIJ_COEF_OUT);
