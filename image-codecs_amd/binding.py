@@ -808,24 +808,29 @@ def mij_write_jpg_to_memory(pixels, quality=90):
 
 
 def mij_write_jpg_batch(images, quality=90, threads=16):
-    """mij_write_jpg_batch: a list of uint8 pictures [h, w, comp] (or [h, w]) -> list of byte streams (None where the picture was refused)."""
+    """mij_write_jpg_batch: a list of uint8 pictures [h, w, comp] (or [h, w]; None = a NULL pixel pointer) -> list of byte streams
+    (None where the picture was refused).  A negative return raises; the C side has released every stream by then."""
     L = lib()
     arrs = []
     for im in images:
+        if im is None:
+            arrs.append(None)
+            continue
         a = np.ascontiguousarray(im, dtype=np.uint8)
         arrs.append(a[:, :, None] if a.ndim == 2 else a)
     n = len(arrs)
     L.mij_write_jpg_batch.restype = C.c_int
     L.mij_write_jpg_batch.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int,
                                       C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
-    px = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
-    xs = (C.c_int * n)(*[a.shape[1] for a in arrs])
-    ys = (C.c_int * n)(*[a.shape[0] for a in arrs])
-    cs = (C.c_int * n)(*[a.shape[2] for a in arrs])
+    px = (C.c_void_p * n)(*[(a.ctypes.data if a is not None else None) for a in arrs])
+    xs = (C.c_int * n)(*[(a.shape[1] if a is not None else 16) for a in arrs])
+    ys = (C.c_int * n)(*[(a.shape[0] if a is not None else 16) for a in arrs])
+    cs = (C.c_int * n)(*[(a.shape[2] if a is not None else 3) for a in arrs])
     out = (C.c_void_p * n)()
     lens = (C.c_size_t * n)()
     rc = L.mij_write_jpg_batch(px, xs, ys, cs, n, int(quality), int(threads), out, lens)
     if rc < 0:
+        assert not any(out[i] for i in range(n)), "mij_write_jpg_batch returned an error and left streams allocated"
         raise MijError("mij_write_jpg_batch: error %d" % rc)
     libc = C.CDLL(None)
     libc.free.argtypes = [C.c_void_p]
@@ -836,6 +841,7 @@ def mij_write_jpg_batch(images, quality=90, threads=16):
             libc.free(out[i])
         else:
             res.append(None)
+    assert rc == sum(r is not None for r in res), "mij_write_jpg_batch: return value and streams disagree"
     return res
 
 

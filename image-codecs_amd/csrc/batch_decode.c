@@ -140,8 +140,9 @@ static void *extract_worker(void *arg)
 		pthread_mutex_unlock(&p->lock);
 		if (i >= p->n)
 			break;
-		if (p->small_px && (size_t)(p->lens[i] > 0 ? p->lens[i] : 0) < p->small_px / 4) {
-			/* a file this short is a small picture whatever its quality (a quarter of a byte per pixel and less): header only,
+		if (p->small_px && (size_t)(p->lens[i] > 0 ? p->lens[i] : 0) < (p->small_px / 4 < 8192 ? p->small_px / 4 : 8192)) {
+			/* a file this short is a small picture whatever its quality (a quarter of a byte per pixel and less; never more than 8 KiB,
+			 * so that a large flat picture of a many-threaded call still has its size looked at): header only,
 			 * the host walk takes it (status 2) without the stream being unstuffed for a GPU walk that will not happen */
 			p->slen[i] = 0;
 			p->status[i] = mjh_probe_memory(p->bufs[i], p->lens[i], p->req_comp, &p->scans[i].desc, &why) ? 2 : 0;
@@ -255,6 +256,13 @@ static void job_free(mjh_gpu_job *j)
 mjh_gpu_job *mjh_decode_batch_gpu_begin(mij_batch *b, const uint8_t *const *bufs, const int *lens, int n, int req_comp, int threads, int *slots,
 													 const char **reasons, int *rc_out)
 {
+#ifdef MIJ_TIMING_BUILD /* -DMIJ_TIMING_BUILD: per-stage wall times of this call on stderr (development builds only) */
+	double t0_ = 0, t1_ = 0, t2_ = 0, t3_ = 0;
+	struct timespec ts_;
+#define NOW_(v) do { clock_gettime(CLOCK_MONOTONIC, &ts_); v = ts_.tv_sec * 1e3 + ts_.tv_nsec * 1e-6; } while (0)
+#else
+#define NOW_(v) do { } while (0)
+#endif
 	mjh_gpu_job *j = NULL;
 	pool_t *p;
 	size_t cap = 0, used = 0, cnt = (size_t)(n > 0 ? n : 1);
@@ -318,10 +326,6 @@ mjh_gpu_job *mjh_decode_batch_gpu_begin(mij_batch *b, const uint8_t *const *bufs
 		rc = MIJ_E_NOMEM;
 		goto fail;
 	}
-	double t0_ = 0, t1_ = 0, t2_ = 0, t3_ = 0;
-	struct timespec ts_;
-	const int timing_ = getenv("MIJ_TIMING") != NULL;
-#define NOW_(v) do { if (timing_) { clock_gettime(CLOCK_MONOTONIC, &ts_); v = ts_.tv_sec * 1e3 + ts_.tv_nsec * 1e-6; } } while (0)
 	NOW_(t0_);
 	pthread_mutex_init(&p->lock, NULL);
 	run_pool(p, extract_worker, threads);
@@ -361,8 +365,9 @@ mjh_gpu_job *mjh_decode_batch_gpu_begin(mij_batch *b, const uint8_t *const *bufs
 	NOW_(t2_);
 	rc = mij_batch_entropy_launch(b);
 	NOW_(t3_);
-	if (timing_)
-		fprintf(stderr, "gpu_begin: extract %.3f ms, add_stream %.3f ms, launch %.3f ms\n", t1_ - t0_, t2_ - t1_, t3_ - t2_);
+#ifdef MIJ_TIMING_BUILD
+	fprintf(stderr, "gpu_begin: extract %.3f ms, add_stream %.3f ms, launch %.3f ms\n", t1_ - t0_, t2_ - t1_, t3_ - t2_);
+#endif
 	if (rc != MIJ_OK)
 		goto fail;
 	return j;
@@ -389,11 +394,17 @@ int mjh_decode_batch_gpu_end(mjh_gpu_job *j)
 			rc = MIJ_E_NOMEM;
 			goto out;
 		}
+		for (i = 0; i <= j->max_slot; ++i)
+			img_of_slot[i] = -1;
 		for (i = 0; i < p->n; ++i)
 			if (p->slots[i] >= 0)
 				img_of_slot[p->slots[i]] = i;
 		for (i = 0; i < n_fb; ++i) {
-			const int img = img_of_slot[j->fb[i]];
+			const int img = j->fb[i] >= 0 && j->fb[i] <= j->max_slot ? img_of_slot[j->fb[i]] : -1;
+			if (img < 0) { /* a scan of the arena that is not one of this call's pictures (mjh_decode_batch_gpu_begin on a batch that was not reset) */
+				rc = MIJ_E_STATE;
+				goto out;
+			}
 			if (mij_batch_fallback_prepare(p->b, j->fb[i]) != MIJ_OK) {
 				/* no staging planes left for the host walk of this one image: it alone fails, the batch goes on */
 				mij_batch_set_flags(p->b, j->fb[i], MIJ_FLAG_SKIP);
@@ -465,7 +476,9 @@ int mjh_decode_batch(mij_batch *b, const uint8_t *const *bufs, const int *lens, 
 	size_t cap = 0;
 	if (!b || !bufs || !lens || !slots || !reasons || n < 0)
 		return MIJ_E_ARG;
-	if (!mjh_gpu_walk_default() || n == 0)
+	/* a batch that already holds pictures of an earlier call (no reset in between) is extended through the host walk: the GPU walk's
+	 * finish step looks at every scan of the arena, and only this call's slots have an owner here */
+	if (!mjh_gpu_walk_default() || n == 0 || mij_batch_image_count(b) != 0)
 		return mjh_decode_batch_host(b, bufs, lens, n, req_comp, threads, slots, reasons);
 	if (!mij_batch_entropy_stage(b, &cap)) {
 		if (mij_batch_image_count(b) != 0 || mij_batch_entropy_reserve(b, entropy_bytes_for(lens, n) + 4096) != MIJ_OK)

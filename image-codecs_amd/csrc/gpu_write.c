@@ -131,14 +131,14 @@ typedef struct {
 	const int *x, *y, *comp, *slot;
 	unsigned char **out;
 	size_t *out_len;
-	int lo, hi, next, phase, ok;
+	int lo, hi, next, phase, ok, stage_failed;
 	pthread_mutex_t lock;
 } wb_job;
 
 static void *wb_worker(void *arg)
 {
 	wb_job *j = (wb_job *)arg;
-	int good = 0;
+	int good = 0, bad = 0;
 	for (;;) {
 		int i;
 		pthread_mutex_lock(&j->lock);
@@ -149,7 +149,8 @@ static void *wb_worker(void *arg)
 		if (j->slot[i] < 0)
 			continue;
 		if (j->phase == 0) { /* pixels -> the slot's pinned staging */
-			(void)mij_enc_stage_pixels(j->enc, j->slot[i], j->pixels[i]);
+			if (mij_enc_stage_pixels(j->enc, j->slot[i], j->pixels[i]) != MIJ_OK)
+				++bad;
 		} else { /* data units -> byte stream */
 			mjw_plan plan;
 			const int16_t *du = mij_enc_units(j->enc, j->slot[i]);
@@ -170,6 +171,7 @@ static void *wb_worker(void *arg)
 	}
 	pthread_mutex_lock(&j->lock);
 	j->ok += good;
+	j->stage_failed += bad;
 	pthread_mutex_unlock(&j->lock);
 	return NULL;
 }
@@ -206,7 +208,7 @@ int mij_write_jpg_batch(const void *const *pixels, const int *x, const int *y, c
 	pooled_enc pe[2];
 	wb_job j;
 	size_t pix_max = 0, dub_max = 0;
-	int i, *slot, *cend, nchunk = 0, rc = MIJ_OK, have[2] = {0, 0}, img_max = 0, c;
+	int i, *slot, *cend, nchunk = 0, rc = MIJ_OK, have[2] = {0, 0}, queued[2] = {0, 0}, img_max = 0, c;
 	if (!pixels || !x || !y || !comp || !out || !out_len || n < 0)
 		return MIJ_E_ARG;
 	for (i = 0; i < n; ++i) {
@@ -266,9 +268,11 @@ int mij_write_jpg_batch(const void *const *pixels, const int *x, const int *y, c
 	if (threads < 1)
 		threads = 1;
 	for (c = 0; c <= nchunk && rc == MIJ_OK; ++c) {
-		mij_encoder *cur = c < nchunk ? pe[c & 1].enc : NULL, *prev = c > 0 ? pe[(c - 1) & 1].enc : NULL;
+		mij_encoder *cur = c < nchunk ? pe[c & 1].enc : NULL, *prev = c > 0 && queued[(c - 1) & 1] ? pe[(c - 1) & 1].enc : NULL;
 		const int lo = c < nchunk ? (c ? cend[c - 1] : 0) : 0, hi = c < nchunk ? cend[c] : 0;
 		if (cur) { /* stage chunk c and queue its GPU work */
+			int added = 0;
+			queued[c & 1] = 0;
 			if (c >= 2)
 				rc = mij_enc_reset(cur); /* its previous chunk was emitted in the last round */
 			for (i = lo; i < hi && rc == MIJ_OK; ++i)
@@ -276,15 +280,23 @@ int mij_write_jpg_batch(const void *const *pixels, const int *x, const int *y, c
 					slot[i] = mij_enc_add_uncopied(cur, x[i], y[i], comp[i], quality, mjw_flip_on_write());
 					if (slot[i] < 0)
 						rc = slot[i];
+					else
+						++added;
 				}
-			if (rc == MIJ_OK) {
+			/* a chunk in which every picture was refused (NULL pixels, bad arguments) has nothing to upload: its outputs stay NULL */
+			if (rc == MIJ_OK && added) {
 				wb_run(&j, cur, 0, lo, hi, threads);
-				rc = mij_enc_upload(cur);
+				if (j.stage_failed)
+					rc = MIJ_E_ARG;
+				if (rc == MIJ_OK)
+					rc = mij_enc_upload(cur);
+				if (rc == MIJ_OK)
+					rc = mij_enc_launch(cur);
+				if (rc == MIJ_OK)
+					rc = mij_enc_fetch_all_async(cur);
+				if (rc == MIJ_OK)
+					queued[c & 1] = 1;
 			}
-			if (rc == MIJ_OK)
-				rc = mij_enc_launch(cur);
-			if (rc == MIJ_OK)
-				rc = mij_enc_fetch_all_async(cur);
 		}
 		if (prev && rc == MIJ_OK) { /* emit chunk c-1 while chunk c is in flight */
 			rc = mij_enc_wait(prev);
@@ -300,5 +312,11 @@ int mij_write_jpg_batch(const void *const *pixels, const int *x, const int *y, c
 		}
 	free(slot);
 	free(cend);
+	if (rc != MIJ_OK) /* an error return hands nothing over: the streams of earlier chunks are released here, not leaked */
+		for (i = 0; i < n; ++i) {
+			free(out[i]);
+			out[i] = NULL;
+			out_len[i] = 0;
+		}
 	return rc == MIJ_OK ? j.ok : rc;
 }

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -54,7 +55,20 @@ struct mij_ctx {
 	int device;
 	hipDeviceProp_t prop;
 	int max_dyn_lds;
+	/* pinned bounce buffer of the one-slot fetches (d2h_bounced) */
+	std::mutex bounce_lock;
+	uint8_t *bounce = nullptr;
 };
+static const size_t MIJ_BOUNCE_BYTES = (size_t)8 << 20;
+
+/* Device -> caller-owned host memory for the one-slot fetches (mij_batch_fetch, mij_enc_fetch, mij_batch_fetch_coef).  The caller's
+ * buffer is ordinary pageable memory, often never touched before; handing it to hipMemcpyAsync makes the runtime pin, DMA into and
+ * unpin pages this library does not own (or stage through a path shared by every stream of the process).  The
+ * copy therefore lands in a pinned buffer of the context, 8 MiB at a time, and the calling thread copies it out after the stream
+ * has drained: the DMA engine only ever writes memory the library allocated with hipHostMalloc.  (Round 3: the one input of the
+ * twice-seen encoder-leg mismatch that was not a pure function of its arguments was a DMA into a fresh numpy buffer, DESIGN.md
+ * section 8.)  Throughput paths do not come here: they copy whole arenas into pinned memory the caller got from mij_host_alloc. */
+static int d2h_bounced(mij_ctx *ctx, hipStream_t st, void *dst, const void *src_dev, size_t bytes);
 
 extern "C" int mij_ctx_create(int device, mij_ctx **out)
 {
@@ -117,7 +131,32 @@ extern "C" int mij_ctx_create(int device, mij_ctx **out)
  * happen before the HIP runtime initialises, hence a constructor of this library (a process that touched HIP earlier keeps its setting). */
 __attribute__((constructor)) static void mij_hip_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 
-extern "C" void mij_ctx_destroy(mij_ctx *ctx) { delete ctx; }
+extern "C" void mij_ctx_destroy(mij_ctx *ctx)
+{
+	if (!ctx)
+		return;
+	if (ctx->bounce) {
+		(void)hipSetDevice(ctx->device);
+		(void)hipHostFree(ctx->bounce);
+	}
+	delete ctx;
+}
+
+static int d2h_bounced(mij_ctx *ctx, hipStream_t st, void *dst, const void *src_dev, size_t bytes)
+{
+	std::lock_guard<std::mutex> guard(ctx->bounce_lock);
+	if (!ctx->bounce)
+		HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->bounce), MIJ_BOUNCE_BYTES, hipHostMallocDefault));
+	for (size_t off = 0; off < bytes; off += MIJ_BOUNCE_BYTES) {
+		const size_t n = bytes - off < MIJ_BOUNCE_BYTES ? bytes - off : MIJ_BOUNCE_BYTES;
+		HIP_TRY(hipMemcpyAsync(ctx->bounce, static_cast<const uint8_t *>(src_dev) + off, n, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
+		memcpy(static_cast<uint8_t *>(dst) + off, ctx->bounce, n);
+	}
+	if (!bytes)
+		HIP_TRY(hipStreamSynchronize(st));
+	return MIJ_OK;
+}
 extern "C" int mij_ctx_device(const mij_ctx *ctx) { return ctx ? ctx->device : -1; }
 
 extern "C" int mij_ctx_info(const mij_ctx *ctx, char *arch, size_t arch_len, int *cu_count, size_t *total_mem)
@@ -1164,9 +1203,7 @@ extern "C" int mij_batch_fetch(mij_batch *b, int slot, uint8_t *dst, size_t dst_
 	if (dst_bytes < bytes)
 		return set_err(MIJ_E_ARG, "destination too small (%zu < %zu)", dst_bytes, bytes);
 	HIP_TRY(hipSetDevice(b->ctx->device));
-	HIP_TRY(hipMemcpyAsync(dst, b->d_out + s.dev.out_off, bytes, hipMemcpyDeviceToHost, b->stream));
-	HIP_TRY(hipStreamSynchronize(b->stream));
-	return MIJ_OK;
+	return d2h_bounced(b->ctx, b->stream, dst, b->d_out + s.dev.out_off, bytes);
 }
 
 extern "C" int mij_batch_fetch_all_async(mij_batch *b, uint8_t *dst, size_t dst_bytes)
@@ -1299,13 +1336,16 @@ extern "C" int mij_batch_diff_slots(mij_batch *b, const int *sa, const int *sb, 
 								 reinterpret_cast<const uint4 *>(b->d_out + y.dev.out_off), (uint32_t)(bytes / 16), d_cnt);
 		e = hipGetLastError();
 	}
+	int rc_copy = MIJ_OK;
 	if (e == hipSuccess)
-		e = hipMemcpyAsync(&h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost, b->stream);
-	if (e == hipSuccess)
-		e = hipStreamSynchronize(b->stream);
+		rc_copy = d2h_bounced(b->ctx, b->stream, &h_cnt, d_cnt, sizeof(h_cnt));
+	else
+		(void)hipStreamSynchronize(b->stream);
 	(void)hipFree(d_cnt);
 	if (e != hipSuccess)
 		return set_err(MIJ_E_HIP, "mij_batch_diff_slots: %s", hipGetErrorString(e));
+	if (rc_copy != MIJ_OK)
+		return rc_copy;
 	*ndiff = (uint64_t)h_cnt;
 	return MIJ_OK;
 }
@@ -1819,14 +1859,15 @@ extern "C" int mij_batch_fetch_coef(mij_batch *b, int slot, int16_t *dst, size_t
 		return set_err(MIJ_E_ARG, "destination too small");
 	HIP_TRY(hipSetDevice(b->ctx->device));
 	if (!s.coef_bytes_fmt) {
-		HIP_TRY(hipMemcpyAsync(dst, b->d_coef + s.coef_base, elems * sizeof(int16_t), hipMemcpyDeviceToHost, b->stream));
-		HIP_TRY(hipStreamSynchronize(b->stream));
-		return MIJ_OK;
+		return d2h_bounced(b->ctx, b->stream, dst, b->d_coef + s.coef_base, elems * sizeof(int16_t));
 	}
 	/* compact planes: bring the region over and expand it on the host into the int16 tile layout */
 	std::vector<uint8_t> raw(s.coef_bytes);
-	HIP_TRY(hipMemcpyAsync(raw.data(), b->d_coef + s.coef_base, s.coef_bytes, hipMemcpyDeviceToHost, b->stream));
-	HIP_TRY(hipStreamSynchronize(b->stream));
+	{
+		const int rc = d2h_bounced(b->ctx, b->stream, raw.data(), b->d_coef + s.coef_base, s.coef_bytes);
+		if (rc != MIJ_OK)
+			return rc;
+	}
 	size_t roff = 0, eoff = 0;
 	for (int c = 0; c < s.desc.ncomp; ++c) {
 		const size_t nt = comp_tiles(s.desc.comp[c]);
@@ -1873,8 +1914,11 @@ extern "C" int mij_batch_slot_escapes(mij_batch *b, int slot)
 	for (int c = 0; c < s.desc.ncomp; ++c) {
 		const size_t nt = comp_tiles(s.desc.comp[c]);
 		std::vector<uint8_t> lo(nt << 12);
-		HIP_TRY(hipMemcpyAsync(lo.data(), b->d_coef + s.dev.comp[c].coef_off, nt << 12, hipMemcpyDeviceToHost, b->stream));
-		HIP_TRY(hipStreamSynchronize(b->stream));
+		{
+			const int rc = d2h_bounced(b->ctx, b->stream, lo.data(), b->d_coef + s.dev.comp[c].coef_off, nt << 12);
+			if (rc != MIJ_OK)
+				return rc;
+		}
 		for (size_t L = 0; L < (size_t)(s.desc.comp[c].bw * s.desc.comp[c].bh); ++L)
 			total += lo[((L >> 6) << 12) + ((L & 63) << 3)] & 1;
 	}
@@ -2308,9 +2352,7 @@ extern "C" int mij_enc_fetch(mij_encoder *e, int slot, int16_t *dst, size_t dst_
 	if (dst_elems < elems)
 		return set_err(MIJ_E_ARG, "destination too small");
 	HIP_TRY(hipSetDevice(e->ctx->device));
-	HIP_TRY(hipMemcpyAsync(dst, reinterpret_cast<const uint8_t *>(e->d_du) + s.dev.du_off, elems * 2, hipMemcpyDeviceToHost, e->stream));
-	HIP_TRY(hipStreamSynchronize(e->stream));
-	return MIJ_OK;
+	return d2h_bounced(e->ctx, e->stream, dst, reinterpret_cast<const uint8_t *>(e->d_du) + s.dev.du_off, elems * 2);
 }
 
 extern "C" int mij_enc_plan(const mij_encoder *e, int slot, mjw_plan *out)

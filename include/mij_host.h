@@ -127,7 +127,9 @@ int mij_write_jpg_to_func(mjw_write_func *func, void *context, int x, int y, int
 /* A batch of pictures in host memory -> their JPEG byte streams (each what stbi_write_jpg_to_func delivers for that picture,
  * codec/jpeg_write.c:283-366): staging copies on `threads` host threads, ONE GPU launch for every picture's transform, one copy
  * back, Huffman emission on the host threads.  out[i] is a malloc'ed stream of out_len[i] bytes (the caller frees it) or NULL for a
- * picture whose arguments were bad.  Returns the number of streams written, or a negative MIJ_E_* when nothing could be done. */
+ * picture whose arguments were bad (NULL pixels, sizes or comp mjw_plan_init refuses) -- such pictures, even a whole call of them,
+ * are not an error.  Returns the number of streams written, or a negative MIJ_E_* (device or memory failure); on a negative
+ * return every out[i] is NULL again and nothing is left for the caller to free. */
 int mij_write_jpg_batch(const void *const *pixels, const int *x, const int *y, const int *comp, int n, int quality, int threads,
                         unsigned char **out, size_t *out_len);
 /* mjw_emit into memory: bytes written, 0 when `cap` is too small or an argument is bad (cap >= 1024 + 2 bytes per coefficient always fits) */

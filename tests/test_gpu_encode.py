@@ -201,3 +201,21 @@ def test_batch_writer_pipelines_chunks_over_two_encoders(ica, oracle, gpu_ctx):
     got = ica.mij_write_jpg_batch([srcs[i % 3] for i in range(72)], 90, 8)
     for i, g in enumerate(got):
         assert g == want[i % 3], i
+
+
+def test_batch_writer_refused_pictures_are_not_errors(ica, oracle, gpu_ctx):
+    """a picture the writer refuses (NULL pixels; a comp of 5, which mjw_plan_init turns down like codec/jpeg_write.c:216)
+    gives a NULL stream and leaves its neighbours alone -- also when it is the only picture of the call, and when a whole chunk of a
+    multi-chunk call (more than 200 MB of pixels) is refused; the count returned is the number of streams."""
+    good = [ica.synth_rgb(96, 64, 5), ica.synth_rgb(1920, 1080, 1)]
+    want = [oracle.encode(im, 90) for im in good]
+    assert ica.mij_write_jpg_batch([None], 90, 4) == [None]
+    assert ica.mij_write_jpg_batch([None, None, None], 90, 1) == [None] * 3
+    bad_comp = np.zeros((8, 8, 5), np.uint8)
+    assert ica.mij_write_jpg_batch([bad_comp], 90, 2) == [None]
+    got = ica.mij_write_jpg_batch([good[0], None, good[1], bad_comp, good[0]], 90, 3)
+    assert got == [want[0], None, want[1], None, want[0]]
+    # chunks close at 200 MB of pixels (33 x 1080p): 33 good | 3 refused + 33 good | 2 refused -- the last chunk holds nothing to upload
+    pics = [good[1]] * 33 + [None] * 3 + [good[1]] * 33 + [None] * 2
+    got = ica.mij_write_jpg_batch(pics, 90, 8)
+    assert got == [want[1]] * 33 + [None] * 3 + [want[1]] * 33 + [None] * 2

@@ -17,6 +17,11 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+latest = src + ".latest"  # tools/profile_r2.sh writes every run into its own directory and names the newest one here
+if len(sys.argv) > 2:
+    src = sys.argv[2]
+elif os.path.exists(latest):
+    src = os.path.join(ROOT, "gpurun_out", open(latest).read().strip())
 
 
 def one(pattern):
