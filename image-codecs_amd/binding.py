@@ -541,6 +541,20 @@ class Batch:
         """Blocks of the slot that hold a coefficient outside -128..127 (compact planes only)."""
         return _check(lib().mij_batch_slot_escapes(self._h, int(slot)), "mij_batch_slot_escapes")
 
+    def count_idct_classes(self, on=True):
+        """Measurement: make the launches that follow count wavefronts per sparse-block class (clears the counters when switched on)."""
+        L = lib()
+        L.mij_batch_count_idct_classes.argtypes = [C.c_void_p, C.c_int]
+        _check(L.mij_batch_count_idct_classes(self._h, int(bool(on))), "mij_batch_count_idct_classes")
+
+    def idct_class_counts(self):
+        """[DC only, inside 2x2, inside 4x4, full] wavefronts since count_idct_classes(True)"""
+        L = lib()
+        out = (C.c_uint64 * 4)()
+        L.mij_batch_idct_class_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        _check(L.mij_batch_idct_class_counts(self._h, out), "mij_batch_idct_class_counts")
+        return [int(v) for v in out]
+
     def entropy_rounds(self):
         L = lib()
         L.mij_batch_entropy_rounds.argtypes = [C.c_void_p]

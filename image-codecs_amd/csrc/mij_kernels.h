@@ -381,17 +381,9 @@ __device__ __forceinline__ CoefView coef_view(const uint8_t *__restrict__ coef, 
  * with coef == sext8(low) + 256*h (mod 2^16); (short)(coef*q) == (short)(sext8(low)*q) + ((h*q & 255) << 8), so
  * the fix is, per pair, two SDWA byte multiplies into bytes 1 and 3 of a zeroed register and one v_pk_add_u16.
  * The branch is wave-uniform (any lane escaped); lanes without escapes add zero. */
-__device__ __forceinline__ void load_block_b8(const CoefView &cv, uint32_t L, const uint32_t *__restrict__ dq, uint4 (&c)[8])
+/* the unpack + de-quantise step on a block's loaded low bytes h[] and DC term (escape bytes are fetched here when a lane needs them) */
+__device__ __forceinline__ void dequant_block_b8(const CoefView &cv, uint32_t L, const uint32_t *__restrict__ dq, const uint2 (&h)[8], uint32_t dc, uint4 (&c)[8])
 {
-	const uint8_t *base = cv.plane + ((size_t)(L >> 6) << 12) + ((size_t)(L & 63u) << 3);
-	uint2 h[8];
-#pragma unroll
-	for (int k = 0; k < 8; ++k) {
-		typedef uint32_t u2v __attribute__((ext_vector_type(2)));
-		const u2v v = __builtin_nontemporal_load(reinterpret_cast<const u2v *>(base + (k << 9)));
-		h[k] = make_uint2(v.x, v.y);
-	}
-	const uint32_t dc = *reinterpret_cast<const uint16_t *>(cv.dc + 2u * (size_t)L);
 	const bool esc = (h[0].x & 1u) != 0;
 	/* the low halves of the four pairs first, then the high halves: the instruction that preserves a register's
 	 * other half never directly follows the one that wrote it (dst_sel forwarding), and the s_nop covers the first
@@ -443,6 +435,20 @@ __device__ __forceinline__ void load_block_b8(const CoefView &cv, uint32_t L, co
 		 : "v"(dc), "s"(dq[0]));
 }
 
+__device__ __forceinline__ void load_block_b8(const CoefView &cv, uint32_t L, const uint32_t *__restrict__ dq, uint4 (&c)[8])
+{
+	const uint8_t *base = cv.plane + ((size_t)(L >> 6) << 12) + ((size_t)(L & 63u) << 3);
+	uint2 h[8];
+#pragma unroll
+	for (int k = 0; k < 8; ++k) {
+		typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+		const u2v v = __builtin_nontemporal_load(reinterpret_cast<const u2v *>(base + (k << 9)));
+		h[k] = make_uint2(v.x, v.y);
+	}
+	const uint32_t dc = *reinterpret_cast<const uint16_t *>(cv.dc + 2u * (size_t)L);
+	dequant_block_b8(cv, L, dq, h, dc, c);
+}
+
 /* one block in either format: the coefficients of c[] come out de-quantised for B8, quantised otherwise */
 template <bool B8>
 __device__ __forceinline__ void load_block_fmt(const CoefView &cv, uint32_t L, const uint32_t *__restrict__ dq, uint4 (&c)[8])
@@ -451,6 +457,223 @@ __device__ __forceinline__ void load_block_fmt(const CoefView &cv, uint32_t L, c
 		load_block_b8(cv, L, dq, c);
 	else
 		load_block(cv.plane, L, c);
+}
+
+/* ------------------------------------------------------------------ sparse blocks (round 3)
+ *
+ * The reference skips work on sparse blocks one column at a time (codec/jpeg.c:625-633: a column whose rows 1..7 are zero is
+ * "dcterm = d[0]*4").  A lane cannot branch per column, but a WAVE can branch per block class: most chroma blocks of an ordinary
+ * picture hold a DC term and a handful of low frequencies (the benchmark's 1080p batch: 89 % of the Cb wavefronts are DC-only, every
+ * Cr wavefront lies inside the top-left 2x2, luma is dense), so the 64 blocks of a wavefront are classified by the extent of their
+ * non-zero coefficients and the wave takes the cheapest transform that covers all of them:
+ *     class 0  DC only          sample = clamp(((short)(dc*q0) * 16384 + 65536 + (128<<17)) >> 17) for all 64 positions
+ *     class 1  inside the 2x2   column pass on columns 0-1 with s2..s7 = 0, row pass with inputs 2..7 = 0
+ *     class 2  inside the 4x4   column pass on columns 0-3 with s4..s7 = 0, row pass with inputs 4..7 = 0
+ *     class 3  anything         the full transform (idct_block)
+ * Exact by construction: the dropped terms are products with zero (the transform is linear over Z/2^32, see idct1d_packed), the
+ * dropped columns give (0 + 512) >> 10 = 0, and the packed second pass needs the same int16 guarantee as the full one.  The class
+ * is computed from the loaded coefficients themselves (about twenty OR / AND instructions a block, 4 % of a full transform) --
+ * not from a flag a producer wrote -- so no plane a producer gets wrong can change a pixel; an escaped block (a coefficient
+ * beyond a byte) is class 3.  Streams that need the WIDE second pass take class 3 throughout.
+ * MIJ_DEV_COUNT_CLASSES in DevImage.flags: lane 0 of every wavefront adds one to g_idct_class[class] (measurement only). */
+#define MIJ_DEV_COUNT_CLASSES 0x200
+__device__ unsigned long long g_idct_class[4];
+
+__device__ __forceinline__ uint32_t or3(uint32_t a, uint32_t b, uint32_t c) { return a | b | c; }
+
+/* wave-uniform class from per-lane "has a non-zero outside ..." words (0 = nothing outside) */
+__device__ __forceinline__ int wave_class(uint32_t bad1, uint32_t bad2, uint32_t bad4)
+{
+	if (__builtin_amdgcn_ballot_w64(bad4 != 0u) != 0ull)
+		return 3;
+	if (__builtin_amdgcn_ballot_w64(bad2 != 0u) != 0ull)
+		return 2;
+	if (__builtin_amdgcn_ballot_w64(bad1 != 0u) != 0ull)
+		return 1;
+	return 0;
+}
+
+/* compact planes: h[k] = column k as the bytes (r0 r4 r2 r6 | r1 r3 r5 r7); byte 0 of h[0].x is the block's flags byte (bit 0: escaped) */
+__device__ __forceinline__ int block_class_b8(const uint2 (&h)[8])
+{
+	const uint32_t z47 = or3(or3(h[4].x, h[4].y, h[5].x), or3(h[5].y, h[6].x, h[6].y), h[7].x | h[7].y);
+	const uint32_t x01 = h[0].x | h[1].x, y01 = h[0].y | h[1].y, x23 = h[2].x | h[3].x, y23 = h[2].y | h[3].y;
+	/* outside the 4x4: columns 4-7, rows 4-7 of columns 0-3 (r4, r6: bytes 1, 3 of .x; r5, r7: bytes 2, 3 of .y); an escaped block counts */
+	const uint32_t bad4 = or3(z47, (x01 | x23) & 0xff00ff00u, (y01 | y23) & 0xffff0000u) | (h[0].x & 1u);
+	/* outside the 2x2: also columns 2-3 and rows 2-3 of columns 0-1 (r2: byte 2 of .x; r3: byte 1 of .y) */
+	const uint32_t bad2 = or3(bad4, x23 | y23, (x01 & 0x00ff0000u) | (y01 & 0x0000ff00u));
+	/* any AC term: also column 1 and row 1 of column 0 (byte 0 of h[0].x is not a coefficient) */
+	const uint32_t bad1 = or3(bad2, h[1].x | h[1].y, h[0].y & 0xffu);
+	return wave_class(bad1, bad2, bad4);
+}
+
+/* int16 tile layout: c[k] = column k as the pairs .x = (r0, r4) .y = (r2, r6) .z = (r1, r3) .w = (r5, r7), quantised */
+__device__ __forceinline__ int block_class_i16(const uint4 (&c)[8])
+{
+	uint32_t z47 = 0;
+#pragma unroll
+	for (int k = 4; k < 8; ++k)
+		z47 = or3(z47, c[k].x | c[k].y, c[k].z | c[k].w);
+	const uint32_t xy01 = or3(c[0].x, c[0].y, c[1].x | c[1].y), xy23 = or3(c[2].x, c[2].y, c[3].x | c[3].y);
+	const uint32_t w03 = or3(c[0].w, c[1].w, c[2].w | c[3].w);
+	const uint32_t bad4 = or3(z47, w03, (xy01 | xy23) & 0xffff0000u);
+	const uint32_t bad2 = or3(bad4, or3(xy23, c[2].z, c[3].z), or3(c[0].y, c[1].y, (c[0].z | c[1].z) & 0xffff0000u));
+	const uint32_t bad1 = or3(bad2, or3(c[1].x, c[1].z, c[0].z), c[0].x & 0xffff0000u);
+	return wave_class(bad1, bad2, bad4);
+}
+
+/* (v >> S) as an int16 in the low half, zero above (so that the untouched high input of a v_dot2 contributes nothing) */
+template <int S>
+__device__ __forceinline__ uint32_t shr_lo16(int v) { return __builtin_amdgcn_ubfe((uint32_t)v, S, 16); }
+/* ((lo >> S) | (hi >> S) << 16) for one pair: see shr_pack8_i16 */
+template <int S>
+__device__ __forceinline__ uint32_t shr_pack_i16(int lo, int hi)
+{
+	uint32_t o;
+	asm("v_ashrrev_i32 %0, %3, %1\n\tv_ashrrev_i32_sdwa %0, %3, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\ts_nop 0"
+		 : "=&v"(o)
+		 : "v"(lo), "v"(hi), "n"(S));
+	return o;
+}
+
+/* STBI__IDCT_1D with s4..s7 = 0 (N = 4: d04 = (s0, 0), d26 = (s2, 0), d13 = (s1, s3)) or s2..s7 = 0 (N = 2: d04 = (s0, 0),
+ * d13 = (s1, 0)): idct1d_packed minus the products with zero */
+template <int N>
+__device__ __forceinline__ Idct1D idct1d_low(const IdctK &K, int bias, uint32_t d04, uint32_t d26, uint32_t d13)
+{
+	const int e = dot2(d04, K.e0, bias);
+	uint32_t x0 = (uint32_t)e, x1 = (uint32_t)e, x2 = (uint32_t)e, x3 = (uint32_t)e;
+	if (N == 4) {
+		x0 = (uint32_t)dot2(d26, K.x0, e);
+		x3 = (uint32_t)dot2(d26, K.x3, e);
+		x1 = (uint32_t)dot2(d26, K.x1, e);
+		x2 = (uint32_t)dot2(d26, K.x2, e);
+	}
+	const uint32_t t3 = (uint32_t)dot2z(d13, K.t3a), t2 = (uint32_t)dot2z(d13, K.t2a), t1 = (uint32_t)dot2z(d13, K.t1a), t0 = (uint32_t)dot2z(d13, K.t0a);
+	Idct1D r;
+	r.o[0] = (int)(x0 + t3);
+	r.o[7] = (int)(x0 - t3);
+	r.o[1] = (int)(x1 + t2);
+	r.o[6] = (int)(x1 - t2);
+	r.o[2] = (int)(x2 + t1);
+	r.o[5] = (int)(x2 - t1);
+	r.o[3] = (int)(x3 + t0);
+	r.o[4] = (int)(x3 - t0);
+	return r;
+}
+
+/* classes 1 and 2 on de-quantised pairs: q[k] = column k as (s0, 0) (s2, 0) (s1, s3) -- N = 2: (s0, 0) - (s1, 0) */
+template <int N>
+__device__ __forceinline__ void idct_block_low(const IdctK &K, const uint32_t (&q04)[4], const uint32_t (&q26)[4], const uint32_t (&q13)[4], uint2 (&rows)[8])
+{
+	Idct1D v[N];
+#pragma unroll
+	for (int k = 0; k < N; ++k)
+		v[k] = idct1d_low<N>(K, K.bias1, q04[k], q26[k], q13[k]);
+#pragma unroll
+	for (int i = 0; i < 8; ++i) {
+		const uint32_t p04 = shr_lo16<10>(v[0].o[i]);
+		const uint32_t p26 = N == 4 ? shr_lo16<10>(v[2].o[i]) : 0u;
+		const uint32_t p13 = N == 4 ? shr_pack_i16<10>(v[1].o[i], v[3].o[i]) : shr_lo16<10>(v[1].o[i]);
+		const Idct1D r = idct1d_low<N>(K, K.bias2, p04, p26, p13);
+		pack_row(r, rows[i].x, rows[i].y);
+	}
+}
+
+/* class 0: every sample of the block is clamp((dcq * 16384 + 65536 + (128 << 17)) >> 17), dcq = (short)(dc * q0) sign-extended */
+__device__ __forceinline__ void idct_block_dc(const IdctK &K, int dcq, uint2 (&rows)[8])
+{
+	const int x = dcq * 16384 + K.bias2;
+	const uint32_t p = sat4<17>(x, x, x, x);
+#pragma unroll
+	for (int i = 0; i < 8; ++i)
+		rows[i] = make_uint2(p, p);
+}
+
+/* One block per lane from either plane format through the cheapest transform that covers the wavefront's blocks.
+ * Returns the class taken (wave-uniform).  count != 0 (wave-uniform): measurement, see MIJ_DEV_COUNT_CLASSES. */
+template <bool WIDE, bool B8>
+__device__ __forceinline__ int load_idct_block(const IdctK &K, const CoefView &cv, uint32_t L, const uint32_t *__restrict__ dq, uint2 (&rows)[8], int count)
+{
+	uint4 c[8];
+	int cls = 3;
+	if constexpr (WIDE) {
+		load_block_fmt<B8>(cv, L, dq, c);
+		idct_block<WIDE, B8>(K, c, dq, rows);
+	} else if constexpr (B8) {
+		const uint8_t *base = cv.plane + ((size_t)(L >> 6) << 12) + ((size_t)(L & 63u) << 3);
+		uint2 h[8];
+#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+			typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+			const u2v v = __builtin_nontemporal_load(reinterpret_cast<const u2v *>(base + (k << 9)));
+			h[k] = make_uint2(v.x, v.y);
+		}
+		const uint32_t dc = *reinterpret_cast<const uint16_t *>(cv.dc + 2u * (size_t)L);
+		cls = block_class_b8(h);
+		if (cls == 3) {
+			dequant_block_b8(cv, L, dq, h, dc, c);
+			idct_block<WIDE, B8>(K, c, dq, rows);
+		} else if (cls == 0) {
+			int dcq;
+			asm("v_mul_i32_i24_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_0\n\tv_bfe_i32 %0, %0, 0, 16" : "=&v"(dcq) : "v"(dc), "s"(dq[0]));
+			idct_block_dc(K, dcq, rows);
+		} else {
+			/* (short)(coef * q) of the terms the class keeps: low halves with a zero above them, (s1, s3) as a pair for the 4x4 */
+			uint32_t q04[4], q26[4], q13[4];
+#define MIJ_DQP(dst, src, q, b) "v_mul_i32_i24_sdwa " dst ", sext(" src "), " q " dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:" b " src1_sel:WORD_0\n\t"
+#define MIJ_DQH(dst, src, q, b) "v_mul_i32_i24_sdwa " dst ", sext(" src "), " q " dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:" b " src1_sel:WORD_1\n\t"
+			if (cls == 2) {
+#pragma unroll
+				for (int k = 0; k < 4; ++k)
+					asm(MIJ_DQP("%0", "%3", "%5", "BYTE_0") MIJ_DQP("%1", "%3", "%6", "BYTE_2") MIJ_DQP("%2", "%4", "%7", "BYTE_0") MIJ_DQH("%2", "%4", "%7", "BYTE_1") "s_nop 0"
+						 : "=&v"(q04[k]), "=&v"(q26[k]), "=&v"(q13[k])
+						 : "v"(h[k].x), "v"(h[k].y), "s"(dq[4 * k + 0]), "s"(dq[4 * k + 1]), "s"(dq[4 * k + 2]));
+			} else {
+#pragma unroll
+				for (int k = 0; k < 2; ++k) {
+					asm(MIJ_DQP("%0", "%2", "%4", "BYTE_0") MIJ_DQP("%1", "%3", "%5", "BYTE_0") "s_nop 0"
+						 : "=&v"(q04[k]), "=&v"(q13[k])
+						 : "v"(h[k].x), "v"(h[k].y), "s"(dq[4 * k + 0]), "s"(dq[4 * k + 2]));
+					q26[k] = 0;
+				}
+				q04[2] = q04[3] = q26[2] = q26[3] = q13[2] = q13[3] = 0;
+			}
+#undef MIJ_DQP
+#undef MIJ_DQH
+			/* the DC term replaces the flags byte's product */
+			asm("v_mul_i32_i24_sdwa %0, sext(%1), %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_0\n\ts_nop 0" : "=v"(q04[0]) : "v"(dc), "s"(dq[0]));
+			if (cls == 2)
+				idct_block_low<4>(K, q04, q26, q13, rows);
+			else
+				idct_block_low<2>(K, q04, q26, q13, rows);
+		}
+	} else {
+		load_block(cv.plane, L, c);
+		cls = block_class_i16(c);
+		if (cls == 3) {
+			idct_block<WIDE, B8>(K, c, dq, rows);
+		} else if (cls == 0) {
+			idct_block_dc(K, (int)(short)(pkmul(c[0].x, dq[0]) & 0xffffu), rows);
+		} else {
+			uint32_t q04[4], q26[4], q13[4];
+#pragma unroll
+			for (int k = 0; k < 4; ++k) { /* the class guarantees zero high halves where a pair is (s, 0) */
+				q04[k] = pkmul(c[k].x, dq[4 * k + 0]);
+				q26[k] = pkmul(c[k].y, dq[4 * k + 1]);
+				q13[k] = pkmul(c[k].z, dq[4 * k + 2]);
+			}
+			if (cls == 2)
+				idct_block_low<4>(K, q04, q26, q13, rows);
+			else
+				idct_block_low<2>(K, q04, q26, q13, rows);
+		}
+	}
+	if (count) {
+		if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u)
+			atomicAdd(&g_idct_class[cls], 1ull);
+	}
+	return cls;
 }
 
 /* ------------------------------------------------------------------ colour (codec/jpeg.c:1976-2018)
@@ -1069,6 +1292,7 @@ __device__ __forceinline__ void fused_band(const DevImage *__restrict__ imgs, co
 	KI.init();
 	ColorK KC;
 	KC.init();
+	const int count_classes = im.flags & MIJ_DEV_COUNT_CLASSES;
 
 	/* ---- chroma-only IDCT of block row mc, keeping sample row 7 (keep != 0) or 0 in dstCb/dstCr (halo rows) */
 	auto chroma_halo = [&](int mc, int keep, uint8_t *dstCb, uint8_t *dstCr) {
@@ -1196,32 +1420,22 @@ __device__ __forceinline__ void fused_band(const DevImage *__restrict__ imgs, co
 
 	for (int m = m0; m < m1; ++m) {
 		__syncthreads(); /* previous phase B (and the prologue) done with the planes / save buffers */
-		/* ---- phase A: IDCT of MCU row m, one block per lane, component uniform per wave */
+		/* ---- phase A: IDCT of MCU row m, one block per lane, component uniform per wave; one call site for the three components
+		 * (the sparse-class transforms of load_idct_block are instantiated once per kernel) */
 		for (int ww = wave; ww < nYw + 2 * nCw; ww += NT / 64) {
-			uint4 c[8];
 			uint2 rows[8];
-			if (ww < nYw) {
-				const int i = ww * 64 + lane; /* block of the two luma block rows 2m, 2m+1 (contiguous in L) */
-				if (i < 2 * bwY) {
-					load_block_fmt<B8>(cvY, (uint32_t)(2 * m * bwY + i), im.dq[0], c);
-					idct_block<WIDE, B8>(KI, c, im.dq[0], rows);
-					const int by = i >= bwY ? 1 : 0, bx = i - by * bwY;
-					uint8_t *dst = sY + (8 * by) * YP + 8 * bx;
+			const int comp = ww < nYw ? 0 : ((ww - nYw) < nCw ? 1 : 2); /* wave-uniform */
+			const int i = (ww - (comp == 0 ? 0 : (comp == 1 ? nYw : nYw + nCw))) * 64 + lane; /* luma: block of the two block rows 2m, 2m+1 (contiguous in L) */
+			const int nblk = comp == 0 ? 2 * bwY : bwC;
+			if (i < nblk) {
+				const int by = (comp == 0 && i >= bwY) ? 1 : 0, bx = i - by * bwY;
+				const int pitch = comp == 0 ? YP : CP;
+				const uint32_t L = (uint32_t)((comp == 0 ? 2 * m * bwY : m * bwC) + i);
+				load_idct_block<WIDE, B8>(KI, comp == 0 ? cvY : (comp == 1 ? cvCb : cvCr), L, im.dq[comp], rows, count_classes);
+				uint8_t *dst = (comp == 0 ? sY : (comp == 1 ? sCb : sCr)) + (8 * by) * pitch + 8 * bx;
 #pragma unroll
-					for (int r = 0; r < 8; ++r)
-						*reinterpret_cast<uint2 *>(dst + r * YP) = rows[r];
-				}
-			} else {
-				const int comp = (ww - nYw) < nCw ? 1 : 2;
-				const int bx = ((ww - nYw) - (comp == 2 ? nCw : 0)) * 64 + lane;
-				if (bx < bwC) {
-					load_block_fmt<B8>(comp == 1 ? cvCb : cvCr, (uint32_t)(m * bwC + bx), im.dq[comp], c);
-					idct_block<WIDE, B8>(KI, c, im.dq[comp], rows);
-					uint8_t *dst = (comp == 1 ? sCb : sCr) + 8 * bx;
-#pragma unroll
-					for (int r = 0; r < 8; ++r)
-						*reinterpret_cast<uint2 *>(dst + r * CP) = rows[r];
-				}
+				for (int r = 0; r < 8; ++r)
+					*reinterpret_cast<uint2 *>(dst + r * pitch) = rows[r];
 			}
 		}
 		__syncthreads();

@@ -1925,6 +1925,51 @@ extern "C" int mij_batch_slot_escapes(mij_batch *b, int slot)
 	return total;
 }
 
+/* Measurement: how many wavefronts of the decode kernels took which sparse-block transform (mij_kernels.h, "sparse blocks").  With
+ * on != 0 every image descriptor of the uploaded batch gets MIJ_DEV_COUNT_CLASSES and the device counters are cleared; the launches
+ * that follow add to them; mij_batch_idct_class_counts waits for the stream and reads them.  Off by default: the timed launches of
+ * bench.py run without it. */
+extern "C" int mij_batch_count_idct_classes(mij_batch *b, int on)
+{
+	if (!b)
+		return set_err(MIJ_E_ARG, "batch is NULL");
+	if (!b->uploaded)
+		return set_err(MIJ_E_STATE, "mij_batch_count_idct_classes before mij_batch_upload");
+	HIP_TRY(hipSetDevice(b->ctx->device));
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	const size_t n = b->slots.size();
+	for (size_t i = 0; i < n; ++i) {
+		if (on)
+			b->h_imgs[i].flags |= MIJ_DEV_COUNT_CLASSES;
+		else
+			b->h_imgs[i].flags &= ~(int32_t)MIJ_DEV_COUNT_CLASSES;
+	}
+	HIP_TRY(copy_table(b->d_imgs, b->h_imgs, sizeof(DevImage) * n, b->stream));
+	if (on) {
+		void *sym = nullptr;
+		HIP_TRY(hipGetSymbolAddress(&sym, HIP_SYMBOL(g_idct_class)));
+		HIP_TRY(hipMemsetAsync(sym, 0, sizeof(unsigned long long) * 4, b->stream));
+	}
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	return MIJ_OK;
+}
+
+extern "C" int mij_batch_idct_class_counts(mij_batch *b, uint64_t out[4])
+{
+	if (!b || !out)
+		return set_err(MIJ_E_ARG, "bad argument");
+	HIP_TRY(hipSetDevice(b->ctx->device));
+	void *sym = nullptr;
+	HIP_TRY(hipGetSymbolAddress(&sym, HIP_SYMBOL(g_idct_class)));
+	unsigned long long v[4];
+	const int rc = d2h_bounced(b->ctx, b->stream, v, sym, sizeof(v));
+	if (rc != MIJ_OK)
+		return rc;
+	for (int i = 0; i < 4; ++i)
+		out[i] = v[i];
+	return MIJ_OK;
+}
+
 extern "C" int mij_batch_slot_coef_bytes(const mij_batch *b, int slot)
 {
 	if (!b || slot < 0 || slot >= (int)b->slots.size())

@@ -275,6 +275,14 @@ int mij_batch_set_coef_format(mij_batch *b, int fmt);
 int mij_batch_slot_coef_bytes(const mij_batch *b, int slot);
 /* number of escaped blocks of a slot (blocks holding a coefficient outside -128..127), read back from HBM; tests */
 int mij_batch_slot_escapes(mij_batch *b, int slot);
+
+/* Measurement only: the decode kernels transform a wavefront's 64 blocks with the cheapest IDCT that covers all of them
+ * (class 0: DC only -- the reference's own shortcut, codec/jpeg.c:625-633, taken per block instead of per column; 1: non-zeros
+ * inside the top-left 2x2; 2: inside the 4x4; 3: the full transform).  mij_batch_count_idct_classes(b, 1) after mij_batch_upload
+ * clears the device counters and makes the batch's launches count wavefronts per class; mij_batch_idct_class_counts reads them
+ * (out[class]); (b, 0) switches the counting off again.  Counting costs an atomic per wavefront: never on in timed launches. */
+int mij_batch_count_idct_classes(mij_batch *b, int on);
+int mij_batch_idct_class_counts(mij_batch *b, uint64_t out[4]);
 /* tests / tuning: synchronisation rounds the last entropy_run needed for its slowest image */
 int mij_batch_entropy_rounds(const mij_batch *b);
 
