@@ -245,6 +245,18 @@ def add_traffic(res, key):
 
 # ---------------------------------------------------------------------------------------------------- secondary legs
 
+def idct_classes(bt):
+    """one more (untimed) launch with the kernels counting wavefronts per sparse-block class (mij.h, mij_batch_count_idct_classes): the
+    fraction of the launch's IDCT wavefronts that took the DC-only / 2x2 / 4x4 / full transform"""
+    bt.count_idct_classes(True)
+    bt.launch()
+    bt.wait()
+    c = bt.idct_class_counts()
+    bt.count_idct_classes(False)
+    tot = float(max(1, sum(c)))
+    return {"dc_only": round(c[0] / tot, 4), "inside_2x2": round(c[1] / tot, 4), "inside_4x4": round(c[2] / tot, 4), "full": round(c[3] / tot, 4), "wavefronts": int(sum(c))}
+
+
 def leg_decode_1080p(ica, ctx, datas, count, fmt, cbytes, obytes, args, expect_path=1, src_hash=None, checker=None, generic=0):
     """Kernel-resident timing of `count` 1080p images in the given plane format; returns (result dict, plane format seen)."""
     bt, owners, _ = resident_batch(ica, ctx, datas, 0, count, fmt, cbytes, obytes, generic)
@@ -264,7 +276,7 @@ def leg_decode_1080p(ica, ctx, datas, count, fmt, cbytes, obytes, args, expect_p
         ms = timed_launches(bt, args.steps)
         esc = sum(bt.slot_escapes(s) for s, (k, src) in enumerate(owners) if src is None) if fmt == "compact" else 0
         return {"kernel_ms_per_launch": round(ms, 4), "images": count, "warmup_launches_issued": n_warm, "parity": True,
-                "escaped_blocks_in_sources": esc}, bt.slot_coef_bytes(0)
+                "escaped_blocks_in_sources": esc, "idct_wavefront_classes": idct_classes(bt)}, bt.slot_coef_bytes(0)
     finally:
         bt.close()
 
@@ -304,6 +316,7 @@ def leg_config4(ica, ctx, args, checker):
                "parity": True, "parity_against": kind, "warmup_launches_issued": n_warm,
                "host_progressive_stage_mpix_s_single_thread": round(size * size / host_s / 1e6, 1), "setup_s": round(time.time() - t0, 1)}
         add_traffic(res, "k_fused444_compact_%d" % n)
+        res["idct_wavefront_classes"] = idct_classes(b)
         # end to end for this layout: 16 streams in host RAM -> pixels in HBM, every scan walked on the host threads (progressive
         # scans cannot take the GPU walk: AC refinement does not re-synchronise), planes re-staged, packed, transformed
         b.close()
@@ -577,6 +590,91 @@ def leg_two_pass(ica, ctx, datas, args, checker):
     return out
 
 
+def gpu_walk_ring(ica, ctx, datas, distinct, n_g, threads, src_hash, cbytes, obytes):
+    """JPEG bytes in host RAM -> pixels in HBM with the Huffman walk on the GPU (mjh_decode_batch_gpu_begin / _end): a ring of `depth`
+    batches of `gchunk` pictures each on its own stream, the host threads parsing headers and removing byte stuffing for the next
+    chunk while the walks of the previous ones run; the same once more with every chunk's pixels copied to pinned host memory.  Runs on
+    every rank at N > 1 (its own slice, its own share of the host cores): this is what north_star's scaling question is about."""
+    res = {}
+    ebs, gpins = [], []
+    try:
+        jg = [datas[i % distinct] for i in range(n_g)]  # this leg is fast: enough chunks for the pipeline to reach its steady state (the images cycle)
+        depth = max(2, int(os.environ.get("MIJ_BENCH_GPU_DEPTH", "4")))  # batches in the ring = walks in flight
+        # chunks of 256 pictures, four batches: measured against 128 / 512 and three / six batches (tools/bench_gpu_walk.py, DESIGN.md 4b)
+        gchunk = max(1, min(int(os.environ.get("MIJ_BENCH_GPU_CHUNK", "256")), n_g // depth))
+        # no coefficient staging to speak of: it is only needed for images the GPU walk hands back
+        ebs = [ica.Batch(ctx, gchunk, cbytes * 4, cbytes * gchunk, obytes * gchunk) for _ in range(depth)]
+        for eb in ebs:
+            eb.entropy_reserve(sum(len(x) * 9 // 8 + 4352 for x in jg[:gchunk]))
+        for eb in ebs:  # warm-up
+            eb.reset()
+            eb.decode_jpegs(jg[:gchunk], 3, threads, gpu_entropy=True)
+            eb.submit()
+            eb.wait()
+        last = {}
+        # begin(k) runs depth-1 chunks ahead of end(k): the walk kernels are latency bound (one chunk is ~2 workgroups
+        # per CU), so several walks in flight on their own streams is what fills the GPU, and the host parses the next
+        # headers meanwhile
+        use_pins = []  # filled for the D2H variant below: one pinned buffer per ring batch
+
+        def finish(side, pjob, plo, plen):
+            ok, slots, reasons = ebs[side].decode_jpegs_gpu_end(pjob)
+            assert ok == plen, reasons
+            ebs[side].submit()
+            if use_pins:
+                ebs[side].fetch_all_async(use_pins[side].ptr, use_pins[side].nbytes)
+            last[side] = (plo + plen - 1, slots[plen - 1])
+
+        def one_pass():
+            t0 = time.perf_counter()
+            pending = []  # (side, job, first image, count) in begin order
+            for k, lo in enumerate(range(0, n_g, gchunk)):
+                eb = ebs[k % depth]
+                eb.reset()
+                part = jg[lo:lo + gchunk]
+                pending.append((k % depth, eb.decode_jpegs_gpu_begin(part, 3, threads), lo, len(part)))
+                if len(pending) == depth:
+                    finish(*pending.pop(0))
+            for item in pending:
+                finish(*item)
+            for eb in ebs:
+                eb.wait()
+            return time.perf_counter() - t0
+
+        passes = [one_pass() for _ in range(3)]  # the leg takes ~0.1 s: three passes, in order; the first follows an idle GPU
+        t_gpu = sorted(passes)[1]
+        for side, (img, slot) in last.items():
+            assert ebs[side].hash_out(slot) == src_hash[img % distinct], "GPU-walked image differs"
+        res["value_gpu_entropy"] = round(n_g * W * H / t_gpu / 1e6, 1)
+        res["gpu_entropy_seconds"] = round(t_gpu, 5)
+        res["gpu_entropy_images"] = n_g
+        res["gpu_entropy_host_threads"] = threads
+        res["gpu_entropy_sync_rounds"] = ebs[0].entropy_rounds()
+        res["gpu_entropy_chunk_images"] = gchunk
+        res["gpu_entropy_batches_in_flight"] = depth
+        res["gpu_entropy_passes_mpix_s"] = [round(n_g * W * H / t / 1e6, 1) for t in passes]
+        # the same ring with every chunk's pixels copied to pinned host memory behind its kernels (3 B/px over PCIe: the
+        # link, not the GPU, sets this figure)
+        gpins.extend(ica.PinnedBuffer(obytes * gchunk) for _ in range(depth))
+        use_pins.extend(gpins)
+        t_gd = sorted(one_pass() for _ in range(3))[1]
+        for side, (img, slot) in last.items():
+            off = ebs[side].out_offset(slot)
+            assert np.array_equal(gpins[side].array[off:off + W * H * 3], ebs[side].fetch(slot).reshape(-1)), "D2H copy of a GPU-walked image differs"
+        res["value_gpu_entropy_with_d2h"] = round(n_g * W * H / t_gd / 1e6, 1)
+        res["gpu_entropy_with_d2h_seconds"] = round(t_gd, 5)
+        res["d2h_gb_s"] = round(n_g * W * H * 3 / t_gd / 1e9, 1)
+    except ica.MijError as exc:
+        res["value_gpu_entropy"] = None
+        res["gpu_entropy_error"] = str(exc)
+    finally:
+        for pb in gpins:
+            pb.close()
+        for eb in ebs:
+            eb.close()
+    return res
+
+
 def end_to_end(ica, ctx, datas, distinct, n_img, src_hash, cbytes, obytes, args):
     """Outside the timed region (rank 0, one GPU): bitstream in host RAM -> RGB in HBM, three ways."""
     n_e = min(args.e2e_images, n_img)
@@ -640,78 +738,10 @@ def end_to_end(ica, ctx, datas, distinct, n_img, src_hash, cbytes, obytes, args)
     # the Huffman walk itself on the GPU (mjh_decode_batch_gpu): the host threads only parse headers and remove byte
     # stuffing, 0.45 MB of bitstream per image crosses PCIe instead of 6.3 MB of coefficients; images the GPU walk
     # refuses are walked on the host
-    try:
-        for eb in ebs:
-            eb.close()
-        n_g = max(4096, 8 * n_e)  # this leg is fast: enough chunks for the pipeline to reach its steady state (the images cycle)
-        jg = [datas[i % distinct] for i in range(n_g)]
-        depth = max(2, int(os.environ.get("MIJ_BENCH_GPU_DEPTH", "4")))  # batches in the ring = walks in flight
-        # chunks of 256 pictures, four batches: measured against 128 / 512 and three / six batches (tools/bench_gpu_walk.py)
-        gchunk = max(1, min(int(os.environ.get("MIJ_BENCH_GPU_CHUNK", "256")), n_g // depth))
-        # no coefficient staging to speak of: it is only needed for images the GPU walk hands back
-        ebs = [ica.Batch(ctx, gchunk, cbytes * 4, cbytes * gchunk, obytes * gchunk) for _ in range(depth)]
-        for eb in ebs:
-            eb.entropy_reserve(sum(len(x) * 9 // 8 + 4352 for x in jg[:gchunk]))
-        for eb in ebs:  # warm-up
-            eb.reset()
-            eb.decode_jpegs(jg[:gchunk], 3, threads, gpu_entropy=True)
-            eb.submit()
-            eb.wait()
-        last = {}
-        # begin(k) runs depth-1 chunks ahead of end(k): the walk kernels are latency bound (one chunk is ~2 workgroups
-        # per CU), so several walks in flight on their own streams is what fills the GPU, and the host parses the next
-        # headers meanwhile
-
-        gpins = []  # filled for the D2H variant below: one pinned buffer per ring batch
-
-        def finish(side, pjob, plo, plen):
-            ok, slots, reasons = ebs[side].decode_jpegs_gpu_end(pjob)
-            assert ok == plen, reasons
-            ebs[side].submit()
-            if gpins:
-                ebs[side].fetch_all_async(gpins[side].ptr, gpins[side].nbytes)
-            last[side] = (plo + plen - 1, slots[plen - 1])
-
-        def one_pass():
-            t0 = time.perf_counter()
-            pending = []  # (side, job, first image, count) in begin order
-            for k, lo in enumerate(range(0, n_g, gchunk)):
-                eb = ebs[k % depth]
-                eb.reset()
-                part = jg[lo:lo + gchunk]
-                pending.append((k % depth, eb.decode_jpegs_gpu_begin(part, 3, threads), lo, len(part)))
-                if len(pending) == depth:
-                    finish(*pending.pop(0))
-            for item in pending:
-                finish(*item)
-            for eb in ebs:
-                eb.wait()
-            return time.perf_counter() - t0
-
-        passes = [one_pass() for _ in range(3)]  # the leg takes ~0.1 s: three passes, in order; the first follows an idle GPU
-        t_gpu = sorted(passes)[1]
-        for side, (img, slot) in last.items():
-            assert ebs[side].hash_out(slot) == src_hash[img % distinct], "GPU-walked image differs"
-        e2e["value_gpu_entropy"] = round(n_g * W * H / t_gpu / 1e6, 1)
-        e2e["gpu_entropy_images"] = n_g
-        e2e["gpu_entropy_sync_rounds"] = ebs[0].entropy_rounds()
-        e2e["gpu_entropy_chunk_images"] = gchunk
-        e2e["gpu_entropy_batches_in_flight"] = depth
-        e2e["gpu_entropy_passes_mpix_s"] = [round(n_g * W * H / t / 1e6, 1) for t in passes]
-        # the same ring with every chunk's pixels copied to pinned host memory behind its kernels (3 B/px over PCIe: the
-        # link, not the GPU, sets this figure)
-        gpins.extend(ica.PinnedBuffer(obytes * gchunk) for _ in range(depth))
-        t_gd = sorted(one_pass() for _ in range(3))[1]
-        for side, (img, slot) in last.items():
-            off = ebs[side].out_offset(slot)
-            assert np.array_equal(gpins[side].array[off:off + W * H * 3], ebs[side].fetch(slot).reshape(-1)), "D2H copy of a GPU-walked image differs"
-        e2e["value_gpu_entropy_with_d2h"] = round(n_g * W * H / t_gd / 1e6, 1)
-        e2e["d2h_gb_s"] = round(n_g * W * H * 3 / t_gd / 1e9, 1)
-        for pb in gpins:
-            pb.close()
-    except ica.MijError as exc:
-        e2e["value_gpu_entropy"] = None
-        e2e["gpu_entropy_error"] = str(exc)
+    for eb in ebs:
+        eb.close()
+    ebs = []
+    e2e.update(gpu_walk_ring(ica, ctx, datas, distinct, max(4096, 8 * n_e), threads, src_hash, cbytes, obytes))
     for pb in pins:
         pb.close()
     for eb in ebs:
@@ -737,6 +767,9 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the (untimed-region) end-to-end measurement")
     ap.add_argument("--no-legs", action="store_true", help="skip the secondary legs (int16 planes, harsh batch, configs 4 and 5, 4:2:2)")
     ap.add_argument("--legs", default="", help="comma-separated subset of the secondary legs to run (default: all)")
+    ap.add_argument("--control-plane", default=os.environ.get("MIJ_CONTROL_PLANE", "gloo"), choices=["gloo", "nccl"],
+                    help="N > 1: backend of the barrier / MAX / SUM / all-gather of a few scalars.  gloo by default: the data path has no collective "
+                         "(independent images), so nothing is gained by taking RCCL's bring-up into the run; nccl (= RCCL) by flag")
     ap.add_argument("--e2e-images", type=int, default=512)
     ap.add_argument("--config4-images", type=int, default=32)
     ap.add_argument("--h2v1-images", type=int, default=512)
@@ -748,10 +781,12 @@ def main():
 
     # MIJ_BENCH_SHARE_DEVICE=1: every rank on device 0 and the control plane over gloo -- the multi-rank path rehearsed on a one-GPU box
     share = os.environ.get("MIJ_BENCH_SHARE_DEVICE") == "1"
-    cp = ControlPlane(backend="gloo" if share else None)
+    cp = ControlPlane(backend="gloo" if share else args.control_plane)
     if cp.world != args.gpus:
         if cp.rank == 0:
             print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, cp.world), file=sys.stderr)
+    if torch.cuda.is_available():  # the control plane may be gloo: torch's own current device still has to be this rank's (torch.cuda.synchronize below)
+        torch.cuda.set_device(0 if share else cp.local_rank)
     if cp.local_rank == 0:
         ica.build_library()  # rebuilds only when a source is newer than the in-tree .so; never from several ranks at once
     cp.barrier()
@@ -815,9 +850,10 @@ def main():
     ms_requested_max = cp.max(ms_requested)
     per_rank = cp.gather_floats([float(cp.rank), float(lo), float(hi), kernel_ms, ms_requested, float(n_verified)])
 
+    main_classes = idct_classes(batch) if cp.rank == 0 else None
     solo = cp.rank == 0 and cp.world == 1
     gpu_px = [batch.fetch(next(s for s, (kk, src) in enumerate(owners) if kk == k and src is None)) for k in range(distinct)] \
-        if (solo and not args.no_cpu_baseline) else None
+        if (cp.rank == 0 and not args.no_cpu_baseline) else None
     # release the timed batch before the legs: 12.8 GB and, more to the point, its stream (a process gets 4 hardware
     # queues; a fifth stream would share one with a batch of the end-to-end ring below and serialise the two)
     batch.close()
@@ -875,6 +911,24 @@ def main():
         except Exception as exc:  # noqa: BLE001
             e2e = {"value": None, "error": "%s: %s" % (type(exc).__name__, exc)}
 
+    # ---- N > 1: what north_star's scaling question is really about -- host threads and PCIe per GPU feeding N walks at once.  Every rank
+    # runs the GPU-walk ring on its own slice with its share of the host cores, all ranks at the same time (barrier in front); the line
+    # carries per-rank and aggregate end-to-end rates, pixels left in HBM and copied to pinned host memory.
+    e2e_ranks = None
+    if cp.world > 1 and not args.no_e2e:
+        local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(cp.world))))
+        threads = max(1, usable_cores() // local_world)
+        n_ring = max(1024, 2 * n_img)
+        cp.barrier()
+        try:
+            ring = gpu_walk_ring(ica, ctx, datas, distinct, n_ring, threads, src_hash, cbytes, obytes)
+        except Exception as exc:  # noqa: BLE001
+            ring = {"value_gpu_entropy": None, "gpu_entropy_error": "%s: %s" % (type(exc).__name__, exc)}
+        ok = ring.get("value_gpu_entropy") is not None
+        e2e_ranks = cp.gather_floats([float(cp.rank), float(n_ring if ok else 0), float(threads), ring.get("gpu_entropy_seconds", 0.0) if ok else 0.0,
+                                      ring.get("gpu_entropy_with_d2h_seconds", 0.0) if ok else 0.0])
+        cp.barrier()
+
     out = None
     if cp.rank == 0:
         algo_launch = ALGO_BYTES_PER_IMAGE * n_img  # rank 0's launch (it owns a largest slice)
@@ -898,6 +952,7 @@ def main():
                     "time / 8 TB/s (fewer: compact planes); at this point the kernel is bound by VALU issue, not by HBM (DESIGN.md 3.1)",
         }
         add_traffic(roof, "k_fused420_compact_%d" % n_img)
+        roof["idct_wavefront_classes"] = main_classes
         out = {
             "metric": "JPEG decode Mpixels/sec, 4:2:0 1080p batch, 1/2/4/8 GPU + %HBM roofline",  # BASELINE.json's string
             "value": round(total_px / t_max / 1e6, 1),
@@ -939,12 +994,26 @@ def main():
             out["legs"] = legs
         if e2e is not None:
             out["end_to_end"] = e2e
-        if solo and not args.no_cpu_baseline:
+        if e2e_ranks is not None:
+            rows = [{"rank": int(r[0]), "images": int(r[1]), "host_threads": int(r[2]),
+                     "mpix_s": round(r[1] * W * H / r[3] / 1e6, 1) if r[3] > 0 else None,
+                     "mpix_s_with_d2h": round(r[1] * W * H / r[4] / 1e6, 1) if r[4] > 0 else None} for r in e2e_ranks]
+            good = [r for r in e2e_ranks if r[3] > 0 and r[4] > 0]
+            out["end_to_end"] = {
+                "unit": "Mpix/s",
+                "includes": "every rank at the same time: JPEG bytes in host RAM -> header parse + byte unstuffing on the rank's host threads -> H2D of the "
+                            "streams -> Huffman walk on the GPU -> fused kernel; ring of four 256-picture batches per rank; pixels left in HBM / copied to pinned host memory",
+                "value_gpu_entropy": round(sum(r[1] for r in good) * W * H / max(r[3] for r in good) / 1e6, 1) if good else None,
+                "value_gpu_entropy_with_d2h": round(sum(r[1] for r in good) * W * H / max(r[4] for r in good) / 1e6, 1) if good else None,
+                "ranks_ok": len(good), "per_rank": rows,
+            }
+        if cp.rank == 0 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(datas, gpu_pixels=lambda i: gpu_px[i])
             except Exception as exc:  # noqa: BLE001
                 out["cpu_baseline"] = {"value": None, "error": "%s: %s" % (type(exc).__name__, exc)}
     ctx.close()
+    cp.barrier()  # rank 0 may still have been timing the CPU baseline
     cp.close()
     if out is not None:
         print(json.dumps(out))

@@ -3,8 +3,10 @@
 The path shards by independent images: image i of a batch goes to exactly one GPU,
 results are concatenated by index, and there is NO data-path collective (no RCCL traffic over
 xGMI).  One process per GPU (torch.distributed launcher); the only cross-rank operations are the
-benchmark's control plane: a barrier and a MAX/SUM reduction of a few scalars.  On GPUs these run
-over backend "nccl" (= RCCL on ROCm); on CPU-only hosts (tests) over "gloo".
+benchmark's control plane: a barrier, MAX/SUM reductions and an all-gather of a few scalars.  bench.py
+runs them over "gloo" by default (round 3: nothing on the data path needs RCCL, so its bring-up is
+not part of the run) and over "nccl" (= RCCL on ROCm) with --control-plane nccl; ControlPlane() without
+an explicit backend keeps the old rule (nccl where a GPU is visible, gloo otherwise).
 """
 import os
 

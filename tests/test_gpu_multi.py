@@ -78,6 +78,35 @@ def test_two_ranks_decode_their_slices_on_one_gpu(tmp_path):
         assert got[i] == helpers.fnv1a64(want), i
 
 
+@pytest.mark.spawns_gpu_children
+def test_bench_two_ranks_share_one_gpu(tmp_path):
+    """bench.py itself at N = 2 (the driver's launch: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), both ranks on device 0
+    (MIJ_BENCH_SHARE_DEVICE=1), control plane over gloo -- the default since round 3: slices, per-rank verification and kernel times, and
+    the end-to-end GPU-walk ring on every rank at the same time with its share of the host cores."""
+    env = dict(os.environ)
+    env.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29551", "WORLD_SIZE": "2", "LOCAL_WORLD_SIZE": "2", "OMP_NUM_THREADS": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0",
+                "MIJ_BENCH_SHARE_DEVICE": "1"})
+    procs = []
+    for r in range(2):
+        e = dict(env)
+        e.update({"RANK": str(r), "LOCAL_RANK": str(r)})
+        procs.append(subprocess.Popen([sys.executable, os.path.join(helpers.ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--total-images", "96",
+                                       "--distinct", "4", "--no-cpu-baseline"], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        so, se = p.communicate(timeout=900)
+        assert p.returncode == 0, se[-3000:]
+        outs.append([l for l in so.splitlines() if l.startswith("{")])
+    assert len(outs[0]) == 1 and len(outs[1]) == 0, "exactly rank 0 prints the line"
+    line = json.loads(outs[0][0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
+    assert line["config"]["slices"] == [[0, 48], [48, 96]] and line["config"]["images_verified_per_rank"] == [48, 48]
+    assert [r["rank"] for r in line["per_rank"]] == [0, 1] and all(r["kernel_ms_per_launch"] > 0 for r in line["per_rank"])
+    e2e = line["end_to_end"]
+    assert e2e["ranks_ok"] == 2 and e2e["value_gpu_entropy"] > 0 and e2e["value_gpu_entropy_with_d2h"] > 0, e2e
+    assert [r["rank"] for r in e2e["per_rank"]] == [0, 1] and all(r["mpix_s"] > 0 and r["host_threads"] >= 1 for r in e2e["per_rank"])
+
+
 def test_decode_batch_multi_two_contexts(ica, oracle, gpu_ctx, golden):
     from image_codecs_amd.sharding import shard_range
     datas = [ica.synth_jpeg(40 + 24 * i, 30 + 16 * i, seed=i, quality=(90, 95, 60)[i % 3]) for i in range(9)]

@@ -51,6 +51,10 @@ CASES = [
     dict(w=1024, h=96, q=75, layout="native", rows=[[0, 1, 2, "mix", 3, 0], [0, 0, 1, 2, "mix", 3], [2, 1, 0, 0, 3, "mix"]]),
     dict(w=1920, h=64, q=90, layout="native", rows=[[2, 0, 1, 3], [0, 1, 2, 3], [1, 2, 0, 0]]),
     dict(w=333, h=80, q=50, layout="native", rows=[["mix", 0, 1, 2, 3], [0, "mix", 2, 1, 0], [1, 0, "mix", 2, 2]]),
+    # the other kernel families: 4:4:4 (k_fused444: three blocks per lane, a class per component), 4:2:2 (k_fused422), grey (k_fused_grey)
+    dict(w=1040, h=80, q=95, layout="native", path=3, rows=[[3, 0, 1, 2, "mix", 3, 0, 2, 1, "mix"], [0, 1, 2, 3, "mix", 0, 0, 1, 2, 3], [1, 1, 0, 2, "mix", 3, 2, 0, 0, 1]]),
+    dict(w=2064, h=72, q=95, layout="422", path=4, rows=[[0, 1, 2, 3, "mix", 3, 0, 2, 1], [0, 1, 2, 3, "mix", 0, 0, 1, 2], [1, 1, 0, 2, "mix", 3, 2, 0, 0]]),
+    dict(w=1040, h=80, q=92, layout="grey", path=5, rows=[[3, 0, 1, 2, "mix", 3, 0, 2, 1, "mix"], [0], [0]]),
 ]
 
 
@@ -78,7 +82,7 @@ def test_every_sparse_class_in_both_plane_formats_and_from_both_producers(ica, o
                 b.wait()
                 counts = b.idct_class_counts()
                 b.count_idct_classes(False)
-                assert all(b.slot_path(s) == 1 for s in slots), "the band kernel did not take these pictures"
+                assert [b.slot_path(s) for s in slots] == [c.get("path", 1) for c in CASES], "a picture did not take the kernel family it was built for"
                 assert all(v > 0 for v in counts), ("a sparse class never ran", fmt, gpu_walk, counts)
                 for i, s in enumerate(slots):
                     assert np.array_equal(b.fetch(s), want[i]), (i, req, fmt, "gpu walk" if gpu_walk else "host walk")
@@ -86,6 +90,18 @@ def test_every_sparse_class_in_both_plane_formats_and_from_both_producers(ica, o
                 b.launch()
                 b.wait()
                 assert np.array_equal(b.fetch(slots[0]), want[0])
+                # and through the two-pass family (k_idct_planes takes the same sparse transforms)
+                b.force_generic(True)
+                b.upload()
+                b.count_idct_classes(True)
+                b.launch()
+                b.wait()
+                counts = b.idct_class_counts()
+                b.count_idct_classes(False)
+                assert all(v > 0 for v in counts), ("two-pass", counts)
+                for i, s in enumerate(slots):
+                    assert b.slot_path(s) == 2 and np.array_equal(b.fetch(s), want[i]), ("two-pass", i, req, fmt)
+                b.force_generic(False)
             b.close()
 
 
