@@ -316,7 +316,6 @@ def leg_config4(ica, ctx, args, checker):
                "parity": True, "parity_against": kind, "warmup_launches_issued": n_warm,
                "host_progressive_stage_mpix_s_single_thread": round(size * size / host_s / 1e6, 1), "setup_s": round(time.time() - t0, 1)}
         add_traffic(res, "k_fused444_compact_%d" % n)
-        res["idct_wavefront_classes"] = idct_classes(b)
         # end to end for this layout: 16 streams in host RAM -> pixels in HBM, every scan walked on the host threads (progressive
         # scans cannot take the GPU walk: AC refinement does not re-synchronise), planes re-staged, packed, transformed
         b.close()

@@ -1749,25 +1749,23 @@ __global__ __launch_bounds__(256) void k_fused444(const DevImage *__restrict__ i
 	IdctK KI;
 	KI.init();
 	uint2 ry[8], rb[8], rr[8];
-	const int count_classes = im.flags & MIJ_DEV_COUNT_CLASSES;
-	if constexpr (B8 && !WIDE) {
-		/* all three blocks' loads first: with a class test between the transforms the compiler can no longer hoist the next block's
-		 * loads above the previous transform (measured: 0.61 -> 0.67 ms per 32 x 4096^2 when each block loaded for itself) */
-		const CoefView v0 = coef_view(coef, im.comp[0]), v1 = coef_view(coef, im.comp[1]), v2 = coef_view(coef, im.comp[2]);
-		RawB8 r0, r1, r2;
-		load_raw_b8(v0, L, r0);
-		load_raw_b8(v1, L, r1);
-		load_raw_b8(v2, L, r2);
-		const int c0 = idct_raw_b8(KI, v0, L, im.dq[0], r0, ry), c1 = idct_raw_b8(KI, v1, L, im.dq[1], r1, rb), c2 = idct_raw_b8(KI, v2, L, im.dq[2], r2, rr);
-		if (count_classes && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u) {
-			atomicAdd(&g_idct_class[c0], 1ull);
-			atomicAdd(&g_idct_class[c1], 1ull);
-			atomicAdd(&g_idct_class[c2], 1ull);
-		}
-	} else {
-		load_idct_block<WIDE, B8>(KI, coef_view(coef, im.comp[0]), L, im.dq[0], ry, count_classes);
-		load_idct_block<WIDE, B8>(KI, coef_view(coef, im.comp[1]), L, im.dq[1], rb, count_classes);
-		load_idct_block<WIDE, B8>(KI, coef_view(coef, im.comp[2]), L, im.dq[2], rr, count_classes);
+	/* No sparse-block classes here (round 3, measured on 32 x 4096^2 4:4:4 whose chroma is almost all DC-only / 2x2, tools/ab3.sh): this
+	 * kernel sits on the HBM roofline, not on instruction issue -- with the class test between the three transforms it ran 0.67 ms, with all
+	 * three blocks' loads issued first 0.74 ms, without any of it 0.61 ms.  What would help here is not reading sparse blocks at all. */
+	{
+		uint4 c[8];
+		load_block_fmt<B8>(coef_view(coef, im.comp[0]), L, im.dq[0], c);
+		idct_block<WIDE, B8>(KI, c, im.dq[0], ry);
+	}
+	{
+		uint4 c[8];
+		load_block_fmt<B8>(coef_view(coef, im.comp[1]), L, im.dq[1], c);
+		idct_block<WIDE, B8>(KI, c, im.dq[1], rb);
+	}
+	{
+		uint4 c[8];
+		load_block_fmt<B8>(coef_view(coef, im.comp[2]), L, im.dq[2], c);
+		idct_block<WIDE, B8>(KI, c, im.dq[2], rr);
 	}
 	const uint32_t by = L / (uint32_t)bw, bx = L - by * (uint32_t)bw;
 	const int x0 = (int)bx * 8, y0 = (int)by * 8;

@@ -51,7 +51,7 @@ CASES = [
     dict(w=1024, h=96, q=75, layout="native", rows=[[0, 1, 2, "mix", 3, 0], [0, 0, 1, 2, "mix", 3], [2, 1, 0, 0, 3, "mix"]]),
     dict(w=1920, h=64, q=90, layout="native", rows=[[2, 0, 1, 3], [0, 1, 2, 3], [1, 2, 0, 0]]),
     dict(w=333, h=80, q=50, layout="native", rows=[["mix", 0, 1, 2, 3], [0, "mix", 2, 1, 0], [1, 0, "mix", 2, 2]]),
-    # the other kernel families: 4:4:4 (k_fused444: three blocks per lane, a class per component), 4:2:2 (k_fused422), grey (k_fused_grey)
+    # the other kernel families: 4:4:4 (k_fused444 keeps the full transform -- it is HBM-bound -- but must of course decode these), 4:2:2 (k_fused422), grey (k_fused_grey)
     dict(w=1040, h=80, q=95, layout="native", path=3, rows=[[3, 0, 1, 2, "mix", 3, 0, 2, 1, "mix"], [0, 1, 2, 3, "mix", 0, 0, 1, 2, 3], [1, 1, 0, 2, "mix", 3, 2, 0, 0, 1]]),
     dict(w=2064, h=72, q=95, layout="422", path=4, rows=[[0, 1, 2, 3, "mix", 3, 0, 2, 1], [0, 1, 2, 3, "mix", 0, 0, 1, 2], [1, 1, 0, 2, "mix", 3, 2, 0, 0]]),
     dict(w=1040, h=80, q=92, layout="grey", path=5, rows=[[3, 0, 1, 2, "mix", 3, 0, 2, 1, "mix"], [0], [0]]),
