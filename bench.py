@@ -504,6 +504,49 @@ def encode_end_to_end(ica, imgs, quality, kind, fenc):
             "includes": "pixels in host RAM -> pinned staging (host threads) -> H2D -> k_encode420 -> D2H of the data units -> Huffman emission (host threads) -> byte streams in host RAM"}
 
 
+def leg_prepass(ica, ctx, datas, n, cbytes, obytes, headline_ms):
+    """What stands between the host walk and the fused kernel, over n DISTINCT slots (own staging, no device-side clones):
+      staged_compact  round 3's pipeline: the baseline walk writes compact planes itself (mjh_decode_memory_fmt), upload is one H2D per picture of
+                      its main part -- nothing runs on the device before the fused kernel
+      staged_int16    the pipeline of rounds 1-2, still what progressive files take: int16 staging -> H2D into a scratch -> k_pack_c8, timed alone
+                      with HIP events on the batch's stream (mij_batch_pack_ms)
+    Staging of the 16 distinct pictures is copied into the other slots on the host (the walk itself is timed elsewhere); wall times include PCIe."""
+    import copy
+    distinct = len(datas)
+    out = {"images": n, "distinct_slots": n, "note": "pack_ms = k_pack_c8 alone (HIP events); upload_wall_ms = H2D of every slot's staging + pack, host wall clock; "
+           "frac_including_pack = algorithmic bytes / (fused kernel ms + pack ms) / 8 TB/s"}
+    for mode in ("staged_compact", "staged_int16"):
+        bt = ica.Batch(ctx, n, cbytes * n, cbytes * n, obytes * n)
+        try:
+            src = [bt.add_jpeg(datas[k], 3, stage=None if mode == "staged_compact" else "int16") for k in range(min(distinct, n))]
+            regions = [bt.stage_region(s) for s in src]
+            for i in range(len(src), n):
+                k = i % distinct
+                s = bt.add(copy.copy(bt.descs[src[k]]))
+                bt.stage_region(s)[:] = regions[k]
+                bt.set_flags(s, bt.descs[src[k]].flags)
+            bt.wait()
+            t0 = time.perf_counter()
+            bt.upload()
+            bt.wait()
+            wall = (time.perf_counter() - t0) * 1e3
+            pack = bt.pack_ms()
+            bt.launch()
+            bt.wait()
+            assert {bt.slot_path(s) for s in range(n)} == {1} and bt.slot_coef_bytes(n - 1) == 1
+            # parity of slots that were never cloned on the device: every 64th against its source picture
+            for s in range(0, n, 64):
+                assert bt.diff_slots([(s, s % distinct)]) == 0 if s >= distinct else True
+            main = sum(((bt.descs[0].comp[c].bw * bt.descs[0].comp[c].bh + 63) // 64) * (4096 + 128) for c in range(3))
+            out[mode] = {"pack_ms": None if pack is None else round(pack, 4), "upload_wall_ms": round(wall, 2),
+                         "h2d_bytes_per_image": main if mode == "staged_compact" else int(cbytes // 8320 * 8192),
+                         "frac_including_pack": round(frac_of(ALGO_BYTES_PER_IMAGE * n, headline_ms + (pack or 0.0)), 4)}
+        finally:
+            bt.close()
+    out["pack_ms_per_1024_distinct"] = None if out["staged_int16"]["pack_ms"] is None else round(out["staged_int16"]["pack_ms"] * 1024.0 / n, 4)
+    return out
+
+
 def leg_h2v1(ica, ctx, args, checker):
     """512 x 1080p 4:2:2 (h2v1) through k_fused422; algorithmic 7 B/px."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -896,6 +939,7 @@ def main():
             add_traffic(res, "k_fused420_compact_harsh_%d" % n_img)
             return res
 
+        run_leg("prepass", lambda: leg_prepass(ica, ctx, datas, n_img, cbytes, obytes, kernel_ms_max))
         run_leg("int16_planes", int16_leg)
         run_leg("harsh_batch", harsh_leg)
         run_leg("config4", lambda: leg_config4(ica, ctx, args, checker))
@@ -973,7 +1017,8 @@ def main():
                 "slices": [r["images"] for r in ranks],
                 "distinct_images": distinct,
                 "sharding": "independent images, contiguous slices (sharding.shard_range), one process + one HIP stream per GPU, no collective on the data path",
-                "coefficient_planes": "compact (library default): low bytes + escape bytes + int16 DC array, packed on the device from the host walk's int16 staging",
+                "coefficient_planes": "compact (library default): low bytes + escape bytes + int16 DC array, written in that form by the host walk itself "
+                                      "(mjh_decode_memory_fmt; no pack pass on the device: legs.prepass)",
                 "images_verified_per_rank": [r["images_verified"] for r in ranks],
                 "warmup_launches_issued": n_warm,
                 "settle_ms": args.settle_ms,

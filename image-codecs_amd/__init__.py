@@ -43,6 +43,9 @@ from .binding import (  # noqa: F401
     stbi_set_flip_vertically_on_load,
     stbi_write_jpg_to_memory,
     detile_coefficients,
+    host_decode_staged,
+    compact_offsets,
+    expand_compact_region,
     decode_jpegs_multi,
     gpu_available,
 )

@@ -395,6 +395,51 @@ class HostDecoder:
         return d, arena
 
 
+def host_decode_staged(data, req_comp=0, want_compact=True):
+    """mjh_decode_memory_fmt into a plain numpy region (no GPU): -> (desc, region bytes).  desc.flags says which format the walk wrote
+    (MIJ_FLAG_STAGED_COMPACT = 4, MIJ_FLAG_HAS_ESCAPES = 8); compact regions follow mij_compact_offsets (compact_offsets below)."""
+    d = HostDecoder.probe(data, req_comp)
+    L = lib()
+    L.mjh_decode_memory_fmt.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(ImageDesc), C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_char_p)]
+    tiles = [((d.comp[c].bw * d.comp[c].bh) + 63) // 64 for c in range(d.ncomp)]
+    region = np.full(sum(tiles) * (4096 + 128 + 4096), 0xA5, dtype=np.uint8)  # poisoned: what the walk does not clear it must not need
+    why = C.c_char_p()
+    d2 = ImageDesc()
+    if not L.mjh_decode_memory_fmt(bytes(data), len(data), int(req_comp), C.byref(d2), region.ctypes.data_as(C.c_void_p), C.c_size_t(region.size), int(bool(want_compact)), C.byref(why)):
+        raise MijError(why.value.decode() if why.value else "decode failed")
+    return d2, region
+
+
+def compact_offsets(desc):
+    """mij_compact_offsets: per component (lo, dc, hi) byte offsets inside an image's region, and the main part's size"""
+    tiles = [((desc.comp[c].bw * desc.comp[c].bh) + 63) // 64 for c in range(desc.ncomp)]
+    main = sum(t * (4096 + 128) for t in tiles)
+    out, m, e = [], 0, main
+    for t in tiles:
+        out.append((m, m + t * 4096, e))
+        m += t * (4096 + 128)
+        e += t * 4096
+    return out, main
+
+
+def expand_compact_region(desc, region):
+    """compact planes (mij.h) -> the int16 tile-layout arena mjh_decode_memory would have written (the inverse of k_pack_c8)"""
+    offs, _ = compact_offsets(desc)
+    parts = []
+    for c, (lo_o, dc_o, hi_o) in enumerate(offs):
+        nt = ((desc.comp[c].bw * desc.comp[c].bh) + 63) // 64
+        lo = region[lo_o:lo_o + nt * 4096].reshape(nt, 8, 64, 8)          # [tile, chunk, lane, slot]
+        dc = region[dc_o:dc_o + nt * 128].view(np.int16).reshape(nt, 64)
+        hi = region[hi_o:hi_o + nt * 4096].reshape(nt, 64, 8, 8)          # [tile, lane, chunk, slot] (64 bytes per block, position order)
+        val = lo.view(np.int8).astype(np.int32)
+        esc = (lo[:, 0, :, 0] & 1).astype(bool)                            # [tile, lane]
+        h = np.where(esc[:, None, :, None], hi.view(np.int8).transpose(0, 2, 1, 3).astype(np.int32), 0)
+        val = val + 256 * h
+        val[:, 0, :, 0] = dc
+        parts.append(val.astype(np.int16).reshape(-1))
+    return np.concatenate(parts)
+
+
 def detile_coefficients(desc, arena):
     """Tile layout -> list of per-component arrays [bh, bw, 8, 8] (natural row, col order), for tests."""
     out = []
@@ -480,6 +525,22 @@ class Batch:
         self.descs.append(self.descs[src])
         return slot
 
+    def stage_region(self, slot):
+        """uint8 numpy view over the slot's whole pinned staging region (mij_batch_stage_region: room for either format)"""
+        L = lib()
+        L.mij_batch_stage_region.restype = C.c_void_p
+        L.mij_batch_stage_region.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]
+        nb = C.c_size_t()
+        p = L.mij_batch_stage_region(self._h, int(slot), C.byref(nb))
+        if not p:
+            raise MijError("mij_batch_stage_region: %s" % L.mij_last_error().decode())
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(nb.value,))
+
+    def set_flags(self, slot, flags):
+        _check(lib().mij_batch_set_flags(self._h, int(slot), int(flags)), "mij_batch_set_flags")
+        d = self._desc(slot)
+        d.flags = int(flags)
+
     def staging(self, slot):
         """int16 numpy view over the slot's pinned planes (all components, back to back)."""
         d = self._desc(slot)
@@ -541,6 +602,14 @@ class Batch:
         """Blocks of the slot that hold a coefficient outside -128..127 (compact planes only)."""
         return _check(lib().mij_batch_slot_escapes(self._h, int(slot)), "mij_batch_slot_escapes")
 
+    def pack_ms(self):
+        """ms of k_pack_c8 in the last upload, or None when nothing was packed (host-staged compact planes, GPU-walk planes, int16 planes)"""
+        L = lib()
+        L.mij_batch_pack_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        ms = C.c_float()
+        _check(L.mij_batch_pack_ms(self._h, C.byref(ms)), "mij_batch_pack_ms")
+        return None if ms.value < 0 else ms.value
+
     def count_idct_classes(self, on=True):
         """Measurement: make the launches that follow count wavefronts per sparse-block class (clears the counters when switched on)."""
         L = lib()
@@ -571,15 +640,33 @@ class Batch:
         _check(L.mij_batch_fetch_coef(self._h, int(slot), out.ctypes.data_as(C.c_void_p), C.c_size_t(out.size)), "mij_batch_fetch_coef")
         return out
 
-    def add_jpeg(self, data, req_comp=0):
-        """Host stage of one image straight into a new slot's pinned staging; returns the slot."""
+    def add_jpeg(self, data, req_comp=0, stage=None):
+        """Host stage of one image straight into a new slot's pinned staging; returns the slot.  stage None: what the batch front ends do
+        (mjh_decode_memory_fmt: a baseline file is staged as COMPACT planes by the walk itself when the batch's format is compact, no
+        pack pass on the device); "int16": int16 tile-layout staging whatever the file (mjh_decode_memory; compact batches then pack
+        it on the device with k_pack_c8 -- the pipeline of rounds 1 and 2, kept for progressive files)."""
         d = HostDecoder.probe(data, req_comp)
         slot = self.add(d)
-        d2, _ = HostDecoder.decode(data, req_comp, out=self.staging(slot))
+        L = lib()
+        if stage == "int16":
+            d2, _ = HostDecoder.decode(data, req_comp, out=self.staging(slot))
+        else:
+            L.mij_batch_stage_region.restype = C.c_void_p
+            L.mij_batch_stage_region.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]
+            L.mij_batch_coef_format.argtypes = [C.c_void_p]
+            L.mjh_decode_memory_fmt.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(ImageDesc), C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_char_p)]
+            nb = C.c_size_t()
+            region = L.mij_batch_stage_region(self._h, int(slot), C.byref(nb))
+            if not region:
+                raise MijError("mij_batch_stage_region: " + L.mij_last_error().decode())
+            d2, why = ImageDesc(), C.c_char_p()
+            if not L.mjh_decode_memory_fmt(bytes(data), len(data), int(req_comp), C.byref(d2), region, nb, int(L.mij_batch_coef_format(self._h) == 1), C.byref(why)):
+                raise MijError("mjh_decode_memory_fmt: %s" % (why.value.decode() if why.value else "failed"))
         if d2.flags:
-            _check(lib().mij_batch_set_flags(self._h, slot, d2.flags), "mij_batch_set_flags")
+            _check(L.mij_batch_set_flags(self._h, slot, d2.flags), "mij_batch_set_flags")
+            d.flags = d2.flags
         if d2.color != d.color:  # a JFIF / Adobe marker behind SOF changed the colour branch (codec/jpeg.c:2244)
-            _check(lib().mij_batch_set_color(self._h, slot, d2.color), "mij_batch_set_color")
+            _check(L.mij_batch_set_color(self._h, slot, d2.color), "mij_batch_set_color")
             d.color = d2.color
         return slot
 

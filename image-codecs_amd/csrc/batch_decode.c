@@ -53,9 +53,11 @@ static void *worker(void *arg)
 			continue;
 		d = p->descs[i];
 		{
-			int16_t *arena = mij_batch_coef(p->b, slot, 0);
-			size_t elems = mij_image_coef_bytes(&d) / sizeof(int16_t);
-			if (arena && mjh_decode_memory(p->bufs[i], p->lens[i], p->req_comp, &d, arena, elems, &why)) {
+			/* baseline files are staged as compact planes by the walk itself (no pack pass, half the bytes over PCIe) unless the
+			 * batch was asked for int16 planes; progressive files stay int16 (mjh_decode_memory_fmt) */
+			size_t bytes = 0;
+			uint8_t *region = mij_batch_stage_region(p->b, slot, &bytes);
+			if (region && mjh_decode_memory_fmt(p->bufs[i], p->lens[i], p->req_comp, &d, region, bytes, mij_batch_coef_format(p->b) == MIJ_COEF_COMPACT, &why)) {
 				if (d.flags)
 					mij_batch_set_flags(p->b, slot, d.flags);
 				if (d.color != p->descs[i].color) /* a JFIF / Adobe marker behind SOF changed the colour branch */
@@ -533,11 +535,10 @@ static void *multi_worker(void *arg)
 		slot = p->slots[i];
 		if (slot >= 0) {
 			mij_batch *b = m->batches[k];
-			int16_t *arena = mij_batch_coef(b, slot, 0);
-			size_t elems;
+			size_t bytes = 0;
+			uint8_t *region = mij_batch_stage_region(b, slot, &bytes);
 			d = p->descs[i];
-			elems = mij_image_coef_bytes(&d) / sizeof(int16_t);
-			if (arena && mjh_decode_memory(p->bufs[i], p->lens[i], p->req_comp, &d, arena, elems, &why)) {
+			if (region && mjh_decode_memory_fmt(p->bufs[i], p->lens[i], p->req_comp, &d, region, bytes, mij_batch_coef_format(b) == MIJ_COEF_COMPACT, &why)) {
 				if (d.flags)
 					mij_batch_set_flags(b, slot, d.flags);
 				if (d.color != p->descs[i].color)

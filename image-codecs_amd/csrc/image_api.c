@@ -272,7 +272,7 @@ static unsigned char *load_main_counted(mjh_reader *r, int *x, int *y, int *comp
 	mij_ctx *ctx;
 	mij_batch *b;
 	unsigned char *pixels = NULL;
-	int slot, i;
+	int slot;
 	size_t nbytes;
 
 	d = (mjh_decoder *)calloc(1, sizeof(*d));
@@ -326,21 +326,29 @@ static unsigned char *load_main_counted(mjh_reader *r, int *x, int *y, int *comp
 		free(d);
 		return fail_ptr("outofmem");
 	}
-	slot = mij_batch_add(b, &desc);
+	slot = mij_batch_add_uncleared(b, &desc); /* mjh_attach_staging clears what the walk uses */
 	if (slot < 0) {
 		free(d);
 		return fail_ptr("outofmem");
 	}
-	for (i = 0; i < desc.ncomp; ++i)
-		d->comp[i].plane = mij_batch_coef(b, slot, i);
+	{
+		/* baseline: the walk writes compact planes itself (what the kernels read: no pack pass, half the bytes over PCIe);
+		 * progressive: int16 planes, packed on the device */
+		uint8_t *region = mij_batch_stage_region(b, slot, NULL);
+		if (!region) {
+			free(d);
+			return fail_ptr("outofmem");
+		}
+		mjh_attach_staging(d, &desc, region, mij_batch_coef_format(b) == MIJ_COEF_COMPACT);
+	}
 
 	if (!mjh_decode_scans(d)) {
 		const char *why = d->reason;
 		free(d);
 		return fail_ptr(why);
 	}
-	if (mjh_needs_wide_idct(d))
-		mij_batch_set_flags(b, slot, MIJ_FLAG_WIDE_IDCT);
+	if (mjh_stage_flags(d))
+		mij_batch_set_flags(b, slot, mjh_stage_flags(d));
 	/* is_rgb / CMYK / YCCK are decided once every marker has been seen (codec/jpeg.c:2244): APP0 / APP14 may follow SOF */
 	if (mjh_color_mode(d, desc.n_out) != desc.color) {
 		desc.color = mjh_color_mode(d, desc.n_out);

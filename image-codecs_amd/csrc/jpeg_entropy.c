@@ -158,6 +158,7 @@ static const uint8_t k_dezigzag[64 + 15] = {
 
 /* zigzag index -> int16 offset inside the block's tile slot: (P>>3)*512 + (P&7) */
 static uint16_t k_tile_off[64 + 15];
+static uint8_t k_pos_of_zig[64 + 15]; /* zigzag index -> in-block position P = 8*column + slot (the escape bytes' order) */
 static uint8_t k_zig_of_pos[64]; /* in-tile position P = 8*chunk + slot -> zigzag index */
 static int k_tile_off_ready;
 
@@ -170,6 +171,7 @@ static void init_tile_off(void)
 		int nat = k_dezigzag[k];
 		int P = 8 * (nat & 7) + mij_rowslot[nat >> 3];
 		k_tile_off[k] = (uint16_t)(((P >> 3) << 9) + (P & 7));
+		k_pos_of_zig[k] = (uint8_t)P;
 		if (k < 64)
 			k_zig_of_pos[P] = (uint8_t)k;
 	}
@@ -469,6 +471,93 @@ static int decode_block(mjh_decoder *d, int16_t *blk, const mjh_huff *hdc, const
 	return 1;
 }
 
+/*
+ * The same block into COMPACT planes (mij.h, "compact coefficient planes"): the low byte of every coefficient at the byte offset
+ * the int16 layout has as element offset, the DC term in the component's int16 array (the byte in its place holds the block's flags),
+ * and -- only for a block that holds a coefficient outside -128..127 -- 64 escape bytes h with coefficient == sext8(low) + 256 * h.
+ * The fast-AC table only holds values inside a byte (build_fast_ac), so only the slow path can escape.  Same symbols, same order,
+ * same failure points as decode_block: the planes k_pack_c8 would make from decode_block's output, byte for byte (tests).
+ */
+static int decode_block_c8(mjh_decoder *d, mjh_comp *cp, int L, const mjh_huff *hdc, const mjh_huff *hac, const int16_t *fac, const uint16_t *qz)
+{
+	uint8_t *blk = cp->lo8 + block_base(L), *esc = NULL;
+	int diff, dc, k, t;
+	int32_t l1;
+	bitreg b = reg_load(d);
+
+	if (b.bits < 16)
+		reg_grow(d, &b);
+	t = huff_decode_r(d, hdc, &b);
+	if (t < 0) {
+		reg_store(d, &b);
+		return fail(d, "bad huffman code");
+	}
+	if (cp->touched) {
+		int c;
+		for (c = 0; c < 8; ++c)
+			memset(blk + (c << 9), 0, 8);
+	}
+
+	diff = t ? extend_receive_r(d, t, &b) : 0;
+	dc = (int)((unsigned)cp->dc_pred + (unsigned)diff);
+	cp->dc_pred = dc;
+	cp->dc16[L] = (int16_t)dc;
+	l1 = iabs16((int)((unsigned)dc * qz[0]));
+
+	k = 1;
+	do {
+		int c, r, s;
+		if (b.bits < 16)
+			reg_grow(d, &b);
+		c = (int)(b.buf >> (32 - MJH_FAST_BITS));
+		r = fac[c];
+		if (r) {
+			k += (r >> 4) & 15;
+			s = r & 15;
+			b.buf <<= s;
+			b.bits -= s;
+			blk[k_tile_off[k]] = (uint8_t)(r >> 8);
+			if (esc) /* a spill position written twice: what was there may have had a high byte */
+				esc[k_pos_of_zig[k]] = 0;
+			l1 += iabs16((r >> 8) * qz[k]);
+			++k;
+		} else {
+			int rs = huff_decode_r(d, hac, &b);
+			if (rs < 0) {
+				reg_store(d, &b);
+				return fail(d, "bad huffman code");
+			}
+			s = rs & 15;
+			r = rs >> 4;
+			if (s == 0) {
+				if (rs != 0xf0)
+					break;
+				k += 16;
+			} else {
+				int v;
+				k += r;
+				v = extend_receive_r(d, s, &b);
+				blk[k_tile_off[k]] = (uint8_t)v;
+				if (esc || v != (int8_t)v) {
+					if (!esc) {
+						esc = cp->hi8 + ((size_t)L << 6);
+						memset(esc, 0, 64);
+						blk[0] = 1; /* flags: escaped */
+						d->any_escape = 1;
+					}
+					esc[k_pos_of_zig[k]] = (uint8_t)(((int16_t)v - (int8_t)v) >> 8);
+				}
+				l1 += iabs16((int)((unsigned)v * qz[k]));
+				++k;
+			}
+		}
+	} while (k < 64);
+	reg_store(d, &b);
+	if (l1 > d->max_block_l1)
+		d->max_block_l1 = l1;
+	return 1;
+}
+
 /* codec/jpeg.c:268-278 on the local register */
 static inline int get_bits_r(mjh_decoder *d, int n, bitreg *b)
 {
@@ -726,7 +815,7 @@ static int parse_entropy_coded_data(mjh_decoder *d)
 			const int16_t *fac = d->fast_ac[cp->ha];
 			for (j = 0; j < h; ++j)
 				for (i = 0; i < w; ++i) {
-					if (!decode_block(d, cp->plane + block_base(i + j * cp->bw), hdc, hac, fac, cp, qz[0]))
+					if (!(d->compact ? decode_block_c8(d, cp, i + j * cp->bw, hdc, hac, fac, qz[0]) : decode_block(d, cp->plane + block_base(i + j * cp->bw), hdc, hac, fac, cp, qz[0])))
 						return 0;
 					if (restart_check(d)) {
 						cp->touched = 1;
@@ -746,7 +835,7 @@ static int parse_entropy_coded_data(mjh_decoder *d)
 						for (y = 0; y < cp->v; ++y)
 							for (x = 0; x < cp->h; ++x) {
 								int L = (i * cp->h + x) + (j * cp->v + y) * cp->bw;
-								if (!decode_block(d, cp->plane + block_base(L), hdc, hac, fac, cp, qz[ci]))
+								if (!(d->compact ? decode_block_c8(d, cp, L, hdc, hac, fac, qz[ci]) : decode_block(d, cp->plane + block_base(L), hdc, hac, fac, cp, qz[ci])))
 									return 0;
 							}
 					}
@@ -1238,6 +1327,75 @@ int mjh_probe_memory(const uint8_t *buf, int len, int req_comp, mij_image_desc *
 		return 0;
 	}
 	ok = probe_common(d, &r, buf, len, req_comp, desc, &why);
+	free(d);
+	if (reason)
+		*reason = why;
+	return ok;
+}
+
+int mjh_attach_staging(mjh_decoder *d, const mij_image_desc *desc, uint8_t *region, int want_compact)
+{
+	int i;
+	init_tile_off();
+	d->any_escape = 0;
+	if (want_compact && !d->progressive) {
+		for (i = 0; i < desc->ncomp; ++i) {
+			size_t lo, dc, hi;
+			mij_compact_offsets(desc, i, &lo, &dc, &hi);
+			d->comp[i].plane = NULL;
+			d->comp[i].lo8 = region + lo;
+			d->comp[i].dc16 = (int16_t *)(region + dc);
+			d->comp[i].hi8 = region + hi;
+		}
+		memset(region, 0, mij_compact_main_bytes(desc));
+		d->compact = 1;
+		return 1;
+	}
+	{
+		size_t off = 0;
+		for (i = 0; i < desc->ncomp; ++i) {
+			d->comp[i].plane = (int16_t *)region + off;
+			d->comp[i].lo8 = d->comp[i].hi8 = NULL;
+			d->comp[i].dc16 = NULL;
+			off += mij_plane_elems((uint32_t)(desc->comp[i].bw * desc->comp[i].bh));
+		}
+		memset(region, 0, off * sizeof(int16_t));
+	}
+	d->compact = 0;
+	return 0;
+}
+
+uint32_t mjh_stage_flags(const mjh_decoder *d)
+{
+	return (mjh_needs_wide_idct(d) ? MIJ_FLAG_WIDE_IDCT : 0u) | (d->compact ? MIJ_FLAG_STAGED_COMPACT : 0u) | ((d->compact && d->any_escape) ? MIJ_FLAG_HAS_ESCAPES : 0u);
+}
+
+int mjh_decode_memory_fmt(const uint8_t *buf, int len, int req_comp, mij_image_desc *desc, uint8_t *region, size_t region_bytes, int want_compact, const char **reason)
+{
+	const char *why = NULL;
+	mjh_reader r;
+	mjh_decoder *d = (mjh_decoder *)calloc(1, sizeof(*d));
+	int ok = 0;
+	if (!d) {
+		if (reason)
+			*reason = "outofmem";
+		return 0;
+	}
+	if (probe_common(d, &r, buf, len, req_comp, desc, &why)) {
+		if (mij_image_region_bytes(desc) > region_bytes) {
+			why = "outofmem";
+			goto done;
+		}
+		mjh_attach_staging(d, desc, region, want_compact);
+		if (!mjh_decode_scans(d)) {
+			why = d->reason;
+			goto done;
+		}
+		desc->flags |= mjh_stage_flags(d);
+		desc->color = mjh_color_mode(d, desc->n_out); /* JFIF / Adobe markers behind SOF count too (codec/jpeg.c:2244) */
+		ok = 1;
+	}
+done:
 	free(d);
 	if (reason)
 		*reason = why;

@@ -61,6 +61,10 @@ typedef struct {
 	int bw, bh;       /* blocks per row / rows of the padded grid */
 	int16_t *plane;   /* tile-layout staging plane (mij.h), owned by the caller */
 	int touched;      /* a previous scan already wrote blocks of this component */
+	/* compact staging (mjh_decoder.compact; baseline files only): low-byte tiles, int16 DC array, escape bytes (mij_compact_offsets) */
+	uint8_t *lo8;
+	int16_t *dc16;
+	uint8_t *hi8;
 } mjh_comp;
 
 enum { MJH_SCAN_LOAD = 0, MJH_SCAN_TYPE = 1, MJH_SCAN_HEADER = 2 };
@@ -86,6 +90,10 @@ typedef struct {
 	int scan_n, order[4];
 	int restart_interval, todo;
 
+	/* 1: baseline blocks go straight into COMPACT planes (comp[].lo8 / dc16 / hi8) instead of int16 tiles -- what the decode kernels
+	 * read, so no pack pass and half the bytes over PCIe; progressive scans read-modify-write int16 planes and never set this.
+	 * any_escape: some block holds a coefficient beyond a byte (its escape bytes are in use: MIJ_FLAG_HAS_ESCAPES) */
+	int compact, any_escape;
 	/* largest per-block sum of |de-quantised coefficient| seen (baseline), for MIJ_FLAG_WIDE_IDCT */
 	int32_t max_block_l1;
 	const char *reason; /* short failure reason, reference wording */
@@ -111,6 +119,13 @@ int mjh_decode_scans(mjh_decoder *d);
 
 /* Non-zero if the finished image needs MIJ_FLAG_WIDE_IDCT. */
 int mjh_needs_wide_idct(const mjh_decoder *d);
+
+/* Points a decoder whose header has been parsed at an image's staging region (mij_image_coef_bytes(desc) bytes) and clears what the
+ * walk will use.  want_compact != 0 and a baseline file: compact planes (returns 1, d->compact set; clears mij_compact_main_bytes);
+ * otherwise int16 tile-layout planes (returns 0; clears them all). */
+int mjh_attach_staging(mjh_decoder *d, const mij_image_desc *desc, uint8_t *region, int want_compact);
+/* MIJ_FLAG_* the finished walk raises: WIDE_IDCT, and STAGED_COMPACT / HAS_ESCAPES for compact staging */
+uint32_t mjh_stage_flags(const mjh_decoder *d);
 
 /* the one-call memory forms and the batch front end are declared in include/mij_host.h */
 

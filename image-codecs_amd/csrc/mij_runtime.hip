@@ -200,6 +200,8 @@ struct mij_batch {
 	mij_ctx *ctx;
 	hipStream_t stream;
 	hipEvent_t ev_begin, ev_end;
+	hipEvent_t ev_pack0, ev_pack1; /* around k_pack_c8 in the last upload (mij_batch_pack_ms); created on first use */
+	bool pack_timed;
 	int max_images;
 	/* arenas */
 	uint8_t *stage;
@@ -279,6 +281,8 @@ extern "C" int mij_batch_create(mij_ctx *ctx, int max_images, size_t stage_bytes
 	b->es = nullptr;
 	b->stream = nullptr;
 	b->ev_begin = b->ev_end = nullptr;
+	b->ev_pack0 = b->ev_pack1 = nullptr;
+	b->pack_timed = false;
 	const char *env = getenv("MIJ_BAND_ROWS");
 	if (env)
 		b->band_rows = atoi(env);
@@ -340,6 +344,10 @@ extern "C" void mij_batch_destroy(mij_batch *b)
 		(void)hipEventDestroy(b->ev_begin);
 	if (b->ev_end)
 		(void)hipEventDestroy(b->ev_end);
+	if (b->ev_pack0)
+		(void)hipEventDestroy(b->ev_pack0);
+	if (b->ev_pack1)
+		(void)hipEventDestroy(b->ev_pack1);
 	if (b->stream)
 		(void)hipStreamDestroy(b->stream);
 	delete b;
@@ -405,12 +413,14 @@ static void layout_coef(Slot &s)
 	for (int c = 0; c < s.desc.ncomp; ++c) {
 		const size_t nt = comp_tiles(s.desc.comp[c]);
 		DevComp &dc = s.dev.comp[c];
-		dc.coef_off = off;
-		if (s.coef_bytes_fmt) {
-			dc.dc_off = off + (nt << 12);
-			dc.hi_off = off + (nt << 12) + (nt << 7);
-			off += nt * MIJ_TILE_COMPACT_BYTES;
+		if (s.coef_bytes_fmt) { /* mij.h, mij_compact_offsets: low bytes + DC of every component first, the escape bytes behind them */
+			size_t lo, dcv, hi;
+			mij_compact_offsets(&s.desc, c, &lo, &dcv, &hi);
+			dc.coef_off = s.coef_base + lo;
+			dc.dc_off = s.coef_base + dcv;
+			dc.hi_off = s.coef_base + hi;
 		} else {
+			dc.coef_off = off;
 			dc.dc_off = dc.hi_off = 0;
 			off += nt << 13;
 		}
@@ -546,6 +556,24 @@ extern "C" int16_t *mij_batch_coef(mij_batch *b, int slot, int comp)
 		off += mij_plane_elems((uint32_t)(s.desc.comp[c].bw * s.desc.comp[c].bh)) * sizeof(int16_t);
 	return reinterpret_cast<int16_t *>(b->stage + off);
 }
+
+extern "C" uint8_t *mij_batch_stage_region(mij_batch *b, int slot, size_t *bytes)
+{
+	if (!b || slot < 0 || slot >= (int)b->slots.size()) {
+		set_err(MIJ_E_ARG, "bad slot");
+		return nullptr;
+	}
+	const Slot &s = b->slots[(size_t)slot];
+	if (s.clone_of >= 0 || !b->stage || s.stage_off == MIJ_NO_STAGE) {
+		set_err(MIJ_E_ARG, "slot has no staging of its own");
+		return nullptr;
+	}
+	if (bytes)
+		*bytes = s.coef_bytes;
+	return b->stage + s.stage_off;
+}
+
+extern "C" int mij_batch_coef_format(const mij_batch *b) { return b ? b->coef_fmt : MIJ_COEF_COMPACT; }
 
 extern "C" int mij_batch_set_flags(mij_batch *b, int slot, uint32_t flags)
 {
@@ -809,10 +837,10 @@ extern "C" int mij_batch_upload(mij_batch *b)
 		Slot &s = b->slots[i];
 		if (s.clone_of >= 0)
 			s.coef_bytes_fmt = b->slots[(size_t)s.clone_of].coef_bytes_fmt;
-		else if (!s.dev_coef)
-			s.coef_bytes_fmt = (b->coef_fmt && !(s.desc.flags & MIJ_FLAG_SKIP)) ? 1 : 0;
+		else if (!s.dev_coef) /* planes the host staged compact keep that format whatever the batch's default */
+			s.coef_bytes_fmt = ((b->coef_fmt || (s.desc.flags & MIJ_FLAG_STAGED_COMPACT)) && !(s.desc.flags & MIJ_FLAG_SKIP)) ? 1 : 0;
 		layout_coef(s);
-		if (s.clone_of < 0 && !s.dev_coef && s.coef_bytes_fmt)
+		if (s.clone_of < 0 && !s.dev_coef && s.coef_bytes_fmt && !(s.desc.flags & MIJ_FLAG_STAGED_COMPACT))
 			need_pack = true;
 	}
 	if (need_pack && !b->d_up16) {
@@ -892,7 +920,7 @@ extern "C" int mij_batch_upload(mij_batch *b)
 			s.path = 0;
 			continue;
 		}
-		if (s.clone_of < 0 && !s.dev_coef && b8) /* int16 planes in the scratch -> compact planes */
+		if (s.clone_of < 0 && !s.dev_coef && b8 && !(d.flags & MIJ_FLAG_STAGED_COMPACT)) /* int16 planes in the scratch -> compact planes */
 			for (int c = 0; c < d.ncomp; ++c)
 				for (uint32_t f = 0, nb = (uint32_t)comp_tiles(d.comp[c]) * 64u; f < nb; f += 256)
 					pack.push_back(Work4{(uint32_t)i, (uint32_t)c, f, 0u});
@@ -1028,10 +1056,17 @@ extern "C" int mij_batch_upload(mij_batch *b)
 			++i;
 			continue;
 		}
+		if (b->slots[i].desc.flags & MIJ_FLAG_STAGED_COMPACT) { /* compact planes written by the host stage: straight to their place, escape region only when used */
+			const Slot &sc = b->slots[i];
+			const size_t main_bytes = mij_compact_main_bytes(&sc.desc);
+			HIP_TRY(hipMemcpyAsync(b->d_coef + sc.coef_base, b->stage + sc.stage_off, (sc.desc.flags & MIJ_FLAG_HAS_ESCAPES) ? sc.coef_bytes : main_bytes, hipMemcpyHostToDevice, b->stream));
+			++i;
+			continue;
+		}
 		size_t j = i, bytes = 0;
 		const int fmt = b->slots[i].coef_bytes_fmt;
 		const size_t s0 = b->slots[i].stage_off, c0 = b->slots[i].coef_base;
-		while (j < n && b->slots[j].clone_of < 0 && !b->slots[j].dev_coef && !(b->slots[j].desc.flags & MIJ_FLAG_SKIP) && b->slots[j].coef_bytes_fmt == fmt &&
+		while (j < n && b->slots[j].clone_of < 0 && !b->slots[j].dev_coef && !(b->slots[j].desc.flags & (MIJ_FLAG_SKIP | MIJ_FLAG_STAGED_COMPACT)) && b->slots[j].coef_bytes_fmt == fmt &&
 				 b->slots[j].stage_off == s0 + bytes && b->slots[j].coef_base == c0 + bytes) {
 			bytes += b->slots[j].coef_bytes;
 			++j;
@@ -1039,9 +1074,17 @@ extern "C" int mij_batch_upload(mij_batch *b)
 		HIP_TRY(hipMemcpyAsync(fmt ? b->d_up16 + s0 : b->d_coef + c0, b->stage + s0, bytes, hipMemcpyHostToDevice, b->stream));
 		i = j;
 	}
+	b->pack_timed = false;
 	if (!pack.empty()) {
+		if (!b->ev_pack0) {
+			HIP_TRY(hipEventCreate(&b->ev_pack0));
+			HIP_TRY(hipEventCreate(&b->ev_pack1));
+		}
+		HIP_TRY(hipEventRecord(b->ev_pack0, b->stream));
 		hipLaunchKernelGGL(k_pack_c8, dim3((unsigned)pack.size()), dim3(256), 0, b->stream, b->d_imgs, reinterpret_cast<const WorkIdct *>(b->d_work), b->d_up16, b->d_coef);
 		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipEventRecord(b->ev_pack1, b->stream));
+		b->pack_timed = true;
 	}
 	for (size_t k = 0; k < n; ++k) {
 		const Slot &s = b->slots[k];
@@ -1276,6 +1319,21 @@ extern "C" int mij_batch_timer_elapsed_ms(mij_batch *b, float *ms)
 	HIP_TRY(hipSetDevice(b->ctx->device));
 	HIP_TRY(hipEventSynchronize(b->ev_end));
 	HIP_TRY(hipEventElapsedTime(ms, b->ev_begin, b->ev_end));
+	return MIJ_OK;
+}
+
+/* duration of k_pack_c8 (int16 staging -> compact planes) in the last mij_batch_upload, HIP events on the batch's stream; *ms = -1
+ * when that upload packed nothing (every slot staged compact by the host walk, written by the GPU entropy stage, or int16 planes) */
+extern "C" int mij_batch_pack_ms(mij_batch *b, float *ms)
+{
+	if (!b || !ms)
+		return set_err(MIJ_E_ARG, "bad argument");
+	*ms = -1.0f;
+	if (!b->pack_timed)
+		return MIJ_OK;
+	HIP_TRY(hipSetDevice(b->ctx->device));
+	HIP_TRY(hipEventSynchronize(b->ev_pack1));
+	HIP_TRY(hipEventElapsedTime(ms, b->ev_pack0, b->ev_pack1));
 	return MIJ_OK;
 }
 
@@ -1868,10 +1926,12 @@ extern "C" int mij_batch_fetch_coef(mij_batch *b, int slot, int16_t *dst, size_t
 		if (rc != MIJ_OK)
 			return rc;
 	}
-	size_t roff = 0, eoff = 0;
+	size_t eoff = 0;
 	for (int c = 0; c < s.desc.ncomp; ++c) {
 		const size_t nt = comp_tiles(s.desc.comp[c]);
-		const uint8_t *lo = raw.data() + roff, *dcp = lo + (nt << 12), *hi = dcp + (nt << 7);
+		size_t lo_o, dc_o, hi_o;
+		mij_compact_offsets(&s.desc, c, &lo_o, &dc_o, &hi_o);
+		const uint8_t *lo = raw.data() + lo_o, *dcp = raw.data() + dc_o, *hi = raw.data() + hi_o;
 		int16_t *out = dst + eoff;
 		for (size_t L = 0; L < nt * 64; ++L) {
 			const uint8_t *blo = lo + ((L >> 6) << 12) + ((L & 63) << 3);
@@ -1887,7 +1947,6 @@ extern "C" int mij_batch_fetch_coef(mij_batch *b, int slot, int16_t *dst, size_t
 			memcpy(&dcv, dcp + 2 * L, 2);
 			bo[0] = (int16_t)dcv;
 		}
-		roff += nt * MIJ_TILE_COMPACT_BYTES;
 		eoff += nt << 12;
 	}
 	return MIJ_OK;

@@ -56,6 +56,9 @@ enum {
                                  run the exact 32-bit second pass (see MIJ_BLOCK_L1_LIMIT) */
 #define MIJ_FLAG_SKIP 2u      /* the host stage rejected this image after its slot was taken: upload and
                                  launch ignore the slot (its output is undefined) */
+#define MIJ_FLAG_STAGED_COMPACT 4u /* the host stage wrote the slot's staging as COMPACT planes itself (mij_compact_offsets; the
+                                      baseline Huffman walk does: mjh_decode_memory_fmt): upload copies them as they are, no pack */
+#define MIJ_FLAG_HAS_ESCAPES 8u    /* ... and at least one block holds a coefficient beyond a byte: the escape region goes up too */
 
 /* per component geometry, exactly the reference's img_comp[] fields (codec/jpeg.c:48-62, :1624-1655) */
 typedef struct {
@@ -125,6 +128,41 @@ static inline size_t mij_coef_index(uint32_t L, uint32_t P)
 /* int16 elements in the plane of a component with nblocks blocks (whole tiles) */
 static inline size_t mij_plane_elems(uint32_t nblocks) { return ((size_t)(nblocks + 63u) >> 6) << 12; }
 
+/* Where the compact planes of component `comp` lie inside an image's coefficient region (the same in pinned staging and in HBM),
+ * in bytes from the region's start: first, for every component in turn, its low-byte tiles followed by its int16 DC array -- the
+ * MAIN part, mij_compact_main_bytes() in all, which is all that has to cross PCIe for an image without escaped blocks -- then the
+ * escape bytes of every component (64 per block, position order P).  n_tiles = whole 64-block tiles of the component. */
+static inline size_t mij_comp_tiles(const mij_comp_desc *c) { return ((size_t)(c->bw * c->bh) + 63u) >> 6; }
+static inline size_t mij_compact_main_bytes(const mij_image_desc *d)
+{
+	size_t t = 0;
+	int c;
+	for (c = 0; c < d->ncomp; ++c)
+		t += mij_comp_tiles(&d->comp[c]) * (4096 + 128);
+	return t;
+}
+/* bytes of an image's coefficient region: room for either format (= mij_image_coef_bytes) */
+static inline size_t mij_image_region_bytes(const mij_image_desc *d)
+{
+	size_t t = 0;
+	int c;
+	for (c = 0; c < d->ncomp; ++c)
+		t += mij_comp_tiles(&d->comp[c]) * MIJ_TILE_COMPACT_BYTES;
+	return t;
+}
+static inline void mij_compact_offsets(const mij_image_desc *d, int comp, size_t *lo, size_t *dc, size_t *hi)
+{
+	size_t main = 0, esc = mij_compact_main_bytes(d);
+	int c;
+	for (c = 0; c < comp; ++c) {
+		main += mij_comp_tiles(&d->comp[c]) * (4096 + 128);
+		esc += mij_comp_tiles(&d->comp[c]) * 4096;
+	}
+	*lo = main;
+	*dc = main + mij_comp_tiles(&d->comp[comp]) * 4096;
+	*hi = esc;
+}
+
 /*
  * Fast/exact IDCT contract.  The second IDCT pass runs on packed int16 first-pass outputs
  * (v_dot2_i32_i16) when the host guarantees they fit; a sufficient condition is that for every
@@ -172,6 +210,11 @@ int mij_batch_add_uncleared(mij_batch *b, const mij_image_desc *d);
 int mij_batch_add_clone(mij_batch *b, int src_slot);
 /* Pinned host plane of component c of a slot (tile layout, int16, zero-filled). */
 int16_t *mij_batch_coef(mij_batch *b, int slot, int comp);
+/* The slot's whole staging region (mij_image_coef_bytes of pinned host memory) for a host stage that writes COMPACT planes itself
+ * (mij_compact_offsets) and then raises MIJ_FLAG_STAGED_COMPACT with mij_batch_set_flags; NULL for clones and slots without staging. */
+uint8_t *mij_batch_stage_region(mij_batch *b, int slot, size_t *bytes);
+/* MIJ_COEF_COMPACT / MIJ_COEF_INT16: the format host-staged planes get in HBM (a host stage asked for int16 planes stages int16) */
+int mij_batch_coef_format(const mij_batch *b);
 /* May be called after the entropy stage to raise flags it only knows late (e.g. WIDE_IDCT). */
 int mij_batch_set_flags(mij_batch *b, int slot, uint32_t flags);
 
@@ -281,6 +324,8 @@ int mij_batch_slot_escapes(mij_batch *b, int slot);
  * inside the top-left 2x2; 2: inside the 4x4; 3: the full transform).  mij_batch_count_idct_classes(b, 1) after mij_batch_upload
  * clears the device counters and makes the batch's launches count wavefronts per class; mij_batch_idct_class_counts reads them
  * (out[class]); (b, 0) switches the counting off again.  Counting costs an atomic per wavefront: never on in timed launches. */
+/* Measurement: milliseconds k_pack_c8 (int16 staging -> compact planes) took in the last mij_batch_upload, -1 when nothing was packed */
+int mij_batch_pack_ms(mij_batch *b, float *ms);
 int mij_batch_count_idct_classes(mij_batch *b, int on);
 int mij_batch_idct_class_counts(mij_batch *b, uint64_t out[4]);
 /* tests / tuning: synchronisation rounds the last entropy_run needed for its slowest image */

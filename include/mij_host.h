@@ -34,6 +34,16 @@ int mjh_probe_memory(const uint8_t *buf, int len, int req_comp, mij_image_desc *
  */
 int mjh_decode_memory(const uint8_t *buf, int len, int req_comp, mij_image_desc *desc, int16_t *arena, size_t arena_elems, const char **reason);
 
+/*
+ * The same into an image's whole staging region (mij_batch_stage_region: mij_image_coef_bytes(desc) bytes), in the format the GPU
+ * reads where the file allows it: want_compact != 0 and a baseline file -> COMPACT planes written by the walk itself (mij.h,
+ * mij_compact_offsets: low bytes + DC array, escape bytes only for blocks that need them), desc->flags gets
+ * MIJ_FLAG_STAGED_COMPACT (and MIJ_FLAG_HAS_ESCAPES): no pack pass on the device and 1.6 instead of 3 bytes per pixel over PCIe.
+ * Progressive files (their scans read-modify-write int16 planes, codec/jpeg.c:372-558) and want_compact == 0: int16 tile layout
+ * as mjh_decode_memory.  The reference's block decoder being restated either way: codec/jpeg.c:308-370.
+ */
+int mjh_decode_memory_fmt(const uint8_t *buf, int len, int req_comp, mij_image_desc *desc, uint8_t *region, size_t region_bytes, int want_compact, const char **reason);
+
 /* Header parse + extraction of the entropy segment for the GPU entropy stage (mij.h: mjg_scan,
  * mij_batch_add_stream).  Returns 1: *scan filled, the segment without its 0xFF00 stuffing written to stream
  * (stream_cap must leave 32 spare bytes); 2: a valid header but not a layout the GPU walk takes (use

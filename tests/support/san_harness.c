@@ -6,7 +6,7 @@
 #include "jpeg_entropy.h"
 int main(int argc, char **argv)
 {
-	int i, ok = 0, ex = 0;
+	int i, ok = 0, okc = 0, ex = 0;
 	for (i = 1; i < argc; ++i) {
 		FILE *f = fopen(argv[i], "rb");
 		long n;
@@ -24,6 +24,13 @@ int main(int argc, char **argv)
 					int16_t *arena = malloc(elems * 2 + 16);
 					ok += mjh_decode_memory(buf, (int)n, req, &d, arena, elems, &why);
 					free(arena);
+					{ /* the same walk staging compact planes itself: a region of exactly the size the batch hands out */
+						mij_image_desc d2; const char *why2 = NULL;
+						size_t bytes = mij_image_region_bytes(&d);
+						uint8_t *region = malloc(bytes ? bytes : 1);
+						okc += mjh_decode_memory_fmt(buf, (int)n, req, &d2, region, bytes, 1, &why2);
+						free(region);
+					}
 				}
 			}
 			{
@@ -36,8 +43,8 @@ int main(int argc, char **argv)
 		}
 		free(buf);
 	}
-	printf("decoded ok %d, extracted %d\n", ok, ex);
-	return 0;
+	printf("decoded ok %d (compact staging %d), extracted %d\n", ok, okc, ex);
+	return ok == okc ? 0 : 1;
 }
 /* the one runtime function the harness needs (the real one lives in the HIP runtime) */
 size_t mij_image_coef_bytes(const mij_image_desc *d) { size_t t = 0; for (int c = 0; c < d->ncomp; ++c) t += mij_plane_elems((uint32_t)(d->comp[c].bw * d->comp[c].bh)) * 2; return t; }

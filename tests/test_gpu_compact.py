@@ -59,7 +59,7 @@ def test_escaped_blocks_decode_exactly_through_both_producers(ica, oracle, gpu_c
             assert np.array_equal(b.fetch(s), want[i]), ("gpu walk", i, req)
         planes_gpu = [b.fetch_coef(s) for s in slots]
         b.close()
-        # producer 2: host walk -> int16 staging -> k_pack_c8 on the device
+        # producer 2: the host walk, which since round 3 stages compact planes itself (mjh_decode_memory_fmt); the k_pack_c8 route is covered below
         b = ica.Batch(gpu_ctx, len(datas), 64 << 20, 64 << 20, 64 << 20)
         ok, slots, reasons = b.decode_jpegs(datas, req, threads=2, gpu_entropy=False)
         assert ok == len(datas), reasons
@@ -79,8 +79,12 @@ def test_escaped_blocks_decode_exactly_through_both_producers(ica, oracle, gpu_c
         b.wait()
         for i, s in enumerate(slots):
             assert b.slot_path(s) == 2 and np.array_equal(b.fetch(s), want[i]), ("two-pass", i, req)
-        b.force_generic(False)
+        b.close()
+        # and once more as int16 planes (the format is the batch's to ask for before the walk stages anything)
+        b = ica.Batch(gpu_ctx, len(datas), 64 << 20, 64 << 20, 64 << 20)
         b.set_coef_format("int16")
+        ok, slots, reasons = b.decode_jpegs(datas, req, threads=2, gpu_entropy=False)
+        assert ok == len(datas), reasons
         b.submit()
         b.wait()
         for i, s in enumerate(slots):
@@ -106,3 +110,43 @@ def test_escapes_through_stbi_load_and_progressive(ica, oracle, gpu_ctx):
                 got = ica.stbi_load_from_memory(data, req)
                 assert got is not None, ica.stbi_failure_reason()
                 assert np.array_equal(got[0], want), (q, req)
+
+
+def test_host_staged_compact_planes_equal_the_packed_ones(ica, oracle, gpu_ctx):
+    """Round 3: the host walk writes compact planes itself (mjh_decode_memory_fmt) and upload copies them as they are -- no k_pack_c8,
+    1.6 instead of 3 bytes per pixel over PCIe.  The planes in HBM equal the ones k_pack_c8 makes from the same walk's int16 staging
+    (expanded element for element, escape counts), the pixels equal the oracle's, a batch asked for int16 planes still gets int16
+    staging, and a progressive file next to baseline ones still goes through the pack."""
+    datas = _streams(ica, 77, True) + [ica.synth_jpeg(1920, 1080, 0), ica.synth_jpeg(333, 211, 3, quality=95)]
+    plan, du = ica.host_transform(ica.synth_rgb(120, 88, 4), 92)
+    datas.append(helpers.progressive_from_du(plan, du))
+    want = [oracle.load(d, 3)[1] for d in datas]
+    direct = ica.Batch(gpu_ctx, len(datas), 128 << 20, 128 << 20, 128 << 20)
+    packed = ica.Batch(gpu_ctx, len(datas), 128 << 20, 128 << 20, 128 << 20)
+    sd = [direct.add_jpeg(d, 3) for d in datas]
+    sp = [packed.add_jpeg(d, 3, stage="int16") for d in datas]
+    for b in (direct, packed):
+        b.submit()
+        b.wait()
+    for i in range(len(datas)):
+        assert direct.slot_coef_bytes(sd[i]) == 1 and packed.slot_coef_bytes(sp[i]) == 1
+        assert np.array_equal(direct.fetch(sd[i]), want[i]), ("direct", i)
+        assert np.array_equal(packed.fetch(sp[i]), want[i]), ("packed", i)
+        assert np.array_equal(direct.fetch_coef(sd[i]), packed.fetch_coef(sp[i])), i
+        assert direct.slot_escapes(sd[i]) == packed.slot_escapes(sp[i]), i
+    # the flags the walk raised: staged compact for the baseline files, not for the progressive one
+    assert [bool(direct.descs[s].flags & 4) for s in sd] == [True] * (len(datas) - 1) + [False]
+    # the front end on host threads takes the same route; int16 batches keep int16 staging
+    for fmt in ("compact", "int16"):
+        b = ica.Batch(gpu_ctx, len(datas), 128 << 20, 128 << 20, 128 << 20)
+        b.set_coef_format(fmt)
+        ok, slots, reasons = b.decode_jpegs(datas, 3, threads=3, gpu_entropy=False)
+        assert ok == len(datas), reasons
+        b.submit()
+        b.wait()
+        for i, s in enumerate(slots):
+            assert b.slot_coef_bytes(s) == (1 if fmt == "compact" else 0)
+            assert np.array_equal(b.fetch(s), want[i]), (fmt, i)
+        b.close()
+    direct.close()
+    packed.close()

@@ -67,16 +67,16 @@ def test_every_sparse_class_in_both_plane_formats_and_from_both_producers(ica, o
             kind, px, _ = oracle.load(d, req)
             assert kind == "ok", px
             want.append(px)
-        for gpu_walk in (False, True):
+        for gpu_walk, fmt in ((False, "compact"), (False, "int16"), (True, "compact")):
             b = ica.Batch(gpu_ctx, len(datas), 64 << 20, 64 << 20, 64 << 20)
+            b.set_coef_format(fmt)  # before the host walk: it stages the format the batch asks for
             if gpu_walk:
                 b.entropy_reserve(16 << 20)
             ok, slots, reasons = b.decode_jpegs(datas, req, threads=2, gpu_entropy=gpu_walk)
             assert ok == len(datas), reasons
-            for fmt in (("compact",) if gpu_walk else ("compact", "int16")):
-                if not gpu_walk:
-                    b.set_coef_format(fmt)
+            if True:
                 b.upload()
+                assert {b.slot_coef_bytes(s) for s in slots} == {1 if fmt == "compact" else 0}
                 b.count_idct_classes(True)
                 b.launch()
                 b.wait()
