@@ -161,6 +161,7 @@ static uint16_t k_tile_off[64 + 15];
 static uint8_t k_pos_of_zig[64 + 15]; /* zigzag index -> in-block position P = 8*column + slot (the escape bytes' order) */
 static uint8_t k_zig_of_pos[64]; /* in-tile position P = 8*chunk + slot -> zigzag index */
 static int k_tile_off_ready;
+static void init_zig_masks(void);
 
 static void init_tile_off(void)
 {
@@ -175,6 +176,7 @@ static void init_tile_off(void)
 		if (k < 64)
 			k_zig_of_pos[P] = (uint8_t)k;
 	}
+	init_zig_masks();
 	k_tile_off_ready = 1;
 }
 
@@ -612,32 +614,43 @@ static int decode_block_prog_dc(mjh_decoder *d, int16_t *blk, const mjh_huff *hd
 	return 1;
 }
 
+/* codec/jpeg.c:497-505: "if (stbi__jpeg_get_bit(j)) if ((*p & bit) == 0) { if (*p > 0) *p += bit; else *p -= bit; }" -- without
+ * data-dependent branches (the correction bits of a photograph are coin flips: as branches they mispredict every other time) */
 static inline void refine_nonzero(mjh_decoder *d, int16_t *p, int bit, bitreg *b)
 {
-	if (get_bit_r(d, b))
-		if ((*p & bit) == 0) {
-			if (*p > 0)
-				*p = (int16_t)(*p + bit);
-			else
-				*p = (int16_t)(*p - bit);
-		}
+	const int take = get_bit_r(d, b) != 0;
+	const int v = *p;
+	const int need = take & ((v & bit) == 0);
+	const int delta = v > 0 ? bit : -bit;
+	*p = (int16_t)(v + (need ? delta : 0));
 }
 
-/* non-zero map of a block in zigzag order: eight 16-byte chunks (one per column) compared against zero */
+/* non-zero map of a block in zigzag order: eight 16-byte chunks (one per column) compared against zero give the map in position
+ * order P; the fixed bit permutation P -> zigzag index goes through eight 256-entry tables (one per byte of the map: 16 KiB, built
+ * once) instead of a loop over the set bits (a luma block of a photograph has twenty of them) */
+static uint64_t k_zig_mask_of_byte[8][256];
+static void init_zig_masks(void)
+{
+	int c, v, bit;
+	for (c = 0; c < 8; ++c)
+		for (v = 0; v < 256; ++v) {
+			uint64_t m = 0;
+			for (bit = 0; bit < 8; ++bit)
+				if (v & (1 << bit))
+					m |= 1ull << k_zig_of_pos[8 * c + bit];
+			k_zig_mask_of_byte[c][v] = m;
+		}
+}
 static inline uint64_t block_nonzero_mask(const int16_t *blk)
 {
 	const __m128i zero = _mm_setzero_si128();
-	uint64_t pm = 0, zm = 0;
+	uint64_t zm = 0;
 	int c;
 	for (c = 0; c < 8; ++c) {
 		const __m128i v = _mm_loadu_si128((const __m128i *)(blk + (c << 9)));
 		const __m128i eq = _mm_cmpeq_epi16(v, zero);
 		const unsigned m8 = (unsigned)_mm_movemask_epi8(_mm_packs_epi16(eq, zero)) & 0xffu; /* 1 = zero */
-		pm |= (uint64_t)(m8 ^ 0xffu) << (8 * c);
-	}
-	while (pm) {
-		zm |= 1ull << k_zig_of_pos[__builtin_ctzll(pm)];
-		pm &= pm - 1;
+		zm |= k_zig_mask_of_byte[c][m8 ^ 0xffu];
 	}
 	return zm;
 }
