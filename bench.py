@@ -618,8 +618,9 @@ def leg_two_pass(ica, ctx, datas, args, checker):
     plan, du = ica.host_transform(ica.synth_rgb(W, H, 2), 92)
     d440 = helpers.baseline_layout_from_444(plan, du, [(1, 2), (1, 1), (1, 1)], -1)
     cases = (("h2v2_forced", datas[0], 1, 2), ("h1v2_440", d440, 0, 6), ("h1v2_440_forced", d440, 1, 2),
-             ("cmyk_adobe", helpers.baseline_layout_from_444(plan, du, [(1, 1)] * 4, 0), 0, 2))
-    out = {"images": n, "kernels": "mij::k_idct_planes<false,true> + mij::k_resample_fast<RS_HV2 | RS_V2 | RS_ROW1, ...>; h1v2_440 (default choice): mij::k_fused440w<3,false,true> (a 1080p row leaves room for two workgroups per CU: the eight-wave form)",
+             ("cmyk_adobe", helpers.baseline_layout_from_444(plan, du, [(1, 1)] * 4, 0), 0, 7),
+             ("cmyk_adobe_forced", helpers.baseline_layout_from_444(plan, du, [(1, 1)] * 4, 0), 1, 2))
+    out = {"images": n, "kernels": "mij::k_idct_planes<false,true> + mij::k_resample_fast<RS_HV2 | RS_V2 | RS_ROW1, ...>; h1v2_440 (default choice): mij::k_fused440w<3,false,true> (a 1080p row leaves room for two workgroups per CU: the eight-wave form); cmyk_adobe (default choice since round 3): mij::k_fused1x1c<3,false,true>",
            "parity_against": checker[1]}
     for name, data, generic, path in cases:
         d = ica.HostDecoder.probe(data, 3)

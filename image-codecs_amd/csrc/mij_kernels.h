@@ -1734,10 +1734,91 @@ MIJ_BAND422(k_fused422t, 64)
  * (RGBA) contiguous bytes per lane.  Algorithmic bytes: 384 B read + 64*NOUT written per MCU
  * (9 B/px for RGB: BASELINE config 4's shape).
  */
+/* One output row of a lane's 8 x 8 block -- 8 pixels = 8 * NOUT bytes in q[0 .. 2*NOUT-1] -- to the picture.
+ * direct: two stores per lane (12 + 12 or 16 + 16 bytes): every 64-byte sector of the row is written in pieces by two instructions, which the
+ * counters showed as 1.21x the pixels' bytes in write traffic (round 2, profiles/r02e).
+ * via_lds (wave-uniform; the wave's 64 blocks are neighbours in ONE block row and lie wholly inside the picture): the 64 lanes' rows are one
+ * contiguous run of 64 * 8 * NOUT bytes; they go through a per-wave LDS row and leave as whole 16-byte chunks in address order, 1 KiB per store
+ * instruction, so a sector is written once. */
+template <int NOUT>
+__device__ __forceinline__ void store_row8(const uint32_t (&q)[2 * NOUT], bool via_lds, uint8_t *lds_row, int lane, uint8_t *__restrict__ dst_lane, uint8_t *__restrict__ dst_wave)
+{
+	if (via_lds) {
+		uint32_t *w = reinterpret_cast<uint32_t *>(lds_row + lane * (8 * NOUT));
+		if constexpr (NOUT == 3) {
+			*reinterpret_cast<uint2 *>(w) = make_uint2(q[0], q[1]);
+			*reinterpret_cast<uint2 *>(w + 2) = make_uint2(q[2], q[3]);
+			*reinterpret_cast<uint2 *>(w + 4) = make_uint2(q[4], q[5]);
+		} else {
+			*reinterpret_cast<uint4 *>(w) = make_uint4(q[0], q[1], q[2], q[3]);
+			*reinterpret_cast<uint4 *>(w + 4) = make_uint4(q[4], q[5], q[6], q[7]);
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		const uint4 c0 = *reinterpret_cast<const uint4 *>(lds_row + lane * 16);
+		__builtin_nontemporal_store((u4v){c0.x, c0.y, c0.z, c0.w}, reinterpret_cast<u4v *>(dst_wave + lane * 16));
+		if (NOUT == 4 || lane < 32) {
+			const uint4 c1 = *reinterpret_cast<const uint4 *>(lds_row + 1024 + lane * 16);
+			__builtin_nontemporal_store((u4v){c1.x, c1.y, c1.z, c1.w}, reinterpret_cast<u4v *>(dst_wave + 1024 + lane * 16));
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier(); /* the row buffer is free again */
+	} else if constexpr (NOUT == 3) {
+		__builtin_nontemporal_store((u3v){q[0], q[1], q[2]}, reinterpret_cast<u3v *>(dst_lane));
+		__builtin_nontemporal_store((u3v){q[3], q[4], q[5]}, reinterpret_cast<u3v *>(dst_lane + 12));
+	} else {
+		__builtin_nontemporal_store((u4v){q[0], q[1], q[2], q[3]}, reinterpret_cast<u4v *>(dst_lane));
+		__builtin_nontemporal_store((u4v){q[4], q[5], q[6], q[7]}, reinterpret_cast<u4v *>(dst_lane + 16));
+	}
+}
+
+/* four pixels' colour sums -> NOUT packed dwords (see store_px4) */
+template <int NOUT>
+__device__ __forceinline__ void pack_px4(const Rgb12 &p0, const Rgb12 &p1, const Rgb12 &p2, const Rgb12 &p3, uint32_t *q)
+{
+	if (NOUT == 4) {
+		const int a = 0x7fffffff; /* saturates to 255 */
+		q[0] = sat4<12>(p0.r, p0.g, p0.b, a);
+		q[1] = sat4<12>(p1.r, p1.g, p1.b, a);
+		q[2] = sat4<12>(p2.r, p2.g, p2.b, a);
+		q[3] = sat4<12>(p3.r, p3.g, p3.b, a);
+	} else {
+		q[0] = sat4<12>(p0.r, p0.g, p0.b, p1.r);
+		q[1] = sat4<12>(p1.g, p1.b, p2.r, p2.g);
+		q[2] = sat4<12>(p2.b, p3.r, p3.g, p3.b);
+	}
+}
+
+/* what a lane of the 1x1 kernels needs to know about where its block's pixels go */
+struct Block1x1 {
+	int x0, y0;
+	bool whole, via_lds;
+	uint8_t *lds_row;
+};
+template <int NOUT>
+__device__ __forceinline__ Block1x1 block_1x1_setup(const DevImage &im, uint32_t L, uint32_t nblk, uint8_t *lds_rows)
+{
+	Block1x1 g;
+	const uint32_t bw = (uint32_t)im.comp[0].bw;
+	const uint32_t by = L / bw, bx = L - by * bw;
+	g.x0 = (int)bx * 8;
+	g.y0 = (int)by * 8;
+	g.whole = (g.x0 + 8 <= im.width) && ((NOUT == 4) || ((im.width & 3) == 0));
+	/* LDS-transposed stores: every lane of the wave active and whole, all in one block row (lane 0's block row == lane 63's) */
+	const int lane = (int)(threadIdx.x & 63u);
+	const uint32_t L0 = L - (uint32_t)lane;
+	const bool one_row = (L0 / bw) == ((L0 + 63u) / bw) && L0 + 63u < nblk;
+	g.via_lds = one_row && __builtin_amdgcn_ballot_w64(g.whole) == ~0ull;
+	g.lds_row = lds_rows + (threadIdx.x >> 6) * (64 * 8 * NOUT);
+	return g;
+}
+
 template <int NOUT, bool WIDE, bool B8 = false>
 __global__ __launch_bounds__(256) void k_fused444(const DevImage *__restrict__ imgs, const WorkIdct *__restrict__ work, const uint8_t *__restrict__ coef,
 																  uint8_t *__restrict__ outbase)
 {
+	__shared__ __attribute__((aligned(16))) uint8_t lds_rows[4 * 64 * 8 * NOUT];
 	const WorkIdct wk = work[blockIdx.x];
 	const DevImage &im = imgs[wk.img];
 	const int bw = im.comp[0].bw;
@@ -1767,15 +1848,14 @@ __global__ __launch_bounds__(256) void k_fused444(const DevImage *__restrict__ i
 		load_block_fmt<B8>(coef_view(coef, im.comp[2]), L, im.dq[2], c);
 		idct_block<WIDE, B8>(KI, c, im.dq[2], rr);
 	}
-	const uint32_t by = L / (uint32_t)bw, bx = L - by * (uint32_t)bw;
-	const int x0 = (int)bx * 8, y0 = (int)by * 8;
+	const Block1x1 g = block_1x1_setup<NOUT>(im, L, nblk, lds_rows);
+	const int x0 = g.x0, y0 = g.y0, lane = (int)(threadIdx.x & 63u);
 	uint8_t *const out = outbase + im.out_off;
 	const size_t opitch = (size_t)W * NOUT;
 	ColorK KC;
 	KC.init();
 	/* (chroma byte j | luma byte j << 16) */
 	const uint32_t s0 = vreg(0x0c000c04u), s1 = vreg(0x0c010c05u), s2 = vreg(0x0c020c06u), s3 = vreg(0x0c030c07u);
-	const bool whole = (x0 + 8 <= W) && ((NOUT == 4) || ((W & 3) == 0));
 #pragma unroll
 	for (int r = 0; r < 8; ++r) {
 		if (y0 + r >= H)
@@ -1790,9 +1870,11 @@ __global__ __launch_bounds__(256) void k_fused444(const DevImage *__restrict__ i
 		const Rgb12 p5 = color_px(KC, __builtin_amdgcn_perm(rhi, yhi, s1), __builtin_amdgcn_perm(bhi, yhi, s1));
 		const Rgb12 p6 = color_px(KC, __builtin_amdgcn_perm(rhi, yhi, s2), __builtin_amdgcn_perm(bhi, yhi, s2));
 		const Rgb12 p7 = color_px(KC, __builtin_amdgcn_perm(rhi, yhi, s3), __builtin_amdgcn_perm(bhi, yhi, s3));
-		if (whole) {
-			store_px4<NOUT>(dst, p0, p1, p2, p3);
-			store_px4<NOUT>(dst + 4 * NOUT, p4, p5, p6, p7);
+		if (g.whole) {
+			uint32_t q[2 * NOUT];
+			pack_px4<NOUT>(p0, p1, p2, p3, q);
+			pack_px4<NOUT>(p4, p5, p6, p7, q + NOUT);
+			store_row8<NOUT>(q, g.via_lds, g.lds_row, lane, dst, dst - (size_t)lane * (8 * NOUT));
 		} else {
 			/* right-edge MCU or a row pitch that is not dword aligned: byte stores of the valid pixels */
 			const Rgb12 px[8] = {p0, p1, p2, p3, p4, p5, p6, p7};
@@ -1800,6 +1882,90 @@ __global__ __launch_bounds__(256) void k_fused444(const DevImage *__restrict__ i
 			for (int j = 0; j < 8; ++j)
 				if (x0 + j < W)
 					store_rgb_px<NOUT>(dst + j * NOUT, clamp255(opaque(px[j].r >> 12)), clamp255(opaque(px[j].g >> 12)), clamp255(opaque(px[j].b >> 12)));
+		}
+	}
+}
+
+/* ------------------------------------------------------------------ fused kernel for the other 1x1 colour layouts (round 3)
+ * RGB-tagged files (three components copied, codec/jpeg.c:2325-2335), Adobe CMYK (:2343-2354) and YCCK (:2355-2366) whose components all
+ * have sampling factors 1x1: the same shape as k_fused444 -- a lane owns the 8 x 8 block position, transforms its three or four blocks
+ * (with the sparse classes: chroma and K planes of such files are often flat) and converts its 64 pixels in registers -- instead of the
+ * two-pass family's round trip of the sample planes through HBM.  The colour mode is wave-uniform (one image per workgroup). */
+template <int NOUT, bool WIDE, bool B8 = false>
+__global__ __launch_bounds__(256) void k_fused1x1c(const DevImage *__restrict__ imgs, const WorkIdct *__restrict__ work, const uint8_t *__restrict__ coef,
+																	uint8_t *__restrict__ outbase)
+{
+	__shared__ __attribute__((aligned(16))) uint8_t lds_rows[4 * 64 * 8 * NOUT];
+	const WorkIdct wk = work[blockIdx.x];
+	const DevImage &im = imgs[wk.img];
+	const int bw = im.comp[0].bw;
+	const uint32_t nblk = (uint32_t)(bw * im.comp[0].bh);
+	const uint32_t L = wk.first + threadIdx.x;
+	if (L >= nblk)
+		return;
+	const int W = im.width, H = im.height, color = im.color;
+	const bool four = color == MIJ_COLOR_CMYK || color == MIJ_COLOR_YCCK;
+	const int count_classes = im.flags & MIJ_DEV_COUNT_CLASSES;
+	IdctK KI;
+	KI.init();
+	uint2 r0[8], r1[8], r2[8], r3[8];
+	load_idct_block<WIDE, B8>(KI, coef_view(coef, im.comp[0]), L, im.dq[0], r0, count_classes);
+	load_idct_block<WIDE, B8>(KI, coef_view(coef, im.comp[1]), L, im.dq[1], r1, count_classes);
+	load_idct_block<WIDE, B8>(KI, coef_view(coef, im.comp[2]), L, im.dq[2], r2, count_classes);
+	if (four)
+		load_idct_block<WIDE, B8>(KI, coef_view(coef, im.comp[3]), L, im.dq[3], r3, count_classes);
+	else {
+#pragma unroll
+		for (int r = 0; r < 8; ++r)
+			r3[r] = make_uint2(0xffffffffu, 0xffffffffu);
+	}
+	const Block1x1 g = block_1x1_setup<NOUT>(im, L, nblk, lds_rows);
+	const int lane = (int)(threadIdx.x & 63u);
+	uint8_t *const out = outbase + im.out_off;
+	const size_t opitch = (size_t)W * NOUT;
+#pragma unroll
+	for (int r = 0; r < 8; ++r) {
+		if (g.y0 + r >= H)
+			break;
+		uint8_t *dst = out + (size_t)(g.y0 + r) * opitch + (size_t)g.x0 * NOUT;
+		uint8_t px[8][4];
+#pragma unroll
+		for (int j = 0; j < 8; ++j) {
+			const int sh = 8 * (j & 3);
+			const int a = (int)(((j < 4 ? r0[r].x : r0[r].y) >> sh) & 255u), b = (int)(((j < 4 ? r1[r].x : r1[r].y) >> sh) & 255u);
+			const int c = (int)(((j < 4 ? r2[r].x : r2[r].y) >> sh) & 255u), k = (int)(((j < 4 ? r3[r].x : r3[r].y) >> sh) & 255u);
+			int R, G, B;
+			if (color == MIJ_COLOR_RGB) {
+				R = a, G = b, B = c;
+			} else if (color == MIJ_COLOR_CMYK) {
+				R = blinn8(a, k), G = blinn8(b, k), B = blinn8(c, k);
+			} else { /* YCCK */
+				ycbcr_to_rgb(a, b, c, R, G, B);
+				R = blinn8(255 - R, k), G = blinn8(255 - G, k), B = blinn8(255 - B, k);
+			}
+			px[j][0] = (uint8_t)R, px[j][1] = (uint8_t)G, px[j][2] = (uint8_t)B, px[j][3] = 255;
+		}
+		if (g.whole) {
+			uint32_t q[2 * NOUT];
+			if constexpr (NOUT == 4) {
+#pragma unroll
+				for (int j = 0; j < 8; ++j)
+					q[j] = (uint32_t)px[j][0] | ((uint32_t)px[j][1] << 8) | ((uint32_t)px[j][2] << 16) | 0xff000000u;
+			} else {
+#pragma unroll
+				for (int h = 0; h < 2; ++h) {
+					const int j = 4 * h;
+					q[3 * h + 0] = (uint32_t)px[j][0] | ((uint32_t)px[j][1] << 8) | ((uint32_t)px[j][2] << 16) | ((uint32_t)px[j + 1][0] << 24);
+					q[3 * h + 1] = (uint32_t)px[j + 1][1] | ((uint32_t)px[j + 1][2] << 8) | ((uint32_t)px[j + 2][0] << 16) | ((uint32_t)px[j + 2][1] << 24);
+					q[3 * h + 2] = (uint32_t)px[j + 2][2] | ((uint32_t)px[j + 3][0] << 8) | ((uint32_t)px[j + 3][1] << 16) | ((uint32_t)px[j + 3][2] << 24);
+				}
+			}
+			store_row8<NOUT>(q, g.via_lds, g.lds_row, lane, dst, dst - (size_t)lane * (8 * NOUT));
+		} else {
+#pragma unroll
+			for (int j = 0; j < 8; ++j)
+				if (g.x0 + j < W)
+					store_rgb_px<NOUT>(dst + j * NOUT, px[j][0], px[j][1], px[j][2]);
 		}
 	}
 }

@@ -191,7 +191,7 @@ struct Slot {
 
 /* kernel families of a launch plan, in launch order */
 /* MK_RS_FAST + RS_*: pass 2 compiled per resampler (k_resample_fast); list index [n_out == 4][YCbCr colour][0] */
-enum { MK_PLANES = 0, MK_RESAMPLE, MK_RS_FAST, MK_420 = MK_RS_FAST + RS_KINDS, MK_422, MK_444, MK_GREY, MK_440, MK_420W, MK_440W /* k_fused420w / k_fused440w: 512 threads, wide pictures */, MK_420X /* 1024 threads: one workgroup per CU */, MK_420S, MK_420T /* 128 / 64 threads: narrow pictures */, MK_422W, MK_422X, MK_422S, MK_422T /* k_fused422 with 512 / 1024 / 128 / 64 threads */, MK_KINDS };
+enum { MK_PLANES = 0, MK_RESAMPLE, MK_RS_FAST, MK_420 = MK_RS_FAST + RS_KINDS, MK_422, MK_444, MK_GREY, MK_440, MK_420W, MK_440W /* k_fused420w / k_fused440w: 512 threads, wide pictures */, MK_420X /* 1024 threads: one workgroup per CU */, MK_420S, MK_420T /* 128 / 64 threads: narrow pictures */, MK_422W, MK_422X, MK_422S, MK_422T /* k_fused422 with 512 / 1024 / 128 / 64 threads */, MK_1X1C /* k_fused1x1c: RGB-tagged / CMYK / YCCK at 1x1 */, MK_KINDS };
 struct Work4 { /* WorkBand and WorkIdct are both four u32 */
 	uint32_t a, b, c, d;
 };
@@ -702,16 +702,30 @@ static int resample_fast_kind(const mij_batch *b, const mij_image_desc &d, int *
 	return hs == 4 ? RS_GEN4 : -1;
 }
 
-static bool fused444_ok(const mij_batch *b, const mij_image_desc &d)
+static bool all_1x1(const mij_image_desc &d)
 {
-	if (b->force_generic || (d.flags & MIJ_FLAG_SKIP))
-		return false;
-	if (d.ncomp != 3 || d.color != MIJ_COLOR_YCBCR || (d.n_out != 3 && d.n_out != 4))
-		return false;
-	for (int c = 0; c < 3; ++c)
+	for (int c = 0; c < d.ncomp; ++c)
 		if (d.comp[c].h != 1 || d.comp[c].v != 1)
 			return false;
 	return (uint64_t)d.width * d.height * d.n_out < 0xfffffff0ull;
+}
+static bool fused444_ok(const mij_batch *b, const mij_image_desc &d)
+{
+	if (b->force_generic || (d.flags & MIJ_FLAG_SKIP) || (d.n_out != 3 && d.n_out != 4))
+		return false;
+	/* three-component YCbCr, or four components whose transform is YCbCr with the fourth ignored (codec/jpeg.c:2367-2370): the kernel only touches components 0-2 */
+	if (!((d.ncomp == 3 && d.color == MIJ_COLOR_YCBCR) || (d.ncomp == 4 && d.color == MIJ_COLOR_YCBCRA)))
+		return false;
+	return all_1x1(d);
+}
+/* k_fused1x1c: RGB-tagged (codec/jpeg.c:2325-2335), Adobe CMYK (:2343-2354), YCCK (:2355-2366) with every component at 1x1 */
+static bool fused1x1c_ok(const mij_batch *b, const mij_image_desc &d)
+{
+	if (b->force_generic || (d.flags & MIJ_FLAG_SKIP) || (d.n_out != 3 && d.n_out != 4))
+		return false;
+	if (!((d.ncomp == 3 && d.color == MIJ_COLOR_RGB) || (d.ncomp == 4 && (d.color == MIJ_COLOR_CMYK || d.color == MIJ_COLOR_YCCK))))
+		return false;
+	return all_1x1(d);
 }
 
 /* Small tables (image descriptors, work lists, Huffman tables) go to the device by a copy KERNEL reading the
@@ -968,6 +982,9 @@ extern "C" int mij_batch_upload(mij_batch *b)
 		} else if (fused444_ok(b, d)) {
 			s.path = 3;
 			per_blocks(lists[MK_444][o4][wide][b8], 0);
+		} else if (fused1x1c_ok(b, d)) {
+			s.path = 7;
+			per_blocks(lists[MK_1X1C][o4][wide][b8], 0);
 		} else {
 			s.path = 2;
 			int ycc = 0;
@@ -1134,7 +1151,7 @@ extern "C" int mij_batch_launch(mij_batch *b)
 		return set_err(MIJ_E_STATE, "mij_batch_launch before mij_batch_upload");
 	HIP_TRY(hipSetDevice(b->ctx->device));
 	for (const auto &L : b->launches) { /* in family order: pass 2 of the two-pass family runs behind every pass-1 launch */
-		const dim3 grid((unsigned)L.count), block((L.kind >= MK_420 && L.kind != MK_444 && L.kind != MK_GREY) ? (unsigned)band_threads(L.kind) : 256u);
+		const dim3 grid((unsigned)L.count), block((L.kind >= MK_420 && L.kind != MK_444 && L.kind != MK_GREY && L.kind != MK_1X1C) ? (unsigned)band_threads(L.kind) : 256u);
 		const Work4 *wk = b->d_work + L.first;
 		switch (L.kind) {
 		case MK_420:
@@ -1175,6 +1192,9 @@ extern "C" int mij_batch_launch(mij_batch *b)
 			break;
 		case MK_444:
 			MIJ_LAUNCH_NWB(k_fused444, WorkIdct, MIJ_COEF_OUT);
+			break;
+		case MK_1X1C:
+			MIJ_LAUNCH_NWB(k_fused1x1c, WorkIdct, MIJ_COEF_OUT);
 			break;
 		case MK_GREY:
 			MIJ_LAUNCH_WB(k_fused_grey, MIJ_COEF_OUT);

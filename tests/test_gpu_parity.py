@@ -471,7 +471,7 @@ def test_two_pass_layouts_specialised_and_general_pass2(ica, oracle, gpu_ctx):
         ([(2, 2), (1, 1), (1, 1), (1, 1)], 2),   # fourth component not at full resolution: general pass 2 only
         ([(1, 1), (2, 2), (2, 2)], -1),          # luma below the chroma resolution: general pass 2 only
     ]
-    sizes = ((64, 48), (36, 20), (128, 72), (4, 4), (30, 17), (200, 97))
+    sizes = ((64, 48), (36, 20), (128, 72), (4, 4), (30, 17), (200, 97), (1040, 24))  # the last: 130 blocks a row, wavefronts inside one block row (LDS-transposed stores)
     datas, fast = [], []
     for li, (hv, app14) in enumerate(layouts):
         for si, (w, h) in enumerate(sizes):
@@ -491,13 +491,20 @@ def test_two_pass_layouts_specialised_and_general_pass2(ica, oracle, gpu_ctx):
                 got = b.fetch(s)
                 assert np.array_equal(got, want), (i, layouts[i // len(sizes)], sizes[i % len(sizes)], req, generic, int((got != want).sum()))
             b.close()
-    # default choice: the same pixels again (fused kernels where they apply, two-pass elsewhere)
-    b, slots = _batch_for(ica, gpu_ctx, datas, 3)
-    b.submit()
-    b.wait()
-    for i, s in enumerate(slots):
-        assert np.array_equal(b.fetch(s), oracle.load(datas[i], 3)[1]), i
-    b.close()
+    # default choice: the same pixels again (fused kernels where they apply, two-pass elsewhere).  Round 3: RGB-tagged, CMYK and YCCK files
+    # whose components are all 1x1 take k_fused1x1c (path 7), four-component YCbCr with the fourth ignored takes k_fused444 (path 3)
+    for req in (3, 4):
+        b, slots = _batch_for(ica, gpu_ctx, datas, req)
+        b.submit()
+        b.wait()
+        for i, s in enumerate(slots):
+            li = i // len(sizes)
+            assert np.array_equal(b.fetch(s), oracle.load(datas[i], req)[1]), (i, layouts[li], sizes[i % len(sizes)], req)
+            if li in (7, 9, 10):
+                assert b.slot_path(s) == 7, (li, b.slot_path(s))
+            if li == 13:
+                assert b.slot_path(s) == 3, (li, b.slot_path(s))
+        b.close()
 
 
 def test_fused_440_kernel_vs_oracle_and_two_pass(ica, oracle, gpu_ctx, monkeypatch):
