@@ -235,12 +235,27 @@ def traffic_entry(key):
     return None
 
 
+def kernel_source_hash():
+    """first 16 hex digits of the SHA-256 over the kernel sources: profiles/traffic.json entries carry the hash of the build they were measured on"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("mij_kernels.h", "mij_entropy_kernels.h", "mij_runtime.hip"):
+        try:
+            h.update(open(os.path.join(ROOT, "image-codecs_amd", "csrc", f), "rb").read())
+        except OSError:
+            h.update(b"missing:" + f.encode())
+    return h.hexdigest()[:16]
+
+
 def add_traffic(res, key):
     t = traffic_entry(key)
     res["traffic"] = t["hbm_bytes_per_launch"] if t else None
     res["traffic_source"] = ("profiles/traffic.json[%s]: %s" % (key, t.get("source", "rocprofv3 --pmc passes"))) if t else \
         "not measured for this launch shape (profiles/traffic.json has no entry %s)" % key
     res["hbm_counter_frac"] = round(t["hbm_bytes_per_launch"] / (res["kernel_ms_per_launch"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if t else None
+    if t:  # ADVICE r2: the committed counters are only as fresh as the build they were taken on -- say so in the line
+        res["traffic_kernel_hash"] = t.get("kernel_source_hash")
+        res["traffic_stale"] = t.get("kernel_source_hash") != kernel_source_hash()
 
 
 # ---------------------------------------------------------------------------------------------------- secondary legs
