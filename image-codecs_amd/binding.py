@@ -602,6 +602,12 @@ class Batch:
         """Blocks of the slot that hold a coefficient outside -128..127 (compact planes only)."""
         return _check(lib().mij_batch_slot_escapes(self._h, int(slot)), "mij_batch_slot_escapes")
 
+    def slot_flags(self, slot):
+        L = lib()
+        L.mij_batch_slot_flags.restype = C.c_uint32
+        L.mij_batch_slot_flags.argtypes = [C.c_void_p, C.c_int]
+        return int(L.mij_batch_slot_flags(self._h, int(slot)))
+
     def pack_ms(self):
         """ms of k_pack_c8 in the last upload, or None when nothing was packed (host-staged compact planes, GPU-walk planes, int16 planes)"""
         L = lib()

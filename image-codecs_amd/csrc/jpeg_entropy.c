@@ -1296,7 +1296,7 @@ int mjh_decode_scans(mjh_decoder *d)
 		}
 		m = get_marker(d);
 	}
-	if (d->progressive)
+	if (d->progressive && !d->defer_l1)
 		progressive_l1(d);
 	return 1;
 }
@@ -1351,6 +1351,7 @@ int mjh_attach_staging(mjh_decoder *d, const mij_image_desc *desc, uint8_t *regi
 	int i;
 	init_tile_off();
 	d->any_escape = 0;
+	d->defer_l1 = (want_compact && d->progressive) ? 1 : 0; /* the planes will be packed on the device: k_pack_c8 takes the L1 bound there */
 	if (want_compact && !d->progressive) {
 		for (i = 0; i < desc->ncomp; ++i) {
 			size_t lo, dc, hi;
@@ -1380,7 +1381,8 @@ int mjh_attach_staging(mjh_decoder *d, const mij_image_desc *desc, uint8_t *regi
 
 uint32_t mjh_stage_flags(const mjh_decoder *d)
 {
-	return (mjh_needs_wide_idct(d) ? MIJ_FLAG_WIDE_IDCT : 0u) | (d->compact ? MIJ_FLAG_STAGED_COMPACT : 0u) | ((d->compact && d->any_escape) ? MIJ_FLAG_HAS_ESCAPES : 0u);
+	return (mjh_needs_wide_idct(d) ? MIJ_FLAG_WIDE_IDCT : 0u) | (d->compact ? MIJ_FLAG_STAGED_COMPACT : 0u) | ((d->compact && d->any_escape) ? MIJ_FLAG_HAS_ESCAPES : 0u) |
+			 ((d->progressive && d->defer_l1) ? MIJ_FLAG_L1_ON_DEVICE : 0u);
 }
 
 int mjh_decode_memory_fmt(const uint8_t *buf, int len, int req_comp, mij_image_desc *desc, uint8_t *region, size_t region_bytes, int want_compact, const char **reason)

@@ -94,6 +94,8 @@ typedef struct {
 	 * read, so no pack pass and half the bytes over PCIe; progressive scans read-modify-write int16 planes and never set this.
 	 * any_escape: some block holds a coefficient beyond a byte (its escape bytes are in use: MIJ_FLAG_HAS_ESCAPES) */
 	int compact, any_escape;
+	/* 1: a progressive file staged for a batch that packs on the device: the per-block L1 bound is taken there (MIJ_FLAG_L1_ON_DEVICE), not in a pass over the planes here */
+	int defer_l1;
 	/* largest per-block sum of |de-quantised coefficient| seen (baseline), for MIJ_FLAG_WIDE_IDCT */
 	int32_t max_block_l1;
 	const char *reason; /* short failure reason, reference wording */

@@ -844,8 +844,13 @@ __global__ __launch_bounds__(256) void k_idct_planes(const DevImage *__restrict_
  * beyond a byte never leaves the GPU path: its blocks get escape bytes.  One block per lane, whole tiles (the
  * padding blocks of the last tile are zero in the source and come out as zero).
  * work.first = first block, work.comp = component. */
+/* MIJ_DEV_L1_MAX in DevImage.flags (progressive files, MIJ_FLAG_L1_ON_DEVICE): every block's sum of |(short)(coef * q)| -- the bound behind
+ * MIJ_FLAG_WIDE_IDCT, which the host computes for baseline files while it walks them and would need one more pass over 100 MB of planes for a
+ * 4096 x 4096 progressive file -- is taken here, where every coefficient passes through registers anyway, and its maximum over the image
+ * lands in l1max[image] (one atomic per wavefront). */
+#define MIJ_DEV_L1_MAX 0x400
 __global__ __launch_bounds__(256) void k_pack_c8(const DevImage *__restrict__ imgs, const WorkIdct *__restrict__ work, const uint8_t *__restrict__ src16,
-																 uint8_t *__restrict__ coef)
+																 uint8_t *__restrict__ coef, uint32_t *__restrict__ l1max)
 {
 	const WorkIdct wk = work[blockIdx.x];
 	const DevImage &im = imgs[wk.img];
@@ -875,6 +880,28 @@ __global__ __launch_bounds__(256) void k_pack_c8(const DevImage *__restrict__ im
 		lo[2 * k + 1] = __builtin_amdgcn_perm(w[3], w[2], 0x06040200u);
 		hi[2 * k] = __builtin_amdgcn_perm(t[1], t[0], 0x07050301u);
 		hi[2 * k + 1] = __builtin_amdgcn_perm(t[3], t[2], 0x07050301u);
+	}
+	if (im.flags & MIJ_DEV_L1_MAX) { /* wave-uniform */
+		const uint32_t *dq = im.dq[wk.comp];
+		uint32_t l1 = 0;
+#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+			const uint32_t w[4] = {c[k].x, c[k].y, c[k].z, c[k].w};
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				const v2s m = __builtin_bit_cast(v2s, pkmul(w[j], dq[4 * k + j]));
+				const v2s a = __builtin_elementwise_max(m, (v2s)(-m)); /* |-32768| stays 0x8000 = 32768 as an unsigned half */
+				const v2u au = __builtin_bit_cast(v2u, a);
+				l1 += (uint32_t)au.x + (uint32_t)au.y;
+			}
+		}
+#pragma unroll
+		for (int off = 32; off >= 1; off >>= 1) {
+			const uint32_t o = (uint32_t)__shfl_xor((int)l1, off, 64);
+			l1 = o > l1 ? o : l1;
+		}
+		if ((threadIdx.x & 63u) == 0u)
+			atomicMax(&l1max[wk.img], l1);
 	}
 	const uint32_t dc = c[0].x & 0xffffu;
 	lo[0] = (lo[0] & 0xffffff00u) | (any ? 1u : 0u); /* flags byte in the DC's place */

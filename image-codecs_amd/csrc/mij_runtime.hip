@@ -213,6 +213,7 @@ struct mij_batch {
 	uint8_t *d_planes;
 	size_t planes_cap;
 	uint8_t *d_up16; /* upload scratch: int16 planes on their way into compact planes (k_pack_c8), stage_cap bytes */
+	uint32_t *d_l1max, *h_l1max; /* per slot: largest per-block L1 the pack kernel saw (MIJ_FLAG_L1_ON_DEVICE); max_images entries, created on first use */
 	/* descriptors + work lists (pinned host mirror + device copy) */
 	DevImage *h_imgs, *d_imgs;
 	Work4 *h_work, *d_work;
@@ -265,6 +266,7 @@ extern "C" int mij_batch_create(mij_ctx *ctx, int max_images, size_t stage_bytes
 	b->h_imgs = b->d_imgs = nullptr;
 	b->h_work = b->d_work = nullptr;
 	b->d_up16 = nullptr;
+	b->d_l1max = b->h_l1max = nullptr;
 	b->stage_cap = stage_bytes;
 	b->coef_cap = coef_bytes;
 	b->out_cap = out_bytes;
@@ -338,6 +340,10 @@ extern "C" void mij_batch_destroy(mij_batch *b)
 		(void)hipFree(b->d_work);
 	if (b->d_up16)
 		(void)hipFree(b->d_up16);
+	if (b->d_l1max)
+		(void)hipFree(b->d_l1max);
+	if (b->h_l1max)
+		(void)hipHostFree(b->h_l1max);
 	if (b->es)
 		es_free_fwd(b->es);
 	if (b->ev_begin)
@@ -574,6 +580,12 @@ extern "C" uint8_t *mij_batch_stage_region(mij_batch *b, int slot, size_t *bytes
 }
 
 extern "C" int mij_batch_coef_format(const mij_batch *b) { return b ? b->coef_fmt : MIJ_COEF_COMPACT; }
+extern "C" uint32_t mij_batch_slot_flags(const mij_batch *b, int slot)
+{
+	if (!b || slot < 0 || slot >= (int)b->slots.size())
+		return 0;
+	return b->slots[(size_t)slot].desc.flags;
+}
 
 extern "C" int mij_batch_set_flags(mij_batch *b, int slot, uint32_t flags)
 {
@@ -852,7 +864,7 @@ extern "C" int mij_batch_upload(mij_batch *b)
 		if (s.clone_of >= 0)
 			s.coef_bytes_fmt = b->slots[(size_t)s.clone_of].coef_bytes_fmt;
 		else if (!s.dev_coef) /* planes the host staged compact keep that format whatever the batch's default */
-			s.coef_bytes_fmt = ((b->coef_fmt || (s.desc.flags & MIJ_FLAG_STAGED_COMPACT)) && !(s.desc.flags & MIJ_FLAG_SKIP)) ? 1 : 0;
+			s.coef_bytes_fmt = ((b->coef_fmt || (s.desc.flags & (MIJ_FLAG_STAGED_COMPACT | MIJ_FLAG_L1_ON_DEVICE))) && !(s.desc.flags & MIJ_FLAG_SKIP)) ? 1 : 0;
 		layout_coef(s);
 		if (s.clone_of < 0 && !s.dev_coef && s.coef_bytes_fmt && !(s.desc.flags & MIJ_FLAG_STAGED_COMPACT))
 			need_pack = true;
@@ -861,6 +873,72 @@ extern "C" int mij_batch_upload(mij_batch *b)
 		hipError_t e = hipMalloc(reinterpret_cast<void **>(&b->d_up16), b->stage_cap ? b->stage_cap : 16);
 		if (e != hipSuccess)
 			return set_err(e == hipErrorOutOfMemory ? MIJ_E_NOMEM : MIJ_E_HIP, "upload scratch: %s", hipGetErrorString(e));
+	}
+
+	/* ---- progressive files whose L1 bound the host left to the device (MIJ_FLAG_L1_ON_DEVICE): their planes go up and are packed NOW, the
+	 * pack kernel takes every block's L1 on the way, the maxima come back, and MIJ_FLAG_WIDE_IDCT is set before the launch plan below sorts
+	 * the images by it.  Afterwards these slots hold finished compact planes in HBM (dev_coef: later uploads leave them alone). */
+	{
+		std::vector<Work4> pre;
+		for (size_t i = 0; i < n; ++i) {
+			const Slot &s = b->slots[i];
+			if (s.clone_of < 0 && !s.dev_coef && (s.desc.flags & MIJ_FLAG_L1_ON_DEVICE) && !(s.desc.flags & MIJ_FLAG_SKIP))
+				for (int c = 0; c < s.desc.ncomp; ++c)
+					for (uint32_t f = 0, nb = (uint32_t)comp_tiles(s.desc.comp[c]) * 64u; f < nb; f += 256)
+						pre.push_back(Work4{(uint32_t)i, (uint32_t)c, f, 0u});
+		}
+		if (!pre.empty()) {
+			if (!b->d_l1max) {
+				HIP_TRY(hipMalloc(reinterpret_cast<void **>(&b->d_l1max), sizeof(uint32_t) * (size_t)b->max_images));
+				HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_l1max), sizeof(uint32_t) * (size_t)b->max_images, hipHostMallocDefault));
+			}
+			if (pre.size() > b->work_cap)
+				HIP_TRY(hipStreamSynchronize(b->stream));
+			int rc0;
+			if ((rc0 = grow_pair(b->h_work, b->d_work, b->work_cap, pre.size())) != MIJ_OK)
+				return rc0;
+			memcpy(b->h_work, pre.data(), pre.size() * sizeof(Work4));
+			for (size_t i = 0; i < n; ++i) {
+				Slot &s = b->slots[i];
+				s.dev.src16_off = s.stage_off == MIJ_NO_STAGE ? 0 : s.stage_off;
+				b->h_imgs[i] = s.dev;
+				if (s.clone_of < 0 && !s.dev_coef && (s.desc.flags & MIJ_FLAG_L1_ON_DEVICE))
+					b->h_imgs[i].flags |= MIJ_DEV_L1_MAX;
+			}
+			HIP_TRY(copy_table(b->d_imgs, b->h_imgs, sizeof(DevImage) * n, b->stream));
+			HIP_TRY(copy_table(b->d_work, b->h_work, sizeof(Work4) * pre.size(), b->stream));
+			HIP_TRY(hipMemsetAsync(b->d_l1max, 0, sizeof(uint32_t) * n, b->stream));
+			for (size_t i = 0; i < n; ++i) {
+				const Slot &s = b->slots[i];
+				if (s.clone_of < 0 && !s.dev_coef && (s.desc.flags & MIJ_FLAG_L1_ON_DEVICE) && !(s.desc.flags & MIJ_FLAG_SKIP)) {
+					size_t bytes16 = 0;
+					for (int c = 0; c < s.desc.ncomp; ++c)
+						bytes16 += comp_tiles(s.desc.comp[c]) << 13;
+					HIP_TRY(hipMemcpyAsync(b->d_up16 + s.stage_off, b->stage + s.stage_off, bytes16, hipMemcpyHostToDevice, b->stream));
+				}
+			}
+			hipLaunchKernelGGL(k_pack_c8, dim3((unsigned)pre.size()), dim3(256), 0, b->stream, b->d_imgs, reinterpret_cast<const WorkIdct *>(b->d_work), b->d_up16, b->d_coef, b->d_l1max);
+			HIP_TRY(hipGetLastError());
+			HIP_TRY(copy_table_to_host(b->h_l1max, b->d_l1max, sizeof(uint32_t) * n, b->stream));
+			HIP_TRY(hipStreamSynchronize(b->stream));
+			for (size_t i = 0; i < n; ++i) {
+				Slot &s = b->slots[i];
+				if (s.clone_of < 0 && !s.dev_coef && (s.desc.flags & MIJ_FLAG_L1_ON_DEVICE) && !(s.desc.flags & MIJ_FLAG_SKIP)) {
+					s.desc.flags &= ~(uint32_t)MIJ_FLAG_L1_ON_DEVICE;
+					if (b->h_l1max[i] > (uint32_t)MIJ_BLOCK_L1_LIMIT)
+						s.desc.flags |= MIJ_FLAG_WIDE_IDCT;
+					s.dev.flags = (int32_t)s.desc.flags | MIJ_DEV_COEF_BYTES;
+					s.dev_coef = 1;
+				}
+			}
+			for (size_t i = 0; i < n; ++i) { /* clones take their source's verdict */
+				Slot &s = b->slots[i];
+				if (s.clone_of >= 0 && (s.desc.flags & MIJ_FLAG_L1_ON_DEVICE)) {
+					s.desc.flags = b->slots[(size_t)s.clone_of].desc.flags;
+					s.dev.flags = (int32_t)s.desc.flags | MIJ_DEV_COEF_BYTES;
+				}
+			}
+		}
 	}
 
 	/* ---- plan: one work list per (kernel family, n_out, wide IDCT, plane format) */
@@ -1098,7 +1176,7 @@ extern "C" int mij_batch_upload(mij_batch *b)
 			HIP_TRY(hipEventCreate(&b->ev_pack1));
 		}
 		HIP_TRY(hipEventRecord(b->ev_pack0, b->stream));
-		hipLaunchKernelGGL(k_pack_c8, dim3((unsigned)pack.size()), dim3(256), 0, b->stream, b->d_imgs, reinterpret_cast<const WorkIdct *>(b->d_work), b->d_up16, b->d_coef);
+		hipLaunchKernelGGL(k_pack_c8, dim3((unsigned)pack.size()), dim3(256), 0, b->stream, b->d_imgs, reinterpret_cast<const WorkIdct *>(b->d_work), b->d_up16, b->d_coef, b->d_l1max);
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipEventRecord(b->ev_pack1, b->stream));
 		b->pack_timed = true;

@@ -59,6 +59,9 @@ enum {
 #define MIJ_FLAG_STAGED_COMPACT 4u /* the host stage wrote the slot's staging as COMPACT planes itself (mij_compact_offsets; the
                                       baseline Huffman walk does: mjh_decode_memory_fmt): upload copies them as they are, no pack */
 #define MIJ_FLAG_HAS_ESCAPES 8u    /* ... and at least one block holds a coefficient beyond a byte: the escape region goes up too */
+#define MIJ_FLAG_L1_ON_DEVICE 16u  /* a progressive file whose per-block L1 bound (MIJ_BLOCK_L1_LIMIT) the host did NOT compute: the pack
+                                      kernel, which reads every coefficient of the int16 staging anyway, takes the maximum and
+                                      mij_batch_upload raises MIJ_FLAG_WIDE_IDCT from it (one small copy back and a wait inside upload) */
 
 /* per component geometry, exactly the reference's img_comp[] fields (codec/jpeg.c:48-62, :1624-1655) */
 typedef struct {
@@ -215,6 +218,8 @@ int16_t *mij_batch_coef(mij_batch *b, int slot, int comp);
 uint8_t *mij_batch_stage_region(mij_batch *b, int slot, size_t *bytes);
 /* MIJ_COEF_COMPACT / MIJ_COEF_INT16: the format host-staged planes get in HBM (a host stage asked for int16 planes stages int16) */
 int mij_batch_coef_format(const mij_batch *b);
+/* MIJ_FLAG_* of a slot as they stand (after mij_batch_upload: with MIJ_FLAG_WIDE_IDCT where the device found it, MIJ_FLAG_L1_ON_DEVICE cleared) */
+uint32_t mij_batch_slot_flags(const mij_batch *b, int slot);
 /* May be called after the entropy stage to raise flags it only knows late (e.g. WIDE_IDCT). */
 int mij_batch_set_flags(mij_batch *b, int slot, uint32_t flags);
 

@@ -150,3 +150,54 @@ def test_host_staged_compact_planes_equal_the_packed_ones(ica, oracle, gpu_ctx):
         b.close()
     direct.close()
     packed.close()
+
+
+def test_progressive_l1_bound_is_taken_by_the_pack_kernel(ica, oracle, gpu_ctx):
+    """Round 3: for a progressive file staged for a compact batch the host no longer makes a pass over the finished planes for the per-block
+    L1 bound behind MIJ_FLAG_WIDE_IDCT (MIJ_FLAG_L1_ON_DEVICE): k_pack_c8 takes it while it packs and mij_batch_upload raises the flag.  The
+    verdict equals the host's own (mjh_decode_memory still computes it), for tame streams, streams just around the limit and wild ones; pixels
+    equal the oracle's either way; clones follow their source."""
+    rng = np.random.default_rng(9)
+    datas = []
+    for (w, h, q, boost) in ((120, 88, 92, 0), (96, 64, 100, 0), (64, 64, 95, 300), (200, 120, 90, 1000), (72, 40, 100, 32767), (40, 24, 75, 40)):
+        img = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+        plan, du = ica.host_transform(img, q)
+        du = du.copy()
+        if boost:
+            du[::3, 1] = boost
+            du[1::5, 5] = -boost
+            du[:, 0] = np.clip(du[:, 0], -900, 900)
+        datas.append(helpers.progressive_from_du(plan, du, 1 if w != 96 else 2))
+    host_wide = [bool(ica.HostDecoder.decode(d, 3)[0].flags & 1) for d in datas]
+    assert any(host_wide) and not all(host_wide)
+    b = ica.Batch(gpu_ctx, 2 * len(datas), 64 << 20, 64 << 20, 64 << 20)
+    slots = [b.add_jpeg(d, 3) for d in datas]
+    assert all(b.slot_flags(s) & 16 for s in slots), "the walk did not leave the L1 bound to the device"
+    clones = [b.add_clone(s) for s in slots]
+    b.submit()
+    b.wait()
+    for i, s in enumerate(slots):
+        f = b.slot_flags(s)
+        assert not (f & 16) and bool(f & 1) == host_wide[i], (i, f, host_wide[i])
+        kind, want, _ = oracle.load(datas[i], 3)
+        assert np.array_equal(b.fetch(s), want), i
+        assert np.array_equal(b.fetch(clones[i]), want), ("clone", i)
+    # a second upload (another kernel family) leaves the packed planes alone
+    b.force_generic(True)
+    b.submit()
+    b.wait()
+    for i, s in enumerate(slots):
+        assert np.array_equal(b.fetch(s), oracle.load(datas[i], 3)[1]), ("two-pass", i)
+    b.close()
+    # the front end on host threads and stbi_load take the same route
+    b = ica.Batch(gpu_ctx, len(datas), 64 << 20, 64 << 20, 64 << 20)
+    ok, slots, reasons = b.decode_jpegs(datas, 3, threads=3, gpu_entropy=False)
+    assert ok == len(datas), reasons
+    b.submit()
+    b.wait()
+    for i, s in enumerate(slots):
+        assert bool(b.slot_flags(s) & 1) == host_wide[i] and np.array_equal(b.fetch(s), oracle.load(datas[i], 3)[1]), i
+    b.close()
+    for i, d in enumerate(datas):
+        got = ica.stbi_load_from_memory(d, 3)
+        assert got is not None and np.array_equal(got[0], oracle.load(d, 3)[1]), i
