@@ -343,18 +343,26 @@ def leg_config4(ica, ctx, args, checker):
                 eb.decode_jpegs([data] * 2, 3, threads, gpu_entropy=False)
                 eb.submit()
                 eb.wait()
+            import threading
             th = 0.0
             te = time.perf_counter()
-            last = {}
+            last, subs = {}, {}
             for k, lo in enumerate(range(0, ne, chunk)):
                 eb = ebs[k & 1]
+                if (k & 1) in subs:
+                    subs.pop(k & 1).join()
                 eb.reset()  # waits for this batch's previous chunk
                 t0 = time.perf_counter()
                 ok, slots, reasons = eb.decode_jpegs([data] * chunk, 3, threads, gpu_entropy=False)
                 th += time.perf_counter() - t0
                 assert ok == chunk, reasons
-                eb.submit()
+                # submit on a helper thread: upload of a progressive chunk waits once for the pack kernel's L1 maxima (1.6 GB of int16 planes
+                # go up first), and the host threads should be walking the next chunk meanwhile (ctypes drops the GIL around the call)
+                subs[k & 1] = threading.Thread(target=eb.submit)
+                subs[k & 1].start()
                 last[k & 1] = slots[-1]
+            for t in subs.values():
+                t.join()
             for eb in ebs:
                 eb.wait()
             te = time.perf_counter() - te
