@@ -112,8 +112,10 @@ def main():
                     datas.append(helpers.baseline_from_du(plan, du, dri, lay))
         req = int(rng.integers(0, 5))
         wants = [oracle.load(d, req) for d in datas]
-        for mode in ("fused", "generic", "generic2", "gpu_walk"):
+        for mode in ("fused", "fused_int16", "generic", "generic2", "gpu_walk"):
             b = ica.Batch(ctx, len(datas), 96 << 20, 96 << 20, 96 << 20)
+            if mode == "fused_int16":  # int16 tile-layout planes: int16 staging, block classes computed from the int16 block
+                b.set_coef_format("int16")
             if mode == "gpu_walk":
                 b.entropy_reserve(8 << 20)
             b.force_generic(1 if mode == "generic" else (2 if mode == "generic2" else 0))
