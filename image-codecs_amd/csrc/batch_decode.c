@@ -155,6 +155,9 @@ static void *extract_worker(void *arg)
 	return NULL;
 }
 
+/* (documented rather than changed: the pool runs ONE job at a time -- callers of the batch front ends on different threads queue
+ * on job_lock for the length of a host stage, which is what a machine whose cores one job already fills wants; the helpers are detached and
+ * live until the process ends, so this library must not be dlclose()d once a batch front end has run -- INTEGRATION.md says so.) */
 /* A process-wide pool of helper threads, created on first use and kept: spawning and joining 15 threads per call cost
  * more than the work of a 128-image chunk's header stage.  One job at a time (callers queue on job_lock); a job is
  * "run fn(arg) on up to `want` helpers besides the caller" -- fn pulls work items itself, so helpers that wake up late
