@@ -2148,7 +2148,7 @@ struct EncSlot {
 	mjw_plan plan;
 	EncImage dev;
 	size_t stage_off, pix_bytes, du_bytes;
-	int pad_w; /* pixels per staged row: the width rounded up to whole MCU columns for 3-component pictures (enc_padded_width) */
+	int pad_w; /* pixels per staged row: the width rounded up to whole MCU columns (enc_padded_width); staged rows are packed RGB */
 	int clone_of, flip;
 };
 
@@ -2267,26 +2267,38 @@ extern "C" int mij_enc_reset(mij_encoder *e)
 	return MIJ_OK;
 }
 
-/* 3-component pictures are staged with rows of whole MCU columns, the last pixel of a row repeated into the padding -- the reference's
- * edge rule (codec/jpeg_write.c:294-296) applied once on the way in -- so the strip kernels (k_encode420 / k_encode444: 16-byte or
- * 8-byte row chunks, no column clamp) take every width, not only multiples of 16 / 8; the per-unit kernels see the same rows. */
-static int enc_padded_width(int width, int comp, int subsample)
+/* Every picture is staged as packed RGB with rows of whole MCU columns: the last pixel of a row repeated into the padding -- the reference's
+ * edge rule (codec/jpeg_write.c:294-296) applied once on the way in -- and, round 3, the reference's channel rule applied there too
+ * (codec/jpeg_write.c:276-279: "ofsG = comp > 2 ? 1 : 0, ofsB = comp > 2 ? 2 : 0", r = data[p]): a grey or grey + alpha picture becomes
+ * r = g = b = grey, an RGBA picture loses its alpha.  The device therefore only ever sees three channels, the same float expressions run on the
+ * same values, and the strip kernels (k_encode420 / k_encode444: 16-byte or 8-byte row chunks, no column clamp) take every width and every
+ * `comp`, not only RGB at multiples of 16 / 8 (the per-unit kernels remain as their test twins, mij_enc_force_generic). */
+static int enc_padded_width(int width, int subsample)
 {
 	const int unit = subsample ? 16 : 8;
-	return comp == 3 ? (width + unit - 1) / unit * unit : width;
+	return (width + unit - 1) / unit * unit;
 }
 static void enc_stage_rows(uint8_t *dst, const uint8_t *src, int width, int height, int comp, int pad_w)
 {
-	if (pad_w == width) {
-		memcpy(dst, src, (size_t)width * height * comp);
+	if (comp == 3 && pad_w == width) {
+		memcpy(dst, src, (size_t)width * height * 3);
 		return;
 	}
-	const size_t in_pitch = (size_t)width * comp, out_pitch = (size_t)pad_w * comp;
+	const size_t in_pitch = (size_t)width * comp, out_pitch = (size_t)pad_w * 3;
+	const int og = comp > 2 ? 1 : 0, ob = comp > 2 ? 2 : 0;
 	for (int y = 0; y < height; ++y) {
 		uint8_t *d = dst + (size_t)y * out_pitch;
-		memcpy(d, src + (size_t)y * in_pitch, in_pitch);
+		const uint8_t *p = src + (size_t)y * in_pitch;
+		if (comp == 3)
+			memcpy(d, p, in_pitch);
+		else
+			for (int x = 0; x < width; ++x) {
+				d[3 * x] = p[(size_t)x * comp];
+				d[3 * x + 1] = p[(size_t)x * comp + og];
+				d[3 * x + 2] = p[(size_t)x * comp + ob];
+			}
 		for (int x = width; x < pad_w; ++x)
-			memcpy(d + (size_t)x * comp, d + (size_t)(width - 1) * comp, (size_t)comp);
+			memcpy(d + (size_t)x * 3, d + (size_t)(width - 1) * 3, 3);
 	}
 }
 extern "C" size_t mij_enc_pixel_bytes(int width, int height, int comp, int quality)
@@ -2294,7 +2306,7 @@ extern "C" size_t mij_enc_pixel_bytes(int width, int height, int comp, int quali
 	mjw_plan plan;
 	if (!mjw_plan_init(&plan, width, height, comp, quality))
 		return 0;
-	return align_up((size_t)enc_padded_width(width, comp, plan.subsample) * height * comp, 256);
+	return align_up((size_t)enc_padded_width(width, plan.subsample) * height * 3, 256);
 }
 
 static int enc_add_common(mij_encoder *e, const mjw_plan &plan, const void *pixels, int flip, int clone_of)
@@ -2305,8 +2317,8 @@ static int enc_add_common(mij_encoder *e, const mjw_plan &plan, const void *pixe
 	s.plan = plan;
 	s.flip = flip;
 	s.clone_of = clone_of;
-	s.pad_w = enc_padded_width(plan.width, plan.comp, plan.subsample);
-	s.pix_bytes = align_up((size_t)s.pad_w * plan.height * plan.comp, 256);
+	s.pad_w = enc_padded_width(plan.width, plan.subsample);
+	s.pix_bytes = align_up((size_t)s.pad_w * plan.height * 3, 256); /* staged as packed RGB whatever plan.comp is (enc_stage_rows) */
 	s.du_bytes = align_up(mjw_plan_du_count(&plan) * 128, 256);
 	if (e->pix_used + s.pix_bytes > e->pix_cap)
 		return set_err(MIJ_E_NOMEM, "pixel arena exhausted");
@@ -2325,7 +2337,7 @@ static int enc_add_common(mij_encoder *e, const mjw_plan &plan, const void *pixe
 	memset(&s.dev, 0, sizeof(s.dev));
 	s.dev.width = s.pad_w; /* the device sees whole MCU columns */
 	s.dev.height = plan.height;
-	s.dev.comp = plan.comp;
+	s.dev.comp = 3; /* what the staging holds */
 	s.dev.subsample = plan.subsample;
 	s.dev.mcu_x = plan.mcu_x;
 	s.dev.mcu_y = plan.mcu_y;
@@ -2440,7 +2452,7 @@ extern "C" int mij_enc_upload(mij_encoder *e)
 		const uint32_t ny = nm * (sub ? 4u : 1u), nc = nm * 2u;
 		e->h_imgs[i] = s.dev;
 		/* strips of 32 MCUs through the fused kernel: whole 16-pixel columns, packed RGB, 16-byte aligned rows (every width: enc_padded_width) */
-		if (sub && s.plan.comp == 3 && !e->force_generic) {
+		if (sub && !e->force_generic) { /* every comp: the staging is packed RGB */
 			for (uint32_t f = 0; f < nm; f += MIJ_ENC_STRIP) {
 				WorkIdct w = {(uint32_t)i, 0u, f, 0u};
 				work[4].push_back(w);
@@ -2448,7 +2460,7 @@ extern "C" int mij_enc_upload(mij_encoder *e)
 			continue;
 		}
 		/* 4:4:4 (quality above 90): strips of 64 MCUs through k_encode444: whole 8-pixel columns, packed RGB, 8-byte aligned rows */
-		if (!sub && s.plan.comp == 3 && !e->force_generic) {
+		if (!sub && !e->force_generic) {
 			for (uint32_t f = 0; f < nm; f += MIJ_ENC444_STRIP) {
 				WorkIdct w = {(uint32_t)i, 0u, f, 0u};
 				work[5].push_back(w);

@@ -356,12 +356,13 @@ int mij_enc_add_clone(mij_encoder *e, int src_slot); /* own device buffers, same
  * mij_enc_upload (batch front ends fill the slots from several host threads at once, mij_write_jpg_batch) */
 int mij_enc_add_uncopied(mij_encoder *e, int width, int height, int comp, int quality, int flip_vertically);
 void *mij_enc_staging(mij_encoder *e, int slot);
-/* Bytes one picture takes in the pixel arenas (pix_cap of mij_enc_create): 3-component pictures are staged with rows of whole MCU
- * columns (width rounded up to 16, or to 8 above quality 90), the last pixel of a row repeated -- codec/jpeg_write.c:294-296 applied on
- * the way in -- so that the strip kernels take every width; rounded up to 256. */
+/* Bytes one picture takes in the pixel arenas (pix_cap of mij_enc_create).  Every picture is staged as packed RGB with rows of whole MCU
+ * columns (width rounded up to 16, or to 8 above quality 90): the last pixel of a row repeated -- codec/jpeg_write.c:294-296 -- and the
+ * channels picked as the reference picks them (:276-279: grey and grey + alpha pictures become r = g = b = grey, RGBA loses its alpha), both
+ * applied on the way in, so that the strip kernels take every width and every comp; rounded up to 256. */
 size_t mij_enc_pixel_bytes(int width, int height, int comp, int quality);
-/* Copies a picture into the staging of a slot made by mij_enc_add_uncopied in that layout (callable from several threads for different
- * slots).  mij_enc_staging() returns the same memory: its row pitch is the padded width x comp. */
+/* Copies a picture (comp bytes per pixel, as passed to stbi_write_jpg) into the staging of a slot made by mij_enc_add_uncopied in that layout
+ * (callable from several threads for different slots).  mij_enc_staging() returns the same memory: packed RGB, row pitch = padded width x 3. */
 int mij_enc_stage_pixels(mij_encoder *e, int slot, const void *pixels);
 /* every slot's data units into the encoder's pinned mirror with one device-to-host copy (waits for it); mij_enc_units(slot)
  * points into that mirror until the next mij_enc_fetch_all / mij_enc_destroy */
