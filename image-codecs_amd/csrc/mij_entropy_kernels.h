@@ -842,12 +842,30 @@ __global__ __launch_bounds__(256) void k_es_pack(const DevImage *__restrict__ im
 		}
 	}
 	uint32_t l1 = 0;
+	/* quantisers that fit a byte (every 8-bit DQT) and no escaped block among the wavefront's: |(short)(c * q)| = |c| * q exactly (|c| <= 128,
+	 * q <= 255: the product cannot wrap), so the sum is sixteen v_dot4_u32_u8 of per-byte absolute values -- |c| = (c ^ m) + s with s the sign
+	 * bits and m = 255 * s -- instead of sixty-three sign-extend / multiply / abs / add steps (round 3: 0.54 -> 0.?? ms per 256 pictures) */
+	uint32_t qhigh = 0;
 #pragma unroll
-	for (int P = 1; P < 64; ++P) { /* position 0 is the DC's place */
-		const int lo8 = (int)(int8_t)((out[P >> 2] >> (8 * (P & 3))) & 255u), hi8 = (int)(int8_t)((hi[P >> 2] >> (8 * (P & 3))) & 255u);
-		const uint32_t q = (dq[P >> 1] >> (16 * (P & 1))) & 0xffffu;
-		const int v = (int)(int16_t)((uint32_t)(lo8 + 256 * hi8) * q);
-		l1 += (uint32_t)(v < 0 ? -v : v);
+	for (int i = 0; i < 32; ++i)
+		qhigh |= dq[i];
+	if ((qhigh & 0xff00ff00u) == 0u && __builtin_amdgcn_ballot_w64(esc) == 0ull) { /* wave-uniform */
+#pragma unroll
+		for (int i = 0; i < 16; ++i) {
+			const uint32_t w = i == 0 ? (out[0] & 0xffffff00u) : out[i]; /* position 0 is the DC's place (the flags byte) */
+			const uint32_t sg = (w >> 7) & 0x01010101u, m = (sg << 8) - sg;
+			const uint32_t a = (w ^ m) + sg;
+			const uint32_t q4 = (dq[2 * i] & 0xffu) | ((dq[2 * i] >> 8) & 0xff00u) | ((dq[2 * i + 1] & 0xffu) << 16) | ((dq[2 * i + 1] >> 16) << 24);
+			l1 = __builtin_amdgcn_udot4(a, q4, l1, false);
+		}
+	} else {
+#pragma unroll
+		for (int P = 1; P < 64; ++P) { /* position 0 is the DC's place */
+			const int lo8 = (int)(int8_t)((out[P >> 2] >> (8 * (P & 3))) & 255u), hi8 = (int)(int8_t)((hi[P >> 2] >> (8 * (P & 3))) & 255u);
+			const uint32_t q = (dq[P >> 1] >> (16 * (P & 1))) & 0xffffu;
+			const int v = (int)(int16_t)((uint32_t)(lo8 + 256 * hi8) * q);
+			l1 += (uint32_t)(v < 0 ? -v : v);
+		}
 	}
 	reinterpret_cast<uint32_t *>(meta + im.es_blk_off + ord)[0] = l1;
 }
