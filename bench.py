@@ -8,16 +8,17 @@ A *step* is one pass of the GPU hot path -- de-quantise + 8x8 integer IDCT + h2v
 YCbCr->RGB, i.e. everything the reference does between the Huffman walk and the pixel buffer
 (codec/jpeg.c:325-365 dequant, :615-679, :1816-1840, :1976-2018, :2301-2432) -- over the rank's batch of
 synthetic 1920x1080 4:2:0 q=90 JPEGs whose quantised coefficients are ALREADY RESIDENT IN HBM when the
-timed region starts (host Huffman walk + H2D + the device-side pack happen before it; see DESIGN.md for
-the PCIe/host-inclusive rates, which are never `value`).
+timed region starts (host Huffman walk + H2D happen before it -- since round 3 nothing else: the walk writes the
+planes in the format the kernel reads, legs.prepass; see DESIGN.md for the PCIe/host-inclusive rates, which are
+never `value`).
 
 Workload.  N = 1: BASELINE configs[1], 1024 images on the one GPU.  N > 1: BASELINE configs[2], ONE logical
 batch of 4096 images cut into contiguous slices with image-codecs_amd/sharding.shard_range -- rank r owns
 images [lo, hi) -- and no data-path collective: images are independent (decoder state is per image,
 codec/jpeg.c:2445).  Every slot has its own coefficient and pixel memory (>= 6 GB per GPU >> the 256 MiB
 Infinity Cache).  The planes are in the library's DEFAULT format -- compact planes with escape bytes
-(include/mij.h) -- produced here by the north-star pipeline: host Huffman walk -> int16 staging -> H2D ->
-k_pack_c8.  No environment knob is involved.  Every owned image is verified before the timed region: the
+(include/mij.h) -- produced here by the north-star pipeline: host Huffman walk -> compact planes in pinned
+staging (mjh_decode_memory_fmt) -> H2D.  No environment knob is involved.  Every owned image is verified before the timed region: the
 distinct sources by hash against the int16 pipeline (and, on rank 0 at N = 1, byte for byte against the
 reference itself in the cpu_baseline leg), every further image by a device-side comparison with its source.
 
@@ -25,7 +26,15 @@ reference itself in the cpu_baseline leg), every further image by a device-side 
 12 487 680 B per image); `roofline.traffic` / `hbm_counter_frac` are what the HBM counters saw (fewer bytes:
 compact planes), from the rocprofv3 --pmc passes committed under profiles/ (tools/profile.sh).
 
+`roofline.idct_wavefront_classes` (and the same per decode leg): fraction of the launch's IDCT wavefronts that took the DC-only /
+2x2 / 4x4 / full transform, counted by one extra untimed launch (mij_batch_count_idct_classes).
+
+N > 1 additionally: every rank runs the end-to-end GPU-walk ring on its slice at the same time with its share of the host
+cores (`end_to_end.per_rank` + aggregate), rank 0 times the CPU baseline; control plane on gloo (--control-plane nccl for RCCL).
+
 The one JSON line (rank 0) also carries, all OUTSIDE the timed region and only at N = 1:
+  legs.prepass          what stands between the host walk and the fused kernel over 1024 DISTINCT slots: nothing for compact
+                        staging; H2D into a scratch + k_pack_c8 (timed alone) for int16 staging; frac_including_pack
   legs.int16_planes     the same kernel family on int16 tile-layout planes
   legs.harsh_batch      1024 images of a harsher declared content (noise&63 + 24 inverted rectangles per image,
                         image-codecs_amd/synth.synth_rgb_edges): escaped blocks in most wavefronts
@@ -35,7 +44,8 @@ The one JSON line (rank 0) also carries, all OUTSIDE the timed region and only a
   legs.h2v1             512 x 1080p 4:2:2 (k_fused422), 7 B/px
   legs.config1          BASELINE configs[0]: one 512x512 4:2:0 JPEG per stbi_load_from_memory call (latency of the drop-in call)
   legs.two_pass         256 x 1080p through the two-pass family (sample planes in HBM, pass 2 compiled per resampler):
-                        the headline images forced off the fused kernel, 4:4:0 and Adobe CMYK
+                        the headline images forced off the fused kernel, 4:4:0 fused and forced, Adobe CMYK through
+                        k_fused1x1c and forced
   end_to_end            bitstream in host RAM -> pixels in HBM (host walk; GPU walk), never `value`
   cpu_baseline          the reference itself (oracle/_ref, compiled in place in the build container and shipped
                         as a .so; "reference") -- or, when that .so is absent (clean checkout), our CPU
