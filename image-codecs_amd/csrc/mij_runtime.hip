@@ -58,14 +58,15 @@ struct mij_ctx {
 	/* pinned bounce buffer of the one-slot fetches (d2h_bounced) */
 	std::mutex bounce_lock;
 	uint8_t *bounce = nullptr;
+	hipEvent_t bounce_ev[2] = {nullptr, nullptr};
 };
 static const size_t MIJ_BOUNCE_BYTES = (size_t)8 << 20;
 
 /* Device -> caller-owned host memory for the one-slot fetches (mij_batch_fetch, mij_enc_fetch, mij_batch_fetch_coef).  The caller's
  * buffer is ordinary pageable memory, often never touched before; handing it to hipMemcpyAsync makes the runtime pin, DMA into and
  * unpin pages this library does not own (or stage through a path shared by every stream of the process).  The
- * copy therefore lands in a pinned buffer of the context, 8 MiB at a time, and the calling thread copies it out after the stream
- * has drained: the DMA engine only ever writes memory the library allocated with hipHostMalloc.  (Round 3: the one input of the
+ * copy therefore lands in a pinned buffer of the context, 8 MiB at a time (two halves: the next chunk's DMA runs while the calling thread
+ * copies this one out): the DMA engine only ever writes memory the library allocated with hipHostMalloc.  (Round 3: the one input of the
  * twice-seen encoder-leg mismatch that was not a pure function of its arguments was a DMA into a fresh numpy buffer, DESIGN.md
  * section 8.)  Throughput paths do not come here: they copy whole arenas into pinned memory the caller got from mij_host_alloc. */
 static int d2h_bounced(mij_ctx *ctx, hipStream_t st, void *dst, const void *src_dev, size_t bytes);
@@ -138,6 +139,9 @@ extern "C" void mij_ctx_destroy(mij_ctx *ctx)
 	if (ctx->bounce) {
 		(void)hipSetDevice(ctx->device);
 		(void)hipHostFree(ctx->bounce);
+		for (int i = 0; i < 2; ++i)
+			if (ctx->bounce_ev[i])
+				(void)hipEventDestroy(ctx->bounce_ev[i]);
 	}
 	delete ctx;
 }
@@ -145,16 +149,29 @@ extern "C" void mij_ctx_destroy(mij_ctx *ctx)
 static int d2h_bounced(mij_ctx *ctx, hipStream_t st, void *dst, const void *src_dev, size_t bytes)
 {
 	std::lock_guard<std::mutex> guard(ctx->bounce_lock);
-	if (!ctx->bounce)
-		HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->bounce), MIJ_BOUNCE_BYTES, hipHostMallocDefault));
-	for (size_t off = 0; off < bytes; off += MIJ_BOUNCE_BYTES) {
-		const size_t n = bytes - off < MIJ_BOUNCE_BYTES ? bytes - off : MIJ_BOUNCE_BYTES;
-		HIP_TRY(hipMemcpyAsync(ctx->bounce, static_cast<const uint8_t *>(src_dev) + off, n, hipMemcpyDeviceToHost, st));
-		HIP_TRY(hipStreamSynchronize(st));
-		memcpy(static_cast<uint8_t *>(dst) + off, ctx->bounce, n);
+	if (!ctx->bounce) {
+		HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->bounce), 2 * MIJ_BOUNCE_BYTES, hipHostMallocDefault));
+		HIP_TRY(hipEventCreateWithFlags(&ctx->bounce_ev[0], hipEventDisableTiming));
+		HIP_TRY(hipEventCreateWithFlags(&ctx->bounce_ev[1], hipEventDisableTiming));
 	}
-	if (!bytes)
+	if (!bytes) {
 		HIP_TRY(hipStreamSynchronize(st));
+		return MIJ_OK;
+	}
+	/* two halves: the DMA of chunk k+1 runs while the calling thread copies chunk k out (a 4096 x 4096 picture is seven chunks) */
+	const size_t nchunk = (bytes + MIJ_BOUNCE_BYTES - 1) / MIJ_BOUNCE_BYTES;
+	for (size_t k = 0; k <= nchunk; ++k) {
+		if (k < nchunk) {
+			const size_t off = k * MIJ_BOUNCE_BYTES, n = bytes - off < MIJ_BOUNCE_BYTES ? bytes - off : MIJ_BOUNCE_BYTES;
+			HIP_TRY(hipMemcpyAsync(ctx->bounce + (k & 1) * MIJ_BOUNCE_BYTES, static_cast<const uint8_t *>(src_dev) + off, n, hipMemcpyDeviceToHost, st));
+			HIP_TRY(hipEventRecord(ctx->bounce_ev[k & 1], st));
+		}
+		if (k > 0) {
+			const size_t off = (k - 1) * MIJ_BOUNCE_BYTES, n = bytes - off < MIJ_BOUNCE_BYTES ? bytes - off : MIJ_BOUNCE_BYTES;
+			HIP_TRY(hipEventSynchronize(ctx->bounce_ev[(k - 1) & 1]));
+			memcpy(static_cast<uint8_t *>(dst) + off, ctx->bounce + ((k - 1) & 1) * MIJ_BOUNCE_BYTES, n);
+		}
+	}
 	return MIJ_OK;
 }
 extern "C" int mij_ctx_device(const mij_ctx *ctx) { return ctx ? ctx->device : -1; }
