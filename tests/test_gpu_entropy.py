@@ -389,3 +389,26 @@ def test_gpu_walk_subsequence_lengths(ica, oracle, gpu_ctx, golden, monkeypatch,
     monkeypatch.setenv("MIJ_GPU_WALK_MIN_PIXELS", "0")
     for d in datas[:4]:
         assert np.array_equal(ica.stbi_load_from_memory(d, 3)[0], oracle.load(d, 3)[1])
+
+
+def test_default_front_end_twice_without_a_reset(ica, oracle, gpu_ctx, golden):
+    """mjh_decode_batch on a batch that already holds the pictures of an earlier call.  The GPU walk's finish step looks at
+    every scan of the arena, and only the current call's slots have an owner there: the second call therefore extends the batch through
+    the host walk.  Both calls' pictures -- some of which the GPU walk hands back, one of which is rejected -- come out right, and the
+    explicit two-half entry on such a batch fails cleanly instead of indexing with an unowned slot."""
+    first = [ica.synth_jpeg(320, 200, 1), golden.jpg("prog_420_64x64"), ica.synth_jpeg(1024, 768, 2), golden.jpg("garbage")]
+    second = [ica.synth_jpeg(640, 480, 3, quality=95), ica.synth_jpeg(64, 64, 4), golden.jpg("grey_33x20")]
+    b = ica.Batch(gpu_ctx, 16, 64 << 20, 64 << 20, 64 << 20)
+    ok1, s1, r1 = b.decode_jpegs(first, 3, threads=3)           # default front end: GPU walk where it applies
+    ok2, s2, r2 = b.decode_jpegs(second, 3, threads=3)          # no reset in between
+    assert ok1 == 3 and ok2 == 3, (r1, r2)
+    b.submit()
+    b.wait()
+    for datas, slots in ((first, s1), (second, s2)):
+        for d, s in zip(datas, slots):
+            kind, want, _ = oracle.load(d, 3)
+            if kind != "ok":
+                assert s < 0
+            else:
+                assert np.array_equal(b.fetch(s), want)
+    b.close()
