@@ -242,6 +242,29 @@ static void build_fast_ac(int16_t *fac, const mjh_huff *h)
 	}
 }
 
+/* The symbols of an AC refinement scan are (run, size 1) followed by one sign bit, ZRL and EOB runs (codec/jpeg.c:507-545).  For the 9-bit
+ * window i: when the code in front is one of "(r, 1) + its sign bit inside the window", "ZRL" or "EOB0" the entry is
+ *     length taken (code, plus the sign bit) | r << 4 | kind << 8 | sign << 10     kind 1 = coefficient, 2 = ZRL, 3 = EOB0; 0 = not here
+ * so that the refinement loop needs one lookup where huff_decode_r + get_bit_r take four dependent ones.  Anything else (long codes, EOB
+ * runs with extra bits, sizes other than 1 -- which the reference rejects) leaves the entry 0 and goes the ordinary way. */
+static void build_fast_refine(uint16_t *fr, const mjh_huff *h)
+{
+	int i;
+	for (i = 0; i < (1 << MJH_FAST_BITS); ++i) {
+		const int sym = h->fast[i];
+		fr[i] = 0;
+		if (sym < 255) {
+			const int rs = h->values[sym], r = (rs >> 4) & 15, s = rs & 15, len = h->size[sym];
+			if (s == 1 && len + 1 <= MJH_FAST_BITS)
+				fr[i] = (uint16_t)((len + 1) | (r << 4) | (1 << 8) | (((i >> (MJH_FAST_BITS - 1 - len)) & 1) << 10));
+			else if (s == 0 && r == 15)
+				fr[i] = (uint16_t)(len | (15 << 4) | (2 << 8));
+			else if (s == 0 && r == 0)
+				fr[i] = (uint16_t)(len | (3 << 8));
+		}
+	}
+}
+
 /* ------------------------------------------------------------------ bit reader */
 
 static const uint32_t k_bmask[17] = {0, 1, 3, 7, 15, 31, 63, 127, 255, 511, 1023, 2047, 4095, 8191, 16383, 32767, 65535};
@@ -658,7 +681,7 @@ static inline uint64_t block_nonzero_mask(const int16_t *blk)
 static inline uint64_t band_mask(int lo, int hi) { return (hi >= 63 ? ~0ull : ((1ull << (hi + 1)) - 1)) & ~((1ull << lo) - 1); }
 
 /* codec/jpeg.c:406-558 */
-static int decode_block_prog_ac(mjh_decoder *d, int16_t *blk, const mjh_huff *hac, const int16_t *fac)
+static int decode_block_prog_ac(mjh_decoder *d, int16_t *blk, const mjh_huff *hac, const int16_t *fac, const uint16_t *fref)
 {
 	const int spec_end = d->spec_end;
 	int k;
@@ -730,6 +753,23 @@ static int decode_block_prog_ac(mjh_decoder *d, int16_t *blk, const mjh_huff *ha
 			k = d->spec_start;
 			do {
 				int r, s;
+				unsigned e;
+				if (b.bits < 16) /* where huff_decode_r refills */
+					reg_grow(d, &b);
+				e = fref[b.buf >> (32 - MJH_FAST_BITS)];
+				if (e && (int)(e & 15u) <= b.bits) { /* the code and, for a coefficient, its sign bit in one step (build_fast_refine) */
+					const int len = (int)(e & 15u), kind = (int)(e >> 8) & 3;
+					b.buf <<= len;
+					b.bits -= len;
+					r = (int)(e >> 4) & 15;
+					s = 0;
+					if (kind == 1)
+						s = (e & 0x400u) ? bit : -bit;
+					else if (kind == 3) {
+						d->eob_run = 0;
+						r = 64; /* run to the end of the band */
+					}
+				} else {
 				int rs = huff_decode_r(d, hac, &b);
 				if (rs < 0) {
 					reg_store(d, &b);
@@ -751,6 +791,7 @@ static int decode_block_prog_ac(mjh_decoder *d, int16_t *blk, const mjh_huff *ha
 						return fail(d, "bad huffman code");
 					}
 					s = get_bit_r(d, &b) ? bit : -bit;
+				}
 				}
 				/* skip r zero-history coefficients, refining the non-zero ones passed on the way, then put
 				 * s into the next zero one */
@@ -871,7 +912,7 @@ static int parse_entropy_coded_data(mjh_decoder *d)
 						if (!decode_block_prog_dc(d, blk, &d->huff_dc[cp->hd], cp))
 							return 0;
 					} else {
-						if (!decode_block_prog_ac(d, blk, &d->huff_ac[cp->ha], d->fast_ac[cp->ha]))
+						if (!decode_block_prog_ac(d, blk, &d->huff_ac[cp->ha], d->fast_ac[cp->ha], d->fast_refine[cp->ha]))
 							return 0;
 					}
 					if (restart_check(d))
@@ -967,8 +1008,10 @@ static int process_marker(mjh_decoder *d, unsigned m)
 				return 0;
 			for (i = 0; i < n; ++i)
 				h->values[i] = (uint8_t)rd8(r);
-			if (tc != 0)
+			if (tc != 0) {
 				build_fast_ac(d->fast_ac[th], h);
+				build_fast_refine(d->fast_refine[th], h);
+			}
 			L -= n;
 		}
 		return L == 0;

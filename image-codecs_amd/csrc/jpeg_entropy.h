@@ -74,6 +74,8 @@ typedef struct {
 	mjh_huff huff_dc[4], huff_ac[4];
 	uint16_t dequant[4][64]; /* natural order (codec/jpeg.c:1376) */
 	int16_t fast_ac[4][1 << MJH_FAST_BITS];
+	/* AC refinement scans (codec/jpeg.c:478-545): code + the sign bit that follows it in one lookup (build_fast_refine); progressive files only */
+	uint16_t fast_refine[4][1 << MJH_FAST_BITS];
 
 	int img_x, img_y, img_n;
 	int h_max, v_max, mcu_x, mcu_y, mcu_w, mcu_h;

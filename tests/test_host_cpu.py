@@ -375,3 +375,36 @@ def test_host_writer_vs_live_reference_seeded(ica):
         else:
             img = np.clip(np.linspace(0, 255, w)[None, :, None] + rng.normal(0, 30, (h, w, c)), 0, 255).astype(np.uint8)
         assert ica.stbi_write_jpg_to_memory(img, q) == ref.encode(img, q), (w, h, c, q, i % 3)
+
+
+def test_progressive_host_walk_vs_oracle_fuzz(golden, ica, oracle):
+    """Progressive streams (DC / AC first and refinement scans, EOB runs, both scan scripts of the test-side writer, the reference-made
+    PIL goldens), intact and with mutated entropy data: the product's host walk -- whose refinement scans take a combined code + sign-bit
+    table since round 3 (build_fast_refine) -- and the oracle agree on accept / reject, on the failure reason and on every de-quantised
+    coefficient.  Where the reference itself is available the oracle's verdict is compared with it on the way."""
+    rng = np.random.default_rng(23)
+    bases = [golden.jpg(n) for n in golden.names if n.startswith("prog")]
+    for (w, h, q, script, kind) in ((97, 51, 95, 1, "noise"), (64, 64, 92, 2, "noise"), (120, 88, 100, 1, "noise"), (200, 120, 95, 2, "synth"), (33, 17, 91, 1, "synth")):
+        img = rng.integers(0, 256, (h, w, 3)).astype(np.uint8) if kind == "noise" else ica.synth_rgb(w, h, w)
+        plan, du = ica.host_transform(img, q)
+        bases.append(helpers.progressive_from_du(plan, du, script))
+    ref = helpers.Reference() if helpers.Reference.available() else None
+    n_ok = n_fail = 0
+    for bi, base in enumerate(bases):
+        for seed in range(-1, 30):
+            data = base if seed < 0 else helpers.mutate(base, seed * 7919 + bi, n_mut=1 + seed % 4, allow_markers=(seed % 5 == 0))
+            o = oracle.load(data, 0)
+            if ref is not None:
+                r = ref.load(data, 0)
+                assert r[0] == o[0] and (r[0] == "fail" and r[1] == o[1] or r[0] == "ok"), (bi, seed, r[:2] if r[0] == "fail" else "ok", o[:2] if o[0] == "fail" else "ok")
+            if o[0] == "fail":
+                with pytest.raises(ica.MijError) as e:
+                    ica.HostDecoder.decode(data, 0)
+                assert str(e.value) == o[1], (bi, seed)
+                n_fail += 1
+            else:
+                desc, arena = ica.HostDecoder.decode(data, 0)
+                got = _dequantised_in_call_order(ica, desc, arena, progressive_order=True)
+                assert np.array_equal(got, oracle.coef(data)), (bi, seed)
+                n_ok += 1
+    assert n_ok > 150 and n_fail > 3, (n_ok, n_fail)
