@@ -247,14 +247,24 @@ static unsigned char *load_gpu_walk(mij_ctx *ctx, const uint8_t *buf, int len, i
 	slot = mij_batch_add_stream(b, scan, stage, slen);
 	if (slot < 0)
 		goto out;
-	if (mij_batch_entropy_run(b, fb, 1, &nfb) != MIJ_OK || nfb != 0)
-		goto out;
 	nbytes = (size_t)scan->desc.n_out * (size_t)scan->desc.width * (size_t)scan->desc.height;
 	if (nbytes > 0x7fffffffu - 1)
 		goto out;
-	pixels = (unsigned char *)malloc(nbytes + 1); /* codec/jpeg.c:2293: n * x * y + 1 bytes */
-	if (!pixels)
+	if (mij_batch_entropy_launch(b) != MIJ_OK)
 		goto out;
+	/* while the GPU walks: the caller's pixel block, and its pages touched once -- a fresh 50 MB block costs 12 000 page faults, which
+	 * otherwise land in the copy-out at the end of the call (round 3: the pixels are copied out of a pinned buffer, not DMA'd in) */
+	pixels = (unsigned char *)malloc(nbytes + 1); /* codec/jpeg.c:2293: n * x * y + 1 bytes */
+	if (pixels && nbytes >= ((size_t)1 << 20)) {
+		size_t i;
+		for (i = 0; i < nbytes; i += 4096)
+			pixels[i] = 0;
+	}
+	if (mij_batch_entropy_finish(b, fb, 1, &nfb) != MIJ_OK || nfb != 0 || !pixels) {
+		free(pixels);
+		pixels = NULL;
+		goto out;
+	}
 	if (mij_batch_submit(b) != MIJ_OK || fetch_pixels(b, slot, pixels, nbytes) != MIJ_OK) {
 		free(pixels);
 		pixels = NULL;
