@@ -161,6 +161,7 @@ static uint16_t k_tile_off[64 + 15];
 static uint8_t k_pos_of_zig[64 + 15]; /* zigzag index -> in-block position P = 8*column + slot (the escape bytes' order) */
 static uint8_t k_zig_of_pos[64]; /* in-tile position P = 8*chunk + slot -> zigzag index */
 static int k_tile_off_ready;
+static int k_have_pdep; /* the CPU has BMI2 pdep and popcnt at full speed: the refinement scans take their correction bits a run at a time */
 static void init_zig_masks(void);
 
 static void init_tile_off(void)
@@ -177,10 +178,35 @@ static void init_tile_off(void)
 			k_zig_of_pos[P] = (uint8_t)k;
 	}
 	init_zig_masks();
+	__builtin_cpu_init();
+	/* pdep is microcoded (hundreds of cycles) before Zen 3; MIJ_NO_PDEP=1 forces the bit-at-a-time loop (tests compare the two) */
+	k_have_pdep = __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("popcnt") && !__builtin_cpu_is("znver1") && !__builtin_cpu_is("znver2") &&
+					  !(getenv("MIJ_NO_PDEP") && getenv("MIJ_NO_PDEP")[0] == '1');
 	k_tile_off_ready = 1;
 }
 
 static inline size_t block_base(int L) { return ((size_t)(L >> 6) << 12) + ((size_t)(L & 63) << 3); }
+
+/* A progressive scan walks a plane of tens of megabytes block after block; a block is eight 16-byte rows 1 KiB apart, four neighbouring blocks
+ * share their cache lines.  Every fourth block asks for the lines the same blocks of the tile MJH_PREFETCH_TILES further on will need.
+ * (Touching memory behind the plane's end is harmless: prefetches never fault.) */
+#ifndef MJH_PREFETCH_TILES
+#define MJH_PREFETCH_TILES 1
+#endif
+static inline void prefetch_tile_ahead(const int16_t *blk, int L)
+{
+#if MJH_PREFETCH_TILES
+	if (!(L & 3)) {
+		const char *p = (const char *)(blk + 4096 * MJH_PREFETCH_TILES);
+		int c;
+		for (c = 0; c < 8; ++c)
+			_mm_prefetch(p + 1024 * c, _MM_HINT_T0);
+	}
+#else
+	(void)blk;
+	(void)L;
+#endif
+}
 
 /* codec/jpeg.c:88-134 */
 static int build_huffman(mjh_decoder *d, mjh_huff *h, const int *count)
@@ -406,6 +432,33 @@ static inline int extend_receive_r(mjh_decoder *d, int n, bitreg *b)
 	k &= k_bmask[n];
 	b->bits -= n;
 	return (int)k + (k_bias[n] & ~sgn);
+}
+
+/* reg_grow on a bit register held in two plain locals (the AC refinement loop: through the bitreg struct the compiler keeps the register
+ * in memory there.  The baseline block loops were tried this way too and came out 8 % SLOWER than with the struct and huff_decode_r out
+ * of line -- measured, 1080p q=90, so they stay as they are). */
+static inline __attribute__((always_inline)) void grow_s(mjh_decoder *d, uint32_t *buf, int *bits)
+{
+	mjh_reader *r = d->r;
+	if (!d->nomore && (unsigned)*bits <= 24 && r->end - r->p >= 4) {
+		uint32_t w, keep, y;
+		const int n = (32 - *bits) >> 3;
+		memcpy(&w, r->p, 4);
+		w = __builtin_bswap32(w);
+		keep = w & (0xffffffffu << (32 - 8 * n));
+		y = ~keep;
+		if (!((y - 0x01010101u) & ~y & 0x80808080u)) {
+			*buf |= keep >> *bits;
+			*bits += 8 * n;
+			r->p += n;
+			return;
+		}
+	}
+	d->code_buffer = *buf;
+	d->code_bits = *bits;
+	bits_grow(d);
+	*buf = d->code_buffer;
+	*bits = d->code_bits;
 }
 
 /* ------------------------------------------------------------------ block decoders */
@@ -680,6 +733,172 @@ static inline uint64_t block_nonzero_mask(const int16_t *blk)
 
 static inline uint64_t band_mask(int lo, int hi) { return (hi >= 63 ? ~0ull : ((1ull << (hi + 1)) - 1)) & ~((1ull << lo) - 1); }
 
+/* pdep / popcnt through inline assembly: the library is built for plain x86-64 and executes these only where init_tile_off found them */
+static inline uint64_t pdep64(uint64_t src, uint64_t mask)
+{
+	uint64_t r;
+	__asm__("pdep %2, %1, %0" : "=r"(r) : "r"(src), "r"(mask));
+	return r;
+}
+static inline int popcnt64(uint64_t x)
+{
+	uint64_t r;
+	__asm__("popcnt %1, %0" : "=r"(r) : "r"(x) : "cc");
+	return (int)r;
+}
+static inline uint64_t bitrev64(uint64_t x)
+{
+	x = __builtin_bswap64(x);
+	x = ((x & 0x0f0f0f0f0f0f0f0full) << 4) | ((x >> 4) & 0x0f0f0f0f0f0f0f0full);
+	x = ((x & 0x3333333333333333ull) << 2) | ((x >> 2) & 0x3333333333333333ull);
+	x = ((x & 0x5555555555555555ull) << 1) | ((x >> 1) & 0x5555555555555555ull);
+	return x;
+}
+
+/* The correction bits of the already non-zero coefficients `where` (a zigzag-order mask, not empty), which the reference reads one
+ * get_bit per coefficient in ascending order (codec/jpeg.c:497-505, :536-553): all of them in one or a few reads, the first bit read
+ * deposited at the lowest position.  Returns the mask of the coefficients whose bit was set.  The bit register is a first-in-first-out
+ * of the stream's bits followed by zeros once the data has run out, so reading n bits at once returns what n single reads return. */
+static inline uint64_t read_corrections(mjh_decoder *d, uint64_t where, bitreg *b)
+{
+	const int n = popcnt64(where);
+	uint64_t bits = 0;
+	int left = n;
+	if (n == 1)
+		return get_bit_r(d, b) ? where : 0;
+	while (left > 16) {
+		bits = (bits << 16) | (uint64_t)get_bits_r(d, 16, b);
+		left -= 16;
+	}
+	bits = (bits << left) | (uint64_t)get_bits_r(d, left, b);
+	return pdep64(bitrev64(bits) >> (64 - n), where);
+}
+
+/* codec/jpeg.c:499-504 for every coefficient of `corr` */
+static inline void apply_corrections(int16_t *blk, uint64_t corr, int bit)
+{
+	while (corr) {
+		int16_t *p = &blk[k_tile_off[__builtin_ctzll(corr)]];
+		const int v = *p; /* not zero: the mask was made from the block */
+		const int sgn = v >> 31;
+		const int delta = (bit ^ sgn) - sgn; /* v > 0: +bit, v < 0: -bit */
+		*p = (int16_t)(v + ((v & bit) == 0 ? delta : 0));
+		corr &= corr - 1;
+	}
+}
+
+/* A symbol of an AC refinement scan that is not in the one-lookup table (a long code, an EOB run with extra bits, a size the reference
+ * rejects): codec/jpeg.c:507-533 on the decoder's own bit register.  Returns the run (64: to the end of the band) | what the symbol
+ * puts there (1: +bit, 2: -bit, 0: nothing) << 8, or -1 for a bad code. */
+static __attribute__((noinline)) int refine_symbol_slow(mjh_decoder *d, const mjh_huff *hac)
+{
+	bitreg b = reg_load(d);
+	int rs = huff_decode_r(d, hac, &b), r, s;
+	if (rs < 0) {
+		reg_store(d, &b);
+		(void)fail(d, "bad huffman code");
+		return -1;
+	}
+	s = rs & 15;
+	r = rs >> 4;
+	if (s == 0) {
+		if (r < 15) {
+			d->eob_run = (1 << r) - 1;
+			if (r)
+				d->eob_run += get_bits_r(d, r, &b);
+			r = 64; /* run to the end of the band */
+		}
+		/* r == 15: sixteen zeros, a run with s = 0 */
+	} else {
+		if (s != 1) {
+			reg_store(d, &b);
+			(void)fail(d, "bad huffman code");
+			return -1;
+		}
+		s = get_bit_r(d, &b) ? 1 : 2;
+	}
+	reg_store(d, &b);
+	return r | (s << 8);
+}
+
+/* The symbols of one block of an AC refinement scan (codec/jpeg.c:507-553) where the CPU has pdep: the target of a run is a select on the
+ * zero map, the correction bits of the coefficients passed on the way come in one read.  The bit register is two plain locals here
+ * (through the bitreg struct the compiler kept it on the stack, a store-to-load round trip on the chain from one symbol to the next).
+ * Returns 0 on a bad code (d->reason set); *corr_out = the coefficients whose correction bit was set.  (Tried and dropped: topping the bit
+ * register up at every symbol instead of when it runs low, and reading the correction bits without a branch -- both slower, the loop is
+ * bound by its instruction count, not by mispredicted branches.) */
+static __attribute__((noinline)) int refine_symbols_wide(mjh_decoder *d, int16_t *blk, const mjh_huff *hac, const uint16_t *fref, uint64_t nz, uint64_t zero, int bit, uint64_t *corr_out)
+{
+	const int spec_end = d->spec_end;
+	uint32_t buf = d->code_buffer;
+	int bits = d->code_bits;
+	uint64_t corr = 0;
+	int k = d->spec_start;
+	do {
+		int r, s;
+		unsigned e;
+		if (bits < 16) /* where huff_decode_r refills */
+			grow_s(d, &buf, &bits);
+		e = fref[buf >> (32 - MJH_FAST_BITS)];
+		if (e && (int)(e & 15u) <= bits) { /* the code and, for a coefficient, its sign bit in one step (build_fast_refine) */
+			const int len = (int)(e & 15u), kind = (int)(e >> 8) & 3;
+			const int sv = (e & 0x400u) ? bit : -bit;
+			buf <<= len;
+			bits -= len;
+			r = kind == 3 ? 64 : (int)(e >> 4) & 15; /* EOB0 (the run count stays 0): to the end of the band */
+			s = kind == 1 ? sv : 0;
+		} else {
+			int rs;
+			d->code_buffer = buf;
+			d->code_bits = bits;
+			rs = refine_symbol_slow(d, hac);
+			if (rs < 0)
+				return 0;
+			r = rs & 255;
+			s = (rs >> 8) == 1 ? bit : ((rs >> 8) == 2 ? -bit : 0);
+			buf = d->code_buffer;
+			bits = d->code_bits;
+		}
+		{
+			/* skip r zero-history coefficients, refining the non-zero ones passed on the way, then put s into the next zero one */
+			const uint64_t from = ~0ull << k; /* k <= spec_end <= 63 */
+			const uint64_t hit = pdep64(r < 64 ? 1ull << r : 0, zero & from); /* the (r+1)-th zero-history position from k on, if the band has one */
+			uint64_t passed = nz & from;
+			if (hit) {
+				const int t = __builtin_ctzll(hit);
+				passed &= hit - 1;
+				blk[k_tile_off[t]] = (int16_t)s;
+				k = t + 1;
+			} else /* the run leaves the band: everything up to its end is refined, s is dropped (:536-553 ends the same way) */
+				k = spec_end + 1;
+			if (passed) {
+				/* read_corrections on the locals: the first bit read belongs to the lowest coefficient */
+				int n = popcnt64(passed);
+				uint64_t v = 0;
+				while (n > 16) {
+					if (bits < 16)
+						grow_s(d, &buf, &bits);
+					v = (v << 16) | (buf >> 16);
+					buf <<= 16;
+					bits -= 16;
+					n -= 16;
+				}
+				if (bits < n)
+					grow_s(d, &buf, &bits);
+				v = (v << n) | (uint64_t)(((uint64_t)buf << n) >> 32);
+				buf <<= n;
+				bits -= n;
+				n = popcnt64(passed);
+				corr |= pdep64(bitrev64(v) >> (64 - n), passed);
+			}
+		}
+	} while (k <= spec_end);
+	d->code_buffer = buf;
+	d->code_bits = bits;
+	*corr_out = corr;
+	return 1;
+}
+
 /* codec/jpeg.c:406-558 */
 static int decode_block_prog_ac(mjh_decoder *d, int16_t *blk, const mjh_huff *hac, const int16_t *fac, const uint16_t *fref)
 {
@@ -740,8 +959,28 @@ static int decode_block_prog_ac(mjh_decoder *d, int16_t *blk, const mjh_huff *ha
 		/* bit k set <=> coefficient k (zigzag order) of this block is already non-zero.  The reference
 		 * walks all positions of the band and tests each (codec/jpeg.c:497-505, :536-553); visiting only
 		 * the set bits, in the same ascending order, reads the same correction bits for the same
-		 * coefficients.  Coefficients placed by this call lie behind the walk and are never revisited. */
-		uint64_t nz = block_nonzero_mask(blk) & band_mask(d->spec_start, spec_end);
+		 * coefficients.  Coefficients placed by this call lie behind the walk and are never revisited.
+		 * Where the CPU has pdep (k_have_pdep) the walk is not a walk at all: the target of a run of r zero-history coefficients is
+		 * the (r+1)-th set bit of the zero map, the non-zero ones passed on the way are a mask, their correction bits are read together
+		 * (read_corrections) and applied once the block's symbols are through -- corrections touch history coefficients, placements
+		 * zero-history ones, so the order between them does not matter. */
+		const uint64_t band = band_mask(d->spec_start, spec_end);
+		uint64_t nz = block_nonzero_mask(blk) & band;
+		uint64_t corr = 0;
+		if (k_have_pdep) {
+			if (d->eob_run) {
+				--d->eob_run;
+				if (nz) {
+					b = reg_load(d);
+					corr = read_corrections(d, nz, &b);
+					reg_store(d, &b);
+				}
+			} else if (!refine_symbols_wide(d, blk, hac, fref, nz, ~nz & band, bit, &corr))
+				return 0;
+			if (corr)
+				apply_corrections(blk, corr, bit);
+			return 1;
+		}
 		b = reg_load(d);
 		if (d->eob_run) {
 			--d->eob_run;
@@ -770,28 +1009,28 @@ static int decode_block_prog_ac(mjh_decoder *d, int16_t *blk, const mjh_huff *ha
 						r = 64; /* run to the end of the band */
 					}
 				} else {
-				int rs = huff_decode_r(d, hac, &b);
-				if (rs < 0) {
-					reg_store(d, &b);
-					return fail(d, "bad huffman code");
-				}
-				s = rs & 15;
-				r = rs >> 4;
-				if (s == 0) {
-					if (r < 15) {
-						d->eob_run = (1 << r) - 1;
-						if (r)
-							d->eob_run += get_bits_r(d, r, &b);
-						r = 64; /* run to the end of the band */
-					}
-					/* r == 15: sixteen zeros, handled by the run below with s = 0 */
-				} else {
-					if (s != 1) {
+					int rs = huff_decode_r(d, hac, &b);
+					if (rs < 0) {
 						reg_store(d, &b);
 						return fail(d, "bad huffman code");
 					}
-					s = get_bit_r(d, &b) ? bit : -bit;
-				}
+					s = rs & 15;
+					r = rs >> 4;
+					if (s == 0) {
+						if (r < 15) {
+							d->eob_run = (1 << r) - 1;
+							if (r)
+								d->eob_run += get_bits_r(d, r, &b);
+							r = 64; /* run to the end of the band */
+						}
+						/* r == 15: sixteen zeros, handled by the run below with s = 0 */
+					} else {
+						if (s != 1) {
+							reg_store(d, &b);
+							return fail(d, "bad huffman code");
+						}
+						s = get_bit_r(d, &b) ? bit : -bit;
+					}
 				}
 				/* skip r zero-history coefficients, refining the non-zero ones passed on the way, then put
 				 * s into the next zero one */
@@ -908,6 +1147,7 @@ static int parse_entropy_coded_data(mjh_decoder *d)
 			for (j = 0; j < h; ++j)
 				for (i = 0; i < w; ++i) {
 					int16_t *blk = cp->plane + block_base(i + j * cp->bw);
+					prefetch_tile_ahead(blk, i + j * cp->bw);
 					if (d->spec_start == 0) {
 						if (!decode_block_prog_dc(d, blk, &d->huff_dc[cp->hd], cp))
 							return 0;

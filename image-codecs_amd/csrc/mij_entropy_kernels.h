@@ -49,6 +49,20 @@ namespace mij {
 #ifndef MIJ_ES_BITS_SINGLE
 #define MIJ_ES_BITS_SINGLE 1024u
 #endif
+/* Threads per workgroup of the passes that walk the stream (cold, sync, write, tails): one subsequence per thread.  The Huffman and pair
+ * tables take 28 KiB of LDS per workgroup whatever its size, so the workgroup size sets how many wavefronts a CU can hold (160 KiB: five
+ * workgroups): 256 threads = 5 waves per SIMD, 512 = 10 (then the registers decide). */
+#ifndef MIJ_ES_WG
+#define MIJ_ES_WG 256u
+#endif
+#ifndef MIJ_ES_WAVES /* A/B: waves per SIMD the compiler must leave room for (its register budget); 0 = its own choice */
+#define MIJ_ES_WAVES 0
+#endif
+#if MIJ_ES_WAVES
+#define MIJ_ES_KERNEL __global__ __launch_bounds__(MIJ_ES_WG) __attribute__((amdgpu_waves_per_eu(MIJ_ES_WAVES, MIJ_ES_WAVES)))
+#else
+#define MIJ_ES_KERNEL __global__ __launch_bounds__(MIJ_ES_WG)
+#endif
 #define MIJ_ES_DEAD 127u  /* z of a state whose decode hit an invalid code */
 
 struct DevHuff { /* stbi__huffman without the code[] array (codec/jpeg.c:21-32) */
@@ -486,7 +500,7 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &
 	return done;
 }
 
-/* every kernel below: grid.x = blocks of 256 subsequences over a (scan, first subsequence) work list */
+/* every kernel below: grid.x = blocks of MIJ_ES_WG subsequences over a (scan, first subsequence) work list */
 struct EsWork {
 	uint32_t scan, first;
 };
@@ -520,7 +534,8 @@ __device__ __forceinline__ void es_load_tables(const DevScan &sc, const DevImage
 			loc->hi[c] = cp.hi_off;
 		}
 	}
-	loc->qz[threadIdx.x >> 6][threadIdx.x & 63u] = sc.qz[threadIdx.x >> 6][threadIdx.x & 63u];
+	if (threadIdx.x < 256u)
+		loc->qz[threadIdx.x >> 6][threadIdx.x & 63u] = sc.qz[threadIdx.x >> 6][threadIdx.x & 63u];
 	__syncthreads();
 	if (pr) {
 		/* the (at most two) AC tables of the scan's components, in order of first use; a third one keeps the ordinary path */
@@ -563,7 +578,7 @@ __device__ __forceinline__ void es_load_tables(const DevScan &sc, const DevImage
 	}
 }
 
-__global__ __launch_bounds__(256) void k_es_cold(const DevScan *__restrict__ scans, const EsWork *__restrict__ work, const DevHuff *__restrict__ huff,
+MIJ_ES_KERNEL void k_es_cold(const DevScan *__restrict__ scans, const EsWork *__restrict__ work, const DevHuff *__restrict__ huff,
 																 const uint8_t *__restrict__ streams, uint64_t *__restrict__ start, uint64_t *__restrict__ end, uint32_t *__restrict__ cnt)
 {
 	__shared__ EsTab tabs[8];
@@ -586,7 +601,7 @@ __global__ __launch_bounds__(256) void k_es_cold(const DevScan *__restrict__ sca
 }
 
 /* one synchronisation round: end_in is the previous round's result, end_out this round's */
-__global__ __launch_bounds__(256) void k_es_sync(const DevScan *__restrict__ scans, const EsWork *__restrict__ work, const DevHuff *__restrict__ huff,
+MIJ_ES_KERNEL void k_es_sync(const DevScan *__restrict__ scans, const EsWork *__restrict__ work, const DevHuff *__restrict__ huff,
 																 const uint8_t *__restrict__ streams, uint64_t *__restrict__ start, const uint64_t *__restrict__ end_in,
 																 uint64_t *__restrict__ end_out, uint32_t *__restrict__ cnt, uint32_t *__restrict__ changed)
 {
@@ -655,7 +670,7 @@ __global__ __launch_bounds__(256) void k_es_offsets(const DevScan *__restrict__ 
 /* Every coefficient is stored where it belongs in planes cleared beforehand (hipMemsetAsync): no staging, so the
  * pass runs at the occupancy of the cold pass.  (Round 1 also had a variant that staged each block in LDS and stored
  * it whole: 37 KiB of LDS per workgroup, 3 waves per SIMD, 5.4 ms against 3.4 ms per 256 images -- removed.) */
-__global__ __launch_bounds__(256) void k_es_write(const DevScan *__restrict__ scans, const EsWork *__restrict__ work, const DevHuff *__restrict__ huff,
+MIJ_ES_KERNEL void k_es_write(const DevScan *__restrict__ scans, const EsWork *__restrict__ work, const DevHuff *__restrict__ huff,
 																  const uint8_t *__restrict__ streams, const DevImage *__restrict__ imgs, const uint64_t *__restrict__ start,
 																  const uint32_t *__restrict__ base, int16_t *__restrict__ coef, uint64_t *__restrict__ meta,
 																  uint32_t *__restrict__ anom, uint32_t *__restrict__ pfinal, uint8_t *__restrict__ zz)
@@ -717,7 +732,7 @@ __global__ __launch_bounds__(256) void k_es_write(const DevScan *__restrict__ sc
 
 /* the rest of every block that began in the previous subsequence: single coefficients into the block that the
  * previous thread's k_es_write stored whole (stream order makes this the later write) */
-__global__ __launch_bounds__(256) void k_es_tails(const DevScan *__restrict__ scans, const EsWork *__restrict__ work, const DevHuff *__restrict__ huff,
+MIJ_ES_KERNEL void k_es_tails(const DevScan *__restrict__ scans, const EsWork *__restrict__ work, const DevHuff *__restrict__ huff,
 																  const uint8_t *__restrict__ streams, const DevImage *__restrict__ imgs, const uint64_t *__restrict__ start,
 																  const uint32_t *__restrict__ base, int16_t *__restrict__ coef, uint64_t *__restrict__ meta,
 																  uint32_t *__restrict__ scratch, uint8_t *__restrict__ zz)

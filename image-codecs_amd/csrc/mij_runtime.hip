@@ -1626,7 +1626,7 @@ extern "C" int mij_batch_entropy_reserve(mij_batch *b, size_t stream_bytes)
 	e->rounds0 = e->sub_bits >= 4096u ? 4 : (e->sub_bits >= 2048u ? 12 : (e->sub_bits >= 1024u ? 24 : 32));
 	e->sub_cap = e->stream_cap * 8 / e->sub_bits + 2 * e->scan_cap;
 	e->blk_cap = b->coef_cap / 128 + n;
-	e->work_cap = e->sub_cap / 256 + 2 * e->scan_cap;
+	e->work_cap = e->sub_cap / MIJ_ES_WG + 2 * e->scan_cap;
 	e->pack_cap = e->blk_cap / 256 + 8 * n;
 	hipError_t r = hipHostMalloc(reinterpret_cast<void **>(&e->stage), e->stream_cap, hipHostMallocDefault);
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_stream), e->stream_cap);
@@ -1721,7 +1721,7 @@ extern "C" int mij_batch_add_stream(mij_batch *b, const mjg_scan *scan, uint8_t 
 			return set_err(MIJ_E_ARG, "bad segment %u", g);
 		const size_t ns = (len * 8 + e->sub_bits - 1) / e->sub_bits;
 		need_sub += ns ? ns : 1;
-		need_work += (ns ? ns : 1) / 256 + 1;
+		need_work += (ns ? ns : 1) / MIJ_ES_WG + 1;
 	}
 	if (scan->n_seg && ((uint64_t)scan->restart_mcus * (nseg - 1) >= nmcu || (uint64_t)scan->restart_mcus * nseg < nmcu))
 		return set_err(MIJ_E_ARG, "segment count does not match the restart interval");
@@ -1782,7 +1782,7 @@ extern "C" int mij_batch_add_stream(mij_batch *b, const mjg_scan *scan, uint8_t 
 		d.tab_off = (uint32_t)(8 * tab);
 		d.sub_bits = e->sub_bits;
 		memcpy(d.qz, scan->qz, sizeof(d.qz));
-		for (uint32_t f = 0; f < d.nsub; f += 256) {
+		for (uint32_t f = 0; f < d.nsub; f += MIJ_ES_WG) {
 			EsWork w = {(uint32_t)k, f};
 			e->h_work[e->work_used++] = w;
 		}
@@ -1803,7 +1803,7 @@ static int es_enqueue_tail(mij_batch *b)
 	/* the counters of the last round queued so far (slice 0 is clear when there was none) */
 	uint32_t *v_anom = e->d_verdict, *v_changed = e->d_changed + (size_t)(e->last_rounds > 0 ? e->last_rounds - 1 : 0) * e->scan_cap, *v_total = e->d_verdict + 2 * e->scan_cap,
 				*v_l1 = e->d_verdict + 3 * e->scan_cap, *v_pfinal = e->d_verdict + 4 * e->scan_cap;
-	const dim3 gw((unsigned)e->work_used), gs((unsigned)ns), blk(256);
+	const dim3 gw((unsigned)e->work_used), gs((unsigned)ns), blk(256), wblk(MIJ_ES_WG);
 	hipLaunchKernelGGL(k_es_offsets, gs, blk, 0, st, e->d_scans, e->d_cnt, e->d_base, v_total);
 	HIP_TRY(hipGetLastError());
 	{
@@ -1829,11 +1829,11 @@ static int es_enqueue_tail(mij_batch *b)
 		}
 		if (hi > lo)
 			HIP_TRY(hipMemsetAsync(b->d_coef + lo, 0, hi - lo, st));
-		hipLaunchKernelGGL(k_es_write, gw, blk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, b->d_imgs, e->d_start, e->d_base,
+		hipLaunchKernelGGL(k_es_write, gw, wblk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, b->d_imgs, e->d_start, e->d_base,
 								 reinterpret_cast<int16_t *>(b->d_coef), e->d_meta, v_anom, v_pfinal, e->d_zz);
 	}
 	HIP_TRY(hipGetLastError());
-	hipLaunchKernelGGL(k_es_tails, gw, blk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, b->d_imgs, e->d_start, e->d_base,
+	hipLaunchKernelGGL(k_es_tails, gw, wblk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, b->d_imgs, e->d_start, e->d_base,
 							 reinterpret_cast<int16_t *>(b->d_coef), e->d_meta, e->d_rounds_changed, e->d_zz);
 	HIP_TRY(hipGetLastError());
 	if (e->pack_used) {
@@ -1857,7 +1857,7 @@ static int es_enqueue_round(mij_batch *b)
 	if (e->last_rounds >= ES_MAX_ROUNDS)
 		return set_err(MIJ_E_STATE, "too many synchronisation rounds");
 	uint32_t *v_changed = e->d_changed + (size_t)e->last_rounds * e->scan_cap; /* this round's slice, cleared by the launch */
-	const dim3 gw((unsigned)e->work_used), blk(256);
+	const dim3 gw((unsigned)e->work_used), blk(MIJ_ES_WG);
 	(void)ns;
 	hipLaunchKernelGGL(k_es_sync, gw, blk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, e->d_start, e->d_end[e->cur], e->d_end[e->cur ^ 1], e->d_cnt, v_changed);
 	HIP_TRY(hipGetLastError());
@@ -1903,7 +1903,7 @@ extern "C" int mij_batch_entropy_launch(mij_batch *b)
 	 * coefficient planes nor the accumulators need clearing; the verdicts do */
 	HIP_TRY(hipMemsetAsync(e->d_verdict, 0, sizeof(uint32_t) * 5 * e->scan_cap, st));
 	HIP_TRY(hipMemsetAsync(e->d_changed, 0, sizeof(uint32_t) * ES_MAX_ROUNDS * e->scan_cap, st));
-	const dim3 gw((unsigned)e->work_used), blk(256);
+	const dim3 gw((unsigned)e->work_used), blk(MIJ_ES_WG);
 	hipLaunchKernelGGL(k_es_cold, gw, blk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, e->d_start, e->d_end[0], e->d_cnt);
 	HIP_TRY(hipGetLastError());
 	e->cur = 0;

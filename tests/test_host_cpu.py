@@ -391,16 +391,21 @@ def test_progressive_host_walk_vs_oracle_fuzz(golden, ica, oracle):
     ref = helpers.Reference() if helpers.Reference.available() else None
     n_ok = n_fail = 0
     for bi, base in enumerate(bases):
-        for seed in range(-1, 30):
-            data = base if seed < 0 else helpers.mutate(base, seed * 7919 + bi, n_mut=1 + seed % 4, allow_markers=(seed % 5 == 0))
+        for seed in range(-1, 36):
+            if seed >= 30:  # cut short inside the entropy data, with and without an EOI behind the cut: the bit register runs dry inside a refinement scan
+                cut = int(rng.integers(len(base) // 3, len(base) - 2))
+                data = base[:cut] + (b"\xff\xd9" if seed % 2 else b"")
+            else:
+                data = base if seed < 0 else helpers.mutate(base, seed * 7919 + bi, n_mut=1 + seed % 4, allow_markers=(seed % 5 == 0))
             o = oracle.load(data, 0)
             if ref is not None:
                 r = ref.load(data, 0)
-                assert r[0] == o[0] and (r[0] == "fail" and r[1] == o[1] or r[0] == "ok"), (bi, seed, r[:2] if r[0] == "fail" else "ok", o[:2] if o[0] == "fail" else "ok")
+                # a reason of None: the reference fails there without calling stbi__err (its stbi_failure_reason() keeps whatever an earlier call left)
+                assert r[0] == o[0] and (r[0] == "fail" and (r[1] == o[1] or o[1] is None) or r[0] == "ok"), (bi, seed, r[:2] if r[0] == "fail" else "ok", o[:2] if o[0] == "fail" else "ok")
             if o[0] == "fail":
                 with pytest.raises(ica.MijError) as e:
                     ica.HostDecoder.decode(data, 0)
-                assert str(e.value) == o[1], (bi, seed)
+                assert str(e.value) == (o[1] if o[1] is not None else "decode failed"), (bi, seed)
                 n_fail += 1
             else:
                 desc, arena = ica.HostDecoder.decode(data, 0)
@@ -408,3 +413,17 @@ def test_progressive_host_walk_vs_oracle_fuzz(golden, ica, oracle):
                 assert np.array_equal(got, oracle.coef(data)), (bi, seed)
                 n_ok += 1
     assert n_ok > 150 and n_fail > 3, (n_ok, n_fail)
+
+
+def test_progressive_refinement_without_pdep():
+    """The AC refinement scans read their correction bits a run at a time where the CPU has BMI2 pdep (jpeg_entropy.c, refine_symbols_wide)
+    and bit by bit elsewhere; MIJ_NO_PDEP=1 (read once, when the library initialises its tables) forces the second form: the same fuzz, in
+    a process of its own, must come out the same."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, MIJ_NO_PDEP="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", os.path.join(here, "test_host_cpu.py") + "::test_progressive_host_walk_vs_oracle_fuzz",
+                        os.path.join(here, "test_progressive_writer.py")], env=env, cwd=os.path.dirname(here), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
