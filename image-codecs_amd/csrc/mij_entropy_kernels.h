@@ -11,7 +11,9 @@
  *                    and records the state it is in when it crosses into the next subsequence
  *   2. k_es_sync     rounds: thread i restarts from the end state of thread i-1 if that differs from what it
  *                    started from last time; the true chain from subsequence 0 wins; stops changing after a
- *                    few rounds because wrong starts re-synchronise inside one subsequence
+ *                    few rounds because wrong starts re-synchronise inside one subsequence.  From the second
+ *                    round on (k_es_syncq) the subsequences that have to run again come off a queue the round before
+ *                    filled, packed into full wavefronts
  *   3. k_es_offsets  prefix sum of the blocks completed per subsequence -> the block ordinal each one starts at
  *   4. k_es_write    decode once more, now knowing where every coefficient goes, DC differences aside.  Compact
  *                    planes (the default): into a cleared intermediate image of 64 bytes per block in ZIGZAG order,
@@ -600,10 +602,33 @@ MIJ_ES_KERNEL void k_es_cold(const DevScan *__restrict__ scans, const EsWork *__
 	end[sc.sub_off + i] = es_pack(s);
 }
 
-/* one synchronisation round: end_in is the previous round's result, end_out this round's */
+/* A subsequence whose end state moved hands that state to its successor for the NEXT round: entries (subsequence, start state) appended to
+ * the scan's queue, one atomic per wavefront.  Only the lanes still running call this (the others have returned). */
+__device__ __forceinline__ void es_push(bool push, uint32_t j, uint64_t state, uint32_t sub_off, uint32_t *__restrict__ qcount, uint32_t *__restrict__ qidx,
+													 uint64_t *__restrict__ qstate)
+{
+	const uint64_t m = __ballot(push);
+	if (!m)
+		return;
+	const uint32_t lane = __lane_id(), leader = (uint32_t)__builtin_ctzll(m);
+	uint32_t base = 0;
+	if (lane == leader)
+		base = atomicAdd(qcount, (uint32_t)__builtin_popcountll(m));
+	base = __shfl(base, (int)leader);
+	if (push) {
+		const uint32_t pos = sub_off + base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+		qidx[pos] = j;
+		qstate[pos] = state;
+	}
+}
+
+/* The first synchronisation round: every subsequence behind the first restarts from the end state the cold pass found for its predecessor
+ * (end_in; practically all of them: a guessed start is a block start at the first bit).  end_out = this round's end states; a subsequence
+ * whose end state is no longer the cold pass's puts its successor on the queue of the second round.  pending[scan] counts those. */
 MIJ_ES_KERNEL void k_es_sync(const DevScan *__restrict__ scans, const EsWork *__restrict__ work, const DevHuff *__restrict__ huff,
 																 const uint8_t *__restrict__ streams, uint64_t *__restrict__ start, const uint64_t *__restrict__ end_in,
-																 uint64_t *__restrict__ end_out, uint32_t *__restrict__ cnt, uint32_t *__restrict__ changed)
+																 uint64_t *__restrict__ end_out, uint32_t *__restrict__ cnt, uint32_t *__restrict__ pending, uint32_t *__restrict__ qidx,
+																 uint64_t *__restrict__ qstate)
 {
 	__shared__ EsTab tabs[8];
 	__shared__ EsLocal loc;
@@ -612,17 +637,16 @@ MIJ_ES_KERNEL void k_es_sync(const DevScan *__restrict__ scans, const EsWork *__
 	const DevScan &sc = scans[wk.scan];
 	const uint32_t i = wk.first + threadIdx.x;
 	const uint32_t slot = sc.sub_off + i;
-	/* who has to decode again?  From the second round on almost nobody: a workgroup without such a thread leaves
-	 * before it has copied the eight tables into LDS (which is most of what an idle round used to cost) */
-	uint64_t want = 0;
+	uint64_t want = 0, was = 0;
 	bool redo = false;
 	if (i < sc.nsub) {
+		was = end_in[slot];
 		if (i > 0) {
 			want = end_in[slot - 1];
 			redo = want != start[slot];
 		}
 		if (!redo)
-			end_out[slot] = end_in[slot];
+			end_out[slot] = was;
 	}
 	if (!__syncthreads_or(redo ? 1 : 0))
 		return;
@@ -633,8 +657,44 @@ MIJ_ES_KERNEL void k_es_sync(const DevScan *__restrict__ scans, const EsWork *__
 	EsState s = es_unpack(want);
 	const uint32_t pe = min((i + 1u) * sc.sub_bits, sc.nbits);
 	cnt[slot] = es_decode<false, MIJ_ES_PAIR != 0>(sc, loc, tabs, streams + sc.stream_off, s, pe, nullptr, nullptr, &pair);
-	end_out[slot] = es_pack(s);
-	atomicAdd(&changed[wk.scan], 1u);
+	const uint64_t now = es_pack(s);
+	end_out[slot] = now;
+	es_push(i + 1u < sc.nsub && now != was, i + 1u, now, sc.sub_off, &pending[wk.scan], qidx, qstate);
+}
+
+/* Every later round: only the subsequences on the scan's queue run -- gathered into full wavefronts, where the first round's form ran a whole
+ * wavefront for one lane that moved (round 2 of the benchmark's pictures: 55 % of a full round's instructions and 84 % of its time for a
+ * small share of the subsequences).  n_in[scan] entries (subsequence, start state) written by the round before; end states are updated in
+ * place (nobody else reads them: a successor gets its state through the queue), the successors of those that moved go on the next queue. */
+MIJ_ES_KERNEL void k_es_syncq(const DevScan *__restrict__ scans, const EsWork *__restrict__ work, const DevHuff *__restrict__ huff,
+																  const uint8_t *__restrict__ streams, uint64_t *__restrict__ start, uint64_t *__restrict__ end, uint32_t *__restrict__ cnt,
+																  const uint32_t *__restrict__ n_in, const uint32_t *__restrict__ qidx_in, const uint64_t *__restrict__ qstate_in,
+																  uint32_t *__restrict__ pending, uint32_t *__restrict__ qidx, uint64_t *__restrict__ qstate)
+{
+	__shared__ EsTab tabs[8];
+	__shared__ EsLocal loc;
+	__shared__ EsPair pair;
+	const EsWork wk = work[blockIdx.x];
+	const uint32_t n = n_in[wk.scan];
+	if (wk.first >= n) /* most workgroups, from the second round on: gone before the tables are copied */
+		return;
+	const DevScan &sc = scans[wk.scan];
+	es_load_tables(sc, nullptr, huff + sc.tab_off, tabs, &loc, MIJ_ES_PAIR ? &pair : nullptr);
+	const uint32_t t = wk.first + threadIdx.x;
+	if (t >= n)
+		return;
+	const uint32_t i = qidx_in[sc.sub_off + t];
+	const uint64_t want = qstate_in[sc.sub_off + t];
+	if (i >= sc.nsub)
+		return;
+	const uint32_t slot = sc.sub_off + i;
+	start[slot] = want;
+	EsState s = es_unpack(want);
+	const uint32_t pe = min((i + 1u) * sc.sub_bits, sc.nbits);
+	cnt[slot] = es_decode<false, MIJ_ES_PAIR != 0>(sc, loc, tabs, streams + sc.stream_off, s, pe, nullptr, nullptr, &pair);
+	const uint64_t now = es_pack(s), was = end[slot];
+	end[slot] = now;
+	es_push(i + 1u < sc.nsub && now != was, i + 1u, now, sc.sub_off, &pending[wk.scan], qidx, qstate);
 }
 
 /* exclusive prefix sum of cnt over a scan's subsequences (one workgroup per scan) */

@@ -1540,7 +1540,9 @@ struct EsArena {
 	size_t work_cap;
 	WorkIdct *h_pack, *d_pack; /* k_es_pack: (slot, component, first block) per 256 blocks of every compact-plane slot */
 	size_t pack_cap, pack_used;
-	uint64_t *d_start, *d_end[2];
+	uint64_t *d_start, *d_end[2]; /* d_end[0]: the cold pass's end states, d_end[1]: the current ones (first round on) */
+	uint32_t *d_qidx[2];  /* the queues of k_es_syncq, alternating by round: subsequence ... */
+	uint64_t *d_qstate[2]; /* ... and the start state it has to run from; a scan's entries start at its sub_off */
 	uint32_t *d_cnt, *d_base;
 	size_t sub_cap;
 	uint32_t sub_bits; /* bits per subsequence of this arena's scans */
@@ -1577,6 +1579,10 @@ static void es_free(EsArena *e)
 	if (e->d_start) (void)hipFree(e->d_start);
 	if (e->d_end[0]) (void)hipFree(e->d_end[0]);
 	if (e->d_end[1]) (void)hipFree(e->d_end[1]);
+	for (int q = 0; q < 2; ++q) {
+		if (e->d_qidx[q]) (void)hipFree(e->d_qidx[q]);
+		if (e->d_qstate[q]) (void)hipFree(e->d_qstate[q]);
+	}
 	if (e->d_cnt) (void)hipFree(e->d_cnt);
 	if (e->d_base) (void)hipFree(e->d_base);
 	if (e->d_meta) (void)hipFree(e->d_meta);
@@ -1641,6 +1647,10 @@ extern "C" int mij_batch_entropy_reserve(mij_batch *b, size_t stream_bytes)
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_start), sizeof(uint64_t) * e->sub_cap);
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_end[0]), sizeof(uint64_t) * e->sub_cap);
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_end[1]), sizeof(uint64_t) * e->sub_cap);
+	for (int q = 0; q < 2; ++q) {
+		if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_qidx[q]), sizeof(uint32_t) * e->sub_cap);
+		if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_qstate[q]), sizeof(uint64_t) * e->sub_cap);
+	}
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_cnt), sizeof(uint32_t) * e->sub_cap);
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_base), sizeof(uint32_t) * e->sub_cap);
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_meta), sizeof(uint64_t) * e->blk_cap);
@@ -1859,9 +1869,15 @@ static int es_enqueue_round(mij_batch *b)
 	uint32_t *v_changed = e->d_changed + (size_t)e->last_rounds * e->scan_cap; /* this round's slice, cleared by the launch */
 	const dim3 gw((unsigned)e->work_used), blk(MIJ_ES_WG);
 	(void)ns;
-	hipLaunchKernelGGL(k_es_sync, gw, blk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, e->d_start, e->d_end[e->cur], e->d_end[e->cur ^ 1], e->d_cnt, v_changed);
+	/* v_changed: what this round leaves for the next one (0 everywhere: the chains have settled) */
+	const int r = e->last_rounds;
+	if (r == 0)
+		hipLaunchKernelGGL(k_es_sync, gw, blk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, e->d_start, e->d_end[0], e->d_end[1], e->d_cnt, v_changed, e->d_qidx[0],
+								 e->d_qstate[0]);
+	else
+		hipLaunchKernelGGL(k_es_syncq, gw, blk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, e->d_start, e->d_end[1], e->d_cnt, v_changed - e->scan_cap,
+								 e->d_qidx[(r - 1) & 1], e->d_qstate[(r - 1) & 1], v_changed, e->d_qidx[r & 1], e->d_qstate[r & 1]);
 	HIP_TRY(hipGetLastError());
-	e->cur ^= 1;
 	++e->last_rounds;
 	return MIJ_OK;
 }
