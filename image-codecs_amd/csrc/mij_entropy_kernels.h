@@ -207,7 +207,8 @@ __device__ __forceinline__ int es_symbol_e(const EsTab &h, uint64_t win, uint32_
 /* codec/jpeg.c:250-265 on the n bits that follow the code */
 __device__ __forceinline__ int es_extend(uint64_t win, uint32_t len, uint32_t n)
 {
-	const uint32_t bits = (uint32_t)((win << len) >> (64u - n));
+	/* a code is at most 16 bits long and brings at most 15 more: everything lies in the window's high dword */
+	const uint32_t bits = ((uint32_t)(win >> 32) << len) >> (32u - n);
 	const int neg = !(bits >> (n - 1u));
 	return neg ? (int)bits - (int)((1u << n) - 1u) : (int)bits;
 }
@@ -234,7 +235,7 @@ struct EsWriter { /* where the blocks of the write pass go */
 	bool stop_after_block;
 	bool owner;          /* k_es_write: this thread stores the meta word of the blocks it begins (k_es_tails adds to the L1) */
 	uint32_t ord;        /* ordinal of the current block */
-	uint32_t mx, my;     /* its MCU (int16 planes only) */
+	uint32_t mx, my;     /* its MCU */
 	int16_t *blk;        /* its tile slot (int16 planes) */
 	uint8_t *zz;         /* compact planes: its 64 bytes, zigzag order, in the intermediate image (blocks in scan order) */
 	uint64_t grp;        /* the eight bytes of group curq gathered so far */
@@ -252,13 +253,14 @@ struct EsWriter { /* where the blocks of the write pass go */
 		const uint32_t L = bx + by * loc->bw[c];
 		blk = reinterpret_cast<int16_t *>(reinterpret_cast<uint8_t *>(coef) + loc->plane[c]) + ((size_t)(L >> 6) << 12) + ((L & 63u) << 3);
 	}
-	/* compact planes, rare: the 64 escape bytes of the current block (block-in-MCU c), from its ordinal */
+	/* compact planes: the 64 escape bytes of the current block (block-in-MCU c of MCU (mx, my)).  Until round 3 this derived the MCU from
+	 * the block's ordinal with two integer divisions (ninety instructions, "rare") -- but a wavefront runs the path whenever ONE of its 64
+	 * lanes meets an escaped coefficient, a quarter of the loop's iterations on the benchmark's pictures and nearly all on high-quality ones;
+	 * counting the MCU along costs five instructions per block end */
 	__device__ __forceinline__ uint8_t *escape_bytes(uint32_t c) const
 	{
-		const uint32_t m = sc->first_mcu + (ord - c) / sc->bpm;
-		const uint32_t ym = m / sc->mcu_x, xm = m - ym * sc->mcu_x;
 		const uint32_t g = loc->geo[c];
-		const uint32_t bx = xm * (g & 255u) + ((g >> 16) & 255u), by = ym * ((g >> 8) & 255u) + (g >> 24);
+		const uint32_t bx = mx * (g & 255u) + ((g >> 16) & 255u), by = my * ((g >> 8) & 255u) + (g >> 24);
 		return reinterpret_cast<uint8_t *>(coef) + loc->hi[c] + ((size_t)(bx + by * loc->bw[c]) << 6);
 	}
 	__device__ __forceinline__ void flush_group()
@@ -404,7 +406,11 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &
 		const int ext = es_extend(win, len, n ? n : 1u);
 		const int v = n ? ext : 0;
 		s.p += len + n;
-		br.take(len + n);
+		/* the write pass shifts the window once per iteration: a pair lies inside the twelve bits its entry was built from, so the second
+		 * symbol needs no refill in between */
+		uint32_t used = len + n;
+		if (!PAIRW)
+			br.take(used);
 		if (isdc) {
 			if (WRITE)
 				wr->dcd = v;
@@ -434,9 +440,9 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &
 		 * checks and its trip round the loop. */
 		if (PAIRW && e2w && s.z < 64u && s.p < p_end) {
 			const uint32_t len2 = e2w >> 12, n2 = (e2w >> 4) & 15u, r2 = (e2w >> 8) & 15u;
-			const int v2 = n2 ? es_extend(br.win, len2, n2) : 0;
+			const int v2 = n2 ? es_extend(win << used, len2, n2) : 0;
 			s.p += len2 + n2;
-			br.take(len2 + n2);
+			used += len2 + n2;
 			if (n2 == 0) {
 				s.z = r2 == 15u ? s.z + 16u : 64u;
 			} else {
@@ -456,6 +462,8 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &
 				}
 			}
 		}
+		if (PAIRW)
+			br.take(used);
 		} /* !paired */
 		if (s.z >= 64u) { /* block complete (ZRL past the end ends it too: same as the host loop's k < 64 test) */
 			s.z = 0;
@@ -477,7 +485,7 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &
 			}
 			if (++s.c == sc.bpm) {
 				s.c = 0;
-				if (WRITE && !sc.fmt) {
+				if (WRITE) {
 					if (++wr->mx == sc.mcu_x) {
 						wr->mx = 0;
 						++wr->my;
@@ -781,11 +789,10 @@ MIJ_ES_KERNEL void k_es_write(const DevScan *__restrict__ scans, const EsWork *_
 		return;
 	}
 	wr.zz = zz + ((size_t)(sc.blk_off + wr.ord) << 6);
-	if (!sc.fmt) {
-		wr.my = m / sc.mcu_x;
-		wr.mx = m - wr.my * sc.mcu_x;
+	wr.my = m / sc.mcu_x;
+	wr.mx = m - wr.my * sc.mcu_x;
+	if (!sc.fmt)
 		wr.locate(s.c);
-	}
 	const uint32_t pe = min((i + 1u) * sc.sub_bits, sc.nbits);
 	es_decode<true, false, MIJ_ES_PAIR != 0>(sc, loc, tabs, streams + sc.stream_off, s, pe, &wr, &anom[wk.scan], &pair);
 }
@@ -846,11 +853,10 @@ MIJ_ES_KERNEL void k_es_tails(const DevScan *__restrict__ scans, const EsWork *_
 	if (wr.ord - ml * sc.bpm != s.c)
 		return;
 	wr.zz = zz + ((size_t)(sc.blk_off + wr.ord) << 6);
-	if (!sc.fmt) {
-		wr.my = m / sc.mcu_x;
-		wr.mx = m - wr.my * sc.mcu_x;
+	wr.my = m / sc.mcu_x;
+	wr.mx = m - wr.my * sc.mcu_x;
+	if (!sc.fmt)
 		wr.locate(s.c);
-	}
 	/* k_es_write walked the same symbols and reported what there was to report: verdict bits go to a scratch word */
 	es_decode<true>(sc, loc, tabs, streams + sc.stream_off, s, sc.nbits, &wr, scratch + 1);
 }
