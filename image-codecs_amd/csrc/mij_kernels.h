@@ -64,8 +64,9 @@ struct DevImage {
 	uint32_t dq[4][32]; /* per component: quantisation table as u16 pairs in in-block position order P */
 };
 
-struct WorkBand { /* one workgroup of k_fused420 */
-	uint32_t img, m0, m1, pad;
+struct WorkBand { /* one workgroup of the band kernels: MCU rows [m0, m1) of an image */
+	uint32_t img, m0, m1;
+	uint32_t cols; /* column-segmented forms (k_fused420c / k_fused440c) only: first MCU column | one past the last << 16 */
 };
 struct WorkIdct { /* one workgroup of k_idct_planes: 256 consecutive blocks of one component */
 	uint32_t img, comp, first, pad;
@@ -1300,7 +1301,11 @@ __device__ __forceinline__ void strip_row_packed(const ColorK &K, uint32_t cb4, 
  * full width and half height (resample_row_v_2, codec/jpeg.c:1774-1782).  Vertically nothing changes (row pairs (2C-1, 2C) on chroma
  * rows C-1 and C, saved rows, halo block rows at the band edges); horizontally there is no neighbourhood: a strip's chroma is one
  * dword per row and (3 near + far + 2) >> 2 runs on four samples at once in 16-bit lanes (rs_v2). */
-template <int NOUT, bool WIDE, bool B8, bool H2, int NT>
+/* SEG = true: the workgroup emits MCU columns [xm0, xm1) only -- pictures whose row of MCUs does not fit the LDS of a CU (4:2:0 beyond
+ * 5840 pixels, 4:4:0 beyond 4300) are cut into column segments.  A segment transforms one MCU column more on either side (the horizontal
+ * chroma filter reads c[i-1] and c[i+1], codec/jpeg.c:1784-1835); everything inside the kernel is in LOCAL columns (the segment plus its
+ * halo), and only the plane addresses, the output columns and the picture-edge tests are global.  SEG = false compiles to the code it was. */
+template <int NOUT, bool WIDE, bool B8, bool H2, int NT, bool SEG = false>
 __device__ __forceinline__ void fused_band(const DevImage *__restrict__ imgs, const WorkBand *__restrict__ work, const uint8_t *__restrict__ coef,
 														 uint8_t *__restrict__ outbase)
 {
@@ -1310,12 +1315,19 @@ __device__ __forceinline__ void fused_band(const DevImage *__restrict__ imgs, co
 	const int tid = threadIdx.x;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
 
-	const int mcu_x = im.mcu_x;
+	const int gmx = im.mcu_x; /* MCU columns of the picture */
+	const int xm0 = SEG ? (int)(wk.cols & 0xffffu) : 0, xm1 = SEG ? (int)(wk.cols >> 16) : gmx; /* columns emitted */
+	const int lm0 = SEG ? max(xm0 - 1, 0) : 0, lm1 = SEG ? min(xm1 + 1, gmx) : gmx;              /* columns transformed */
+	const int mcu_x = lm1 - lm0;
 	const int W = im.width, H = im.height;
 	const int YP = (H2 ? 16 : 8) * mcu_x, CP = 8 * mcu_x;
 	const int wc = H2 ? (W + 1) >> 1 : W; /* w_lores of the chroma planes, codec/jpeg.c:2276 */
 	const int hc = im.comp[1].y;    /* effective chroma rows */
-	const int bwY = (H2 ? 2 : 1) * mcu_x, bwC = mcu_x;
+	const int bwY = (H2 ? 2 : 1) * mcu_x, bwC = mcu_x;        /* blocks per row held in LDS */
+	const int gbwY = (H2 ? 2 : 1) * gmx, gbwC = gmx;          /* blocks per row of the planes */
+	const int bx0Y = (H2 ? 2 : 1) * lm0, bx0C = lm0;          /* the planes' block column of local column 0 */
+	const int spm = H2 ? 4 : 2;                               /* 4-pixel strips per MCU column */
+	const int soff = spm * lm0;                               /* global strip index of local strip 0 */
 
 	uint8_t *const sY = lds;
 	uint8_t *const sCb = sY + 16 * YP;
@@ -1349,7 +1361,7 @@ __device__ __forceinline__ void fused_band(const DevImage *__restrict__ imgs, co
 			const int bx = (comp == 1 ? ww : ww - nCw) * 64 + lane;
 			if (bx < bwC) {
 				uint2 rows[8];
-				load_idct_block<WIDE, B8>(KI, comp == 1 ? cvCb : cvCr, (uint32_t)(mc * bwC + bx), im.dq[comp], rows, 0);
+				load_idct_block<WIDE, B8>(KI, comp == 1 ? cvCb : cvCr, (uint32_t)(mc * gbwC + bx0C + bx), im.dq[comp], rows, 0);
 				*reinterpret_cast<uint2 *>((comp == 1 ? dstCb : dstCr) + 8 * bx) = keep ? rows[7] : rows[0];
 			}
 		}
@@ -1365,10 +1377,12 @@ __device__ __forceinline__ void fused_band(const DevImage *__restrict__ imgs, co
 		/* fast strips: 4 whole pixels, dword-aligned rows.  Two strips per thread and iteration, all LDS
 		 * reads of both issued before either is processed (hides LDS latency, halves the loop overhead) */
 		const int nfast = aligned ? (W >> 2) : 0;
+		const int s_lo = SEG ? spm * xm0 : 0, s_hi = SEG ? min(spm * xm1, nfast) : nfast; /* the fast strips of this workgroup (global indices) */
 		struct StripIn {
 			uint32_t bA0, bA1, bB0, bB1, rA0, rA1, rB0, rB1, yA, yB;
 		};
-		auto load_strip = [&](int s, StripIn &in) {
+		auto load_strip = [&](int sg, StripIn &in) {
+			const int s = sg - soff; /* the strip inside the LDS rows */
 			if (!H2) { /* 4:4:0: the strip's four chroma samples are one dword of each row */
 				in.bA0 = reinterpret_cast<const uint32_t *>(cbA)[s];
 				in.bB0 = reinterpret_cast<const uint32_t *>(cbB)[s];
@@ -1431,30 +1445,31 @@ __device__ __forceinline__ void fused_band(const DevImage *__restrict__ imgs, co
 				strip_row<NOUT>(KC, KC.wAk, KC.wAk1, vb0, vb1, vb2, vr0, vr1, vr2, in.yA, out + (offA + xo));
 		};
 		if (NT >= 512) { /* one strip per thread and iteration: a 1080p row is 480 strips */
-			for (int sa = tid; sa < nfast; sa += NT) {
+			for (int sa = s_lo + tid; sa < s_hi; sa += NT) {
 				StripIn ia;
 				load_strip(sa, ia);
 				do_strip(sa, ia);
 			}
 		} else
-		for (int base = 0; base < nfast; base += 2 * NT) {
+		for (int base = s_lo; base < s_hi; base += 2 * NT) {
 			const int sa = base + tid, sb = sa + NT;
 			StripIn ia, ib;
-			load_strip(min(sa, nfast - 1), ia);
-			load_strip(min(sb, nfast - 1), ib);
-			if (sa < nfast)
+			load_strip(min(sa, s_hi - 1), ia);
+			load_strip(min(sb, s_hi - 1), ib);
+			if (sa < s_hi)
 				do_strip(sa, ia);
-			if (sb < nfast)
+			if (sb < s_hi)
 				do_strip(sb, ib);
 		}
-		/* the rest (partial last strip, unaligned widths): careful per-pixel path */
-		for (int s = nfast + tid; s < nstrip; s += NT) {
+		/* the rest (partial last strip, unaligned widths): careful per-pixel path, on row pointers moved back to the picture's column 0 */
+		const int ypx0 = (H2 ? 16 : 8) * lm0, cpx0 = 8 * lm0;
+		for (int s = (SEG ? max(nfast, s_lo) : nfast) + tid; s < (SEG ? min(nstrip, spm * xm1) : nstrip); s += NT) {
 			const int x0 = 4 * s, xe = min(x0 + 4, W);
 			for (int x = x0; x < xe; ++x) {
 				if (doA)
-					fused420_pixel<NOUT, H2>(yA, cbA, cbB, crA, crB, 0, wc, x, out + (size_t)ra * opitch);
+					fused420_pixel<NOUT, H2>(yA - ypx0, cbA - cpx0, cbB - cpx0, crA - cpx0, crB - cpx0, 0, wc, x, out + (size_t)ra * opitch);
 				if (doB)
-					fused420_pixel<NOUT, H2>(yB, cbA, cbB, crA, crB, 1, wc, x, out + (size_t)rb * opitch);
+					fused420_pixel<NOUT, H2>(yB - ypx0, cbA - cpx0, cbB - cpx0, crA - cpx0, crB - cpx0, 1, wc, x, out + (size_t)rb * opitch);
 			}
 		}
 	};
@@ -1476,7 +1491,7 @@ __device__ __forceinline__ void fused_band(const DevImage *__restrict__ imgs, co
 			if (i < nblk) {
 				const int by = (comp == 0 && i >= bwY) ? 1 : 0, bx = i - by * bwY;
 				const int pitch = comp == 0 ? YP : CP;
-				const uint32_t L = (uint32_t)((comp == 0 ? 2 * m * bwY : m * bwC) + i);
+				const uint32_t L = SEG ? (uint32_t)(comp == 0 ? (2 * m + by) * gbwY + bx0Y + bx : m * gbwC + bx0C + bx) : (uint32_t)((comp == 0 ? 2 * m * bwY : m * bwC) + i);
 				load_idct_block<WIDE, B8>(KI, comp == 0 ? cvY : (comp == 1 ? cvCb : cvCr), L, im.dq[comp], rows, count_classes);
 				uint8_t *dst = (comp == 0 ? sY : (comp == 1 ? sCb : sCr)) + (8 * by) * pitch + 8 * bx;
 #pragma unroll
@@ -1602,6 +1617,27 @@ __global__ __launch_bounds__(MIJ_F420W_NT) void k_fused440w(const DevImage *__re
 																				 uint8_t *__restrict__ outbase)
 {
 	fused_band<NOUT, WIDE, B8, false, MIJ_F420W_NT>(imgs, work, coef, outbase);
+}
+
+/* Column-segmented forms (fused_band, SEG): pictures whose row of MCUs exceeds a CU's LDS.  Eight waves and segments that let two
+ * workgroups share a CU (at most 180 MCU columns of 4:2:0), measured per 0.53 Gpix resident against the two-pass kernels these pictures
+ * took before (tools/seg_sweep.sh, profiles/r03_wide_segments.txt): 6000 x 4000 0.847 -> 0.707 ms, 8192 x 5464 0.741 -> 0.643; one
+ * workgroup of sixteen waves on a segment that fills the LDS: 0.717 / 0.670; three of four waves on 119 columns: 0.829 / 0.687.  Cutting
+ * pictures that DO fit (2560 .. 5120 pixels) into segments as well loses 0-9 % against the w / x forms, so only the others are cut. */
+#ifndef MIJ_F420C_NT
+#define MIJ_F420C_NT 512
+#endif
+template <int NOUT, bool WIDE, bool B8 = false>
+__global__ __launch_bounds__(MIJ_F420C_NT) void k_fused420c(const DevImage *__restrict__ imgs, const WorkBand *__restrict__ work, const uint8_t *__restrict__ coef,
+																				 uint8_t *__restrict__ outbase)
+{
+	fused_band<NOUT, WIDE, B8, true, MIJ_F420C_NT, true>(imgs, work, coef, outbase);
+}
+template <int NOUT, bool WIDE, bool B8 = false>
+__global__ __launch_bounds__(MIJ_F420C_NT) void k_fused440c(const DevImage *__restrict__ imgs, const WorkBand *__restrict__ work, const uint8_t *__restrict__ coef,
+																				 uint8_t *__restrict__ outbase)
+{
+	fused_band<NOUT, WIDE, B8, false, MIJ_F420C_NT, true>(imgs, work, coef, outbase);
 }
 
 /* ------------------------------------------------------------------ fused h2v1 (4:2:2) YCbCr kernel

@@ -113,6 +113,8 @@ extern "C" int mij_ctx_create(int device, mij_ctx **out)
 	MIJ_LDS_ATTR8(k_fused420t);
 	MIJ_LDS_ATTR8(k_fused440);
 	MIJ_LDS_ATTR8(k_fused440w);
+	MIJ_LDS_ATTR8(k_fused420c);
+	MIJ_LDS_ATTR8(k_fused440c);
 	MIJ_LDS_ATTR8(k_fused422);
 	MIJ_LDS_ATTR8(k_fused422w);
 	MIJ_LDS_ATTR8(k_fused422x);
@@ -208,7 +210,7 @@ struct Slot {
 
 /* kernel families of a launch plan, in launch order */
 /* MK_RS_FAST + RS_*: pass 2 compiled per resampler (k_resample_fast); list index [n_out == 4][YCbCr colour][0] */
-enum { MK_PLANES = 0, MK_RESAMPLE, MK_RS_FAST, MK_420 = MK_RS_FAST + RS_KINDS, MK_422, MK_444, MK_GREY, MK_440, MK_420W, MK_440W /* k_fused420w / k_fused440w: 512 threads, wide pictures */, MK_420X /* 1024 threads: one workgroup per CU */, MK_420S, MK_420T /* 128 / 64 threads: narrow pictures */, MK_422W, MK_422X, MK_422S, MK_422T /* k_fused422 with 512 / 1024 / 128 / 64 threads */, MK_1X1C /* k_fused1x1c: RGB-tagged / CMYK / YCCK at 1x1 */, MK_KINDS };
+enum { MK_PLANES = 0, MK_RESAMPLE, MK_RS_FAST, MK_420 = MK_RS_FAST + RS_KINDS, MK_422, MK_444, MK_GREY, MK_440, MK_420W, MK_440W /* k_fused420w / k_fused440w: 512 threads, wide pictures */, MK_420X /* 1024 threads: one workgroup per CU */, MK_420S, MK_420T /* 128 / 64 threads: narrow pictures */, MK_422W, MK_422X, MK_422S, MK_422T /* k_fused422 with 512 / 1024 / 128 / 64 threads */, MK_1X1C /* k_fused1x1c: RGB-tagged / CMYK / YCCK at 1x1 */, MK_420C, MK_440C /* column segments: a row of MCUs beyond a CU's LDS */, MK_KINDS };
 struct Work4 { /* WorkBand and WorkIdct are both four u32 */
 	uint32_t a, b, c, d;
 };
@@ -658,8 +660,7 @@ static bool fused420_ok(const mij_batch *b, const mij_image_desc &d)
 	for (int c = 1; c < 3; ++c)
 		if (d.comp[c].h != 1 || d.comp[c].v != 1)
 			return false;
-	size_t lds = (size_t)d.mcu_x * (16 * 16 + 2 * 8 * 8 + 2 * 16 + 4 * 8);
-	return lds <= (size_t)b->ctx->max_dyn_lds;
+	return true; /* any width: a row of MCUs beyond the LDS of a CU goes in column segments (fused420_kind) */
 }
 
 /* single-component images: IDCT straight into the pixel buffer */
@@ -676,7 +677,7 @@ static bool fused440_ok(const mij_batch *b, const mij_image_desc &d)
 	for (int c = 1; c < 3; ++c)
 		if (d.comp[c].h != 1 || d.comp[c].v != 1)
 			return false;
-	return fused440_lds(d) <= (size_t)b->ctx->max_dyn_lds;
+	return true; /* any width, see fused420_ok */
 }
 
 static bool fused_grey_ok(const mij_batch *b, const mij_image_desc &d)
@@ -829,6 +830,26 @@ static int grow_pair(T *&h, T *&d, size_t &cap, size_t need)
 	return MIJ_OK;
 }
 
+/* experiment knobs (environment, read once): MIJ_SEG_MIN = MCU columns beyond which a picture goes in column segments although its row
+ * fits the LDS; MIJ_SEG_COLS = widest segment in MCU columns (0: whatever fills the LDS) */
+static int seg_min_cols()
+{
+	static int v = -1;
+	if (v < 0) {
+		const char *e = getenv("MIJ_SEG_MIN");
+		v = e ? atoi(e) : 1 << 30;
+	}
+	return v;
+}
+static int seg_max_cols()
+{
+	static int v = -1;
+	if (v < 0) {
+		const char *e = getenv("MIJ_SEG_COLS");
+		v = e ? atoi(e) : 0;
+	}
+	return v;
+}
 static size_t fused420_lds(const mij_image_desc &d) { return (size_t)d.mcu_x * (16 * 16 + 2 * 8 * 8 + 2 * 16 + 4 * 8); }
 /* fewer than three workgroups of the band kernel fit a CU's LDS: the eight-wave form (k_fused420w) */
 /* which form of the band kernel a 4:2:0 picture takes (-1: none): by the workgroups of its width that fit a CU's LDS, and for narrow
@@ -838,6 +859,8 @@ static int fused420_kind(const mij_batch *b, const mij_image_desc &d)
 	if (!fused420_ok(b, d))
 		return -1;
 	const size_t lds = fused420_lds(d), cap = (size_t)b->ctx->max_dyn_lds;
+	if (lds > cap || d.mcu_x > seg_min_cols())
+		return MK_420C;
 	if (2 * lds > cap)
 		return MK_420X;
 	if (3 * lds > cap)
@@ -854,6 +877,7 @@ static int band_threads(int kind)
 {
 	switch (kind) {
 	case MK_420X: case MK_422X: return MIJ_F420X_NT;
+	case MK_420C: case MK_440C: return MIJ_F420C_NT;
 	case MK_420W: case MK_440W: case MK_422W: return MIJ_F420W_NT;
 	case MK_420S: case MK_422S: return MIJ_F420S_NT;
 	case MK_420T: case MK_422T: return MIJ_F420T_NT;
@@ -861,7 +885,31 @@ static int band_threads(int kind)
 	}
 }
 static bool fused440_wide(const mij_batch *b, const mij_image_desc &d) { return fused440_ok(b, d) && 3 * fused440_lds(d) > (size_t)b->ctx->max_dyn_lds; }
-static int fused440_kind(const mij_batch *b, const mij_image_desc &d) { return !fused440_ok(b, d) ? -1 : (fused440_wide(b, d) ? MK_440W : MK_440); }
+static int fused440_kind(const mij_batch *b, const mij_image_desc &d)
+{
+	return !fused440_ok(b, d) ? -1 : (fused440_lds(d) > (size_t)b->ctx->max_dyn_lds ? MK_440C : (fused440_wide(b, d) ? MK_440W : MK_440));
+}
+/* Column segments of a picture too wide for one workgroup's LDS (bytes_per_col per MCU column): the fewest segments, of equal width, of
+ * which two fit a CU with their two halo columns each.  Returns the segment count; segment k spans MCU columns [mcu_x * k / n, mcu_x * (k + 1) / n). */
+static int band_segments(const mij_batch *b, int mcu_x, size_t bytes_per_col)
+{
+	const int most = (int)((size_t)b->ctx->max_dyn_lds / bytes_per_col) - 2; /* what fits at all */
+	int fit = (int)((size_t)b->ctx->max_dyn_lds / (2 * bytes_per_col)) - 2;   /* two workgroups per CU (mij_kernels.h, k_fused420c) */
+	if (seg_max_cols() > 0)
+		fit = seg_max_cols() < most ? seg_max_cols() : most;
+	if (fit < 1)
+		return mcu_x; /* cannot happen with 160 KiB of LDS: one column per segment */
+	return (mcu_x + fit - 1) / fit;
+}
+static size_t band_segment_lds(int mcu_x, int nseg, size_t bytes_per_col)
+{
+	int widest = 0;
+	for (int k = 0; k < nseg; ++k) {
+		const int w = (int)((long)mcu_x * (k + 1) / nseg - (long)mcu_x * k / nseg);
+		widest = w > widest ? w : widest;
+	}
+	return (size_t)(widest + 2) * bytes_per_col;
+}
 
 extern "C" int mij_batch_upload(mij_batch *b)
 {
@@ -995,7 +1043,7 @@ extern "C" int mij_batch_upload(mij_batch *b)
 			/* up to 16 bands per picture; up to MIJ_BAND_CAP for 4:2:0 batches so small that sixteen bands each leave workgroup slots
 			 * empty (a lone picture from stbi_load, a handful): 16 x 1080p 0.078 -> 0.058 ms.  Not for 4:4:0, whose halo is a larger share
 			 * of a band (0.069 -> 0.093 ms), and not once the slots are full (36 x 5120 x 2880: 0.70 -> 0.73 ms with the higher cap). */
-			const int cap = (kind != MK_440 && kind != MK_440W && n_fused * 16 <= slots) ? MIJ_BAND_CAP : 16;
+			const int cap = (kind != MK_440 && kind != MK_440W && kind != MK_440C && n_fused * 16 <= slots) ? MIJ_BAND_CAP : 16;
 			for (int nb = 1; nb <= cap && nb <= (int)avg_rows; ++nb) {
 				const size_t wgs = n_fused * (size_t)nb;
 				const size_t rounds = (wgs + slots - 1) / slots;
@@ -1016,9 +1064,9 @@ extern "C" int mij_batch_upload(mij_batch *b)
 	int auto_nb[MK_KINDS];
 	for (int k = 0; k < MK_KINDS; ++k)
 		auto_nb[k] = 1;
-	for (int k : {MK_420, MK_420W, MK_420X, MK_420S, MK_420T})
+	for (int k : {MK_420, MK_420W, MK_420X, MK_420S, MK_420T, MK_420C})
 		auto_nb[k] = auto_bands(fused420_kind, k, fused420_lds);
-	for (int k : {MK_440, MK_440W})
+	for (int k : {MK_440, MK_440W, MK_440C})
 		auto_nb[k] = auto_bands(fused440_kind, k, fused440_lds);
 
 	for (size_t i = 0; i < n; ++i) {
@@ -1047,10 +1095,14 @@ extern "C" int mij_batch_upload(mij_batch *b)
 				nb = d.mcu_y;
 			if (nb < 1)
 				nb = 1;
+			const int nseg = mk == MK_420C ? band_segments(b, d.mcu_x, fused420_lds(d) / (size_t)d.mcu_x) : 1;
 			for (int k = 0; k < nb; ++k)
-				lists[mk][o4][wide][b8].push_back(Work4{(uint32_t)i, (uint32_t)((long)d.mcu_y * k / nb), (uint32_t)((long)d.mcu_y * (k + 1) / nb), 0u});
+				for (int g = 0; g < nseg; ++g) /* cols: only the column-segmented form reads it */
+					lists[mk][o4][wide][b8].push_back(Work4{(uint32_t)i, (uint32_t)((long)d.mcu_y * k / nb), (uint32_t)((long)d.mcu_y * (k + 1) / nb),
+																		 (uint32_t)((long)d.mcu_x * g / nseg) | (uint32_t)((long)d.mcu_x * (g + 1) / nseg) << 16});
 			size_t &l = lds_need[mk][o4][wide][b8];
-			l = fused420_lds(d) > l ? fused420_lds(d) : l;
+			const size_t need = mk == MK_420C ? band_segment_lds(d.mcu_x, nseg, fused420_lds(d) / (size_t)d.mcu_x) : fused420_lds(d);
+			l = need > l ? need : l;
 		} else if (fused_grey_ok(b, d)) {
 			s.path = 5;
 			per_blocks(lists[MK_GREY][0][wide][b8], 0);
@@ -1067,13 +1119,17 @@ extern "C" int mij_batch_upload(mij_batch *b)
 		} else if (fused440_ok(b, d)) {
 			s.path = 6;
 			const int mk = fused440_kind(b, d);
+			const int nseg = mk == MK_440C ? band_segments(b, d.mcu_x, fused440_lds(d) / (size_t)d.mcu_x) : 1;
 			size_t &l = lds_need[mk][o4][wide][b8];
-			l = fused440_lds(d) > l ? fused440_lds(d) : l;
+			const size_t need = mk == MK_440C ? band_segment_lds(d.mcu_x, nseg, fused440_lds(d) / (size_t)d.mcu_x) : fused440_lds(d);
+			l = need > l ? need : l;
 			/* band count by rounds of co-resident workgroups, as for 4:2:0 */
 			int nb = b->band_rows > 0 ? (d.mcu_y + b->band_rows - 1) / b->band_rows : auto_nb[mk];
 			nb = nb > d.mcu_y ? d.mcu_y : (nb < 1 ? 1 : nb);
 			for (int k = 0; k < nb; ++k)
-				lists[mk][o4][wide][b8].push_back(Work4{(uint32_t)i, (uint32_t)((long)d.mcu_y * k / nb), (uint32_t)((long)d.mcu_y * (k + 1) / nb), 0u});
+				for (int g = 0; g < nseg; ++g)
+					lists[mk][o4][wide][b8].push_back(Work4{(uint32_t)i, (uint32_t)((long)d.mcu_y * k / nb), (uint32_t)((long)d.mcu_y * (k + 1) / nb),
+																		 (uint32_t)((long)d.mcu_x * g / nseg) | (uint32_t)((long)d.mcu_x * (g + 1) / nseg) << 16});
 		} else if (fused444_ok(b, d)) {
 			s.path = 3;
 			per_blocks(lists[MK_444][o4][wide][b8], 0);
@@ -1284,6 +1340,12 @@ extern "C" int mij_batch_launch(mij_batch *b)
 			break;
 		case MK_440W:
 			MIJ_LAUNCH_NWB(k_fused440w, WorkBand, MIJ_COEF_OUT);
+			break;
+		case MK_420C:
+			MIJ_LAUNCH_NWB(k_fused420c, WorkBand, MIJ_COEF_OUT);
+			break;
+		case MK_440C:
+			MIJ_LAUNCH_NWB(k_fused440c, WorkBand, MIJ_COEF_OUT);
 			break;
 		case MK_444:
 			MIJ_LAUNCH_NWB(k_fused444, WorkIdct, MIJ_COEF_OUT);

@@ -199,16 +199,38 @@ def test_full_size_1080p_batch_properties(ica, oracle, gpu_ctx):
     b2.close()
 
 
-def test_wide_image_uses_whole_lds_or_two_pass(ica, oracle, gpu_ctx):
-    """4:2:0 images wider than the fused kernel's LDS budget fall to the two-pass kernels; the
-    widest that fits (5840 px -> 160 KiB) still runs fused.  Both exact."""
-    for w, path in ((5840, 1), (6000, 2)):
-        data = ica.synth_jpeg(w, 40, 9, 90)
-        b, slots = _batch_for(ica, gpu_ctx, [data], 3)
-        b.submit()
-        assert b.slot_path(slots[0]) == path, (w, b.slot_path(slots[0]))
-        assert np.array_equal(b.fetch(slots[0]), oracle.load(data, 3)[1]), w
-        b.close()
+def test_wide_images_take_the_band_kernel_in_column_segments(ica, oracle, gpu_ctx, monkeypatch):
+    """A row of 4:2:0 MCUs beyond 5840 pixels (4:4:0: 4300) does not fit the LDS of a CU: since round 3 such pictures are cut into column
+    segments, each transformed with one MCU column of halo on either side (k_fused420c / k_fused440c, fused_band SEG), instead of falling to
+    the two-pass kernels.  Widths on both sides of the switch and of the segment counts, odd and unaligned widths (the careful strips of the
+    last segment), pictures a few rows high and several bands high, both output widths, both plane formats, both producers: all equal to
+    the CPU checker, all on the fused path."""
+    import helpers
+    datas = []
+    for w, h, q in ((5840, 40, 90), (5841, 33, 90), (5856, 40, 90), (6000, 40, 90), (8191, 50, 85), (8192, 17, 90), (11615, 36, 90), (11616, 16, 80), (11632, 48, 90), (16385, 20, 90)):
+        datas.append(ica.synth_jpeg(w, h, w & 7, q))  # 4:2:0 (the writer's layout up to quality 90)
+    for w, h in ((4296, 40), (4312, 33), (6001, 24), (9000, 40)):  # 4:4:0: 304 B per 8 pixels, 538 MCU columns fit
+        plan, du = ica.host_transform(ica.synth_rgb(w, h, w & 7), 92)
+        datas.append(helpers.baseline_layout_from_444(plan, du, [(1, 2), (1, 1), (1, 1)], -1))
+    for req in (3, 4):
+        wants = [oracle.load(d, req)[1] for d in datas]
+        for band_rows, fmt, gpu_walk in ((0, "compact", False), (1, "int16", False), (0, "compact", True)):
+            if band_rows:
+                monkeypatch.setenv("MIJ_BAND_ROWS", str(band_rows))
+            else:
+                monkeypatch.delenv("MIJ_BAND_ROWS", raising=False)
+            b = ica.Batch(gpu_ctx, len(datas), 96 << 20, 96 << 20, 96 << 20)
+            b.set_coef_format(fmt)
+            if gpu_walk:
+                b.entropy_reserve(32 << 20)
+            ok, slots, reasons = b.decode_jpegs(datas, req, threads=2, gpu_entropy=gpu_walk)
+            assert ok == len(datas), reasons
+            b.submit()
+            for i, (s, want) in enumerate(zip(slots, wants)):
+                assert b.slot_path(s) in (1, 6), (i, b.slot_path(s))
+                got = b.fetch(s)
+                assert np.array_equal(got, want), (i, want.shape, req, band_rows, fmt, gpu_walk, int((got != want).sum()), np.argwhere((got != want).any(axis=2))[:4].tolist())
+            b.close()
 
 
 def test_band_kernels_by_workgroups_per_cu(ica, oracle, gpu_ctx, monkeypatch):
