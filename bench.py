@@ -42,6 +42,7 @@ The one JSON line (rank 0) also carries, all OUTSIDE the timed region and only a
   legs.config5          BASELINE configs[4]: 1024 x 1080p RGB -> data units (k_encode420), bytes == reference
   legs.config5_q95_444  the same at quality 95: the writer's 4:4:4 layout, 512 images (k_encode444), 9 B/px
   legs.h2v1             512 x 1080p 4:2:2 (k_fused422), 7 B/px
+  legs.wide_420         22 x 6000x4000 4:2:0: the band kernel in column segments (k_fused420c), and the two-pass kernels on the same pictures
   legs.config1          BASELINE configs[0]: one 512x512 4:2:0 JPEG per stbi_load_from_memory call (latency of the drop-in call)
   legs.two_pass         256 x 1080p through the two-pass family (sample planes in HBM, pass 2 compiled per resampler):
                         the headline images forced off the fused kernel, 4:4:0 fused and forced, Adobe CMYK through
@@ -613,6 +614,28 @@ def leg_h2v1(ica, ctx, args, checker):
     return res
 
 
+def leg_wide420(ica, ctx, args, checker):
+    """22 x 6000x4000 baseline 4:2:0 (a 24-megapixel camera file): a row of MCUs beyond the LDS of a CU, the band kernel in column
+    segments (k_fused420c, round 3) where the two-pass kernels ran before; the same pictures through those for comparison."""
+    n, w, h = 22, 6000, 4000
+    data = ica.synth_jpeg(w, h, 0, 90)
+    d = ica.HostDecoder.probe(data, 3)
+    cb, ob = ica.Batch.coef_bytes(d), ica.Batch.out_bytes(d)
+    blocks = sum(d.comp[c].bw * d.comp[c].bh for c in range(3))
+    algo = n * (128 * blocks + 3 * w * h)
+    out = {}
+    for name, generic, path in (("segments", 0, 1), ("two_pass", 1, 2)):
+        res, fmt = leg_decode_1080p(ica, ctx, [data], n, "compact", cb, ob, args, expect_path=path, checker=checker, generic=generic)
+        ms = res["kernel_ms_per_launch"]
+        res.pop("escaped_blocks_in_sources", None)
+        res.update({"mpix_s": round(n * w * h / ms / 1e3, 1), "frac": round(frac_of(algo, ms), 4)})
+        out[name] = res
+    res = out["segments"]
+    res.update({"workload": "%d x %dx%d baseline 4:2:0 q=90, coefficients resident" % (n, w, h), "kernel": "mij::k_fused420c<3,false,true>", "algorithmic_bytes_per_launch": algo,
+                "parity_against": checker[1], "two_pass_kernels_on_the_same_pictures": {k: out["two_pass"][k] for k in ("kernel_ms_per_launch", "mpix_s", "frac", "parity")}})
+    return res
+
+
 def leg_config1(ica, checker):
     """BASELINE configs[0]: ONE 512x512 baseline 4:2:0 q=90 JPEG through stbi_load_from_memory, the call a user of the reference
     makes -- bitstream in host memory -> malloc'ed pixels in host memory, per call: header parse, Huffman walk (on the GPU from
@@ -993,6 +1016,7 @@ def main():
         run_leg("config5", lambda: leg_config5(ica, ctx, args, checker))
         run_leg("config5_q95_444", lambda: leg_config5(ica, ctx, args, checker, quality=95, count=512))
         run_leg("h2v1", lambda: leg_h2v1(ica, ctx, args, checker))
+        run_leg("wide_420", lambda: leg_wide420(ica, ctx, args, checker))
         run_leg("two_pass", lambda: leg_two_pass(ica, ctx, datas, args, checker))
         run_leg("config1", lambda: leg_config1(ica, checker))
     if solo and not args.no_e2e:

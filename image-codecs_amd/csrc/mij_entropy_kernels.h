@@ -181,6 +181,10 @@ __device__ __forceinline__ int es_symbol_e(const EsTab &h, uint64_t win, uint32_
 		len = e >> 8;
 		return (int)(e & 255u);
 	}
+	if (MIJ_VARIANT & 2048) { /* ablation: what the search below costs (wrong symbols: timing only) */
+		len = 10;
+		return 0x11;
+	}
 	/* :219-221 "for (k = FAST_BITS+1;; ++k) if (temp < maxcode[k]) break": maxcode never decreases with the length
 	 * (each is (code + count) << 1 of the one before, left-aligned), so the first length that holds the prefix is
 	 * 10 + the number of shorter limits at or below it; maxcode[17] = 0xffffffff ends the count in a defined table */
