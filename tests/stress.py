@@ -88,6 +88,15 @@ def main():
                 w = (w + 3) & ~3  # multiples of four take the specialised pass 2 of the two-pass family
             h = int(rng.integers(1, 96)) if rng.random() < 0.3 else int(rng.integers(1, 500))
             q = int(rng.choice([1, 10, 35, 50, 75, 85, 90, 91, 95, 100]))
+            if rng.random() < 0.05:  # a row of MCUs beyond the LDS of a CU: the band kernels in column segments (round 3)
+                w, h = int(rng.integers(4200, 13000)), int(rng.integers(1, 56))
+                img = picture(rng, w, h)
+                if rng.random() < 0.5:
+                    datas.append(ica.stbi_write_jpg_to_memory(img, min(q, 90)))  # 4:2:0
+                else:
+                    plan, du = ica.host_transform(img, max(q, 91))
+                    datas.append(helpers.baseline_layout_from_444(plan, du, [(1, 2), (1, 1), (1, 1)], -1, int(rng.choice([0, 0, 7]))))  # 4:4:0
+                continue
             img = picture(rng, w, h)
             layout = int(rng.integers(0, 12))
             if layout <= 1:
