@@ -168,6 +168,24 @@ struct EsPair {
 	uint8_t slot[8]; /* table index 0..7 -> 0 / 1 (its pair table) or 255 (none: a DC table, or a third AC table) */
 };
 
+/* Round 3, second session: the state-only passes look EVERY symbol up in one table chosen by data -- the block's AC table by the next
+ * twelve bits of the stream, its DC table by the next nine -- with one entry format, so that a loop iteration is one LDS read, a few
+ * field extractions and one window update whatever the 64 lanes of the wavefront are standing at.  Until then an iteration carried the
+ * pair lookup, the nine-bit lookup of the ordinary path (the only one DC terms and long AC symbols had) and, whenever one lane of the
+ * wave met a code longer than nine bits, the reference's fifty-instruction search.
+ *   0                 not here (a code longer than the index, a non-code, a pair that may not be taken): es_state_slow
+ *   bit 15 clear      one symbol:  bits [0:5) = code + extra bits (up to 27), [5:10) = positions it moves on, bit 10 = it ends the block
+ *                     (EOB); a DC symbol moves one position
+ *   bit 15 set        two AC symbols (EsPair's format): bits [0:4) = bits of both, [4:9) = positions of the first, [9:14) of the second,
+ *                     bit 14 = the second is an EOB
+ * A single AC symbol only needs its CODE inside the twelve bits: what the extra bits are does not matter to the state. */
+#define MIJ_ES_DC_BITS 9u
+struct EsUni {
+	uint16_t ac[2][1u << MIJ_ES_PAIR_BITS];
+	uint16_t dc[2][1u << MIJ_ES_DC_BITS];
+	uint16_t off[12]; /* block-in-MCU -> index of its AC table's first entry in ac[][] (0 or 4096) | 0x8000 if it has none; bits 13-14: the same for dc[][] (0 / 1, 3 = none) */
+};
+
 /* codec/jpeg.c:193-243: returns the symbol and its code length, or -1 */
 __device__ __forceinline__ int es_symbol_e(const EsTab &h, uint64_t win, uint32_t e, uint32_t &len); /* the same with the fast-table entry already fetched */
 __device__ __forceinline__ int es_symbol(const EsTab &h, uint64_t win, uint32_t &len)
@@ -514,6 +532,71 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &
 	return done;
 }
 
+/* The state-only passes' walk (EsUni): from state s until the bit position reaches p_end (a symbol that starts before p_end is finished, a pair
+ * is only taken when both of its symbols END by p_end -- otherwise the first goes alone and the loop decides about the second: what
+ * es_decode<true> does with its pairs, so the hand-over states agree).  Returns the number of blocks completed.  On a true state of a
+ * stream the write pass accepts, every symbol moves the state exactly as es_decode<true> moves it; on guessed states any deterministic
+ * walk will do, and this one slips a bit at a non-code like the ordinary path. */
+__device__ __forceinline__ uint32_t es_state_walk(const DevScan &sc, const EsLocal &loc, const EsTab *__restrict__ tabs, const EsUni &un, const uint8_t *__restrict__ stream,
+																  EsState &s, uint32_t p_end)
+{
+	uint32_t done = 0, guard = 0;
+	const uint32_t limit = sc.nbits + 64u, bpm = sc.bpm;
+	const uint16_t *__restrict__ u16 = &un.ac[0][0]; /* ac[2][4096], then dc[2][512] */
+	EsBits br;
+	br.start(stream, s.p);
+	uint32_t off = un.off[s.c];
+	while (s.p < p_end && s.z != MIJ_ES_DEAD) {
+		if (++guard > MIJ_ES_BITS + 64u) { /* every iteration takes at least one bit: cannot happen, but a wave must always end */
+			s.z = MIJ_ES_DEAD;
+			break;
+		}
+		const uint32_t hi = (uint32_t)(br.win >> 32);
+		const bool isdc = s.z == 0;
+		const uint32_t sd = off >> 13 & 3u;
+		const uint32_t idx = isdc ? (2u << MIJ_ES_PAIR_BITS) + ((sd & 1u) << MIJ_ES_DC_BITS) + (hi >> (32u - MIJ_ES_DC_BITS)) : (off & (1u << MIJ_ES_PAIR_BITS)) + (hi >> (32u - MIJ_ES_PAIR_BITS));
+		const bool have = isdc ? sd < 2u : !(off & 0x8000u);
+		const uint32_t e = have ? u16[idx] : 0u;
+		const bool pair = (e & 0x8000u) != 0;
+		const uint32_t a1 = (e >> 4) & 31u;
+		const bool two = pair && s.z + a1 < 64u && s.p + (e & 15u) <= p_end;
+		const bool one = e != 0u && !pair;
+		uint32_t bits, znew;
+		if (two || one) {
+			bits = pair ? (e & 15u) : (e & 31u);
+			znew = pair ? ((e & 0x4000u) ? 64u : s.z + a1 + ((e >> 9) & 31u)) : ((e & 0x400u) ? 64u : s.z + ((e >> 5) & 31u));
+		} else { /* a code longer than the index, a table without entries, a pair that may not be taken, a non-code: one symbol by the reference's search */
+			const uint32_t tb = loc.tabs[s.c];
+			const EsTab &htab = tabs[isdc ? (tb >> 8) & 255u : tb >> 16];
+			uint32_t len = 0;
+			const int sym = es_symbol(htab, br.win, len);
+			if (sym < 0 || len == 0 || (isdc && sym > 11)) { /* a guessed start ran into a non-code: slip one bit and keep looking for the true sequence */
+				bits = 1;
+				znew = s.z;
+			} else {
+				const uint32_t n = isdc ? (uint32_t)sym : ((uint32_t)sym & 15u), r = (uint32_t)sym >> 4;
+				bits = len + n;
+				znew = isdc ? 1u : (n ? s.z + r + 1u : (r == 15u ? s.z + 16u : 64u)); /* a run past coefficient 63 ends the block like the ordinary path's k > 63 */
+			}
+		}
+		s.p += bits;
+		br.take(bits);
+		s.z = znew;
+		if (s.z >= 64u) { /* block complete */
+			s.z = 0;
+			++done;
+			if (++s.c == bpm)
+				s.c = 0;
+			off = un.off[s.c];
+		}
+		if (s.p > limit) {
+			s.z = MIJ_ES_DEAD;
+			break;
+		}
+	}
+	return done;
+}
+
 /* every kernel below: grid.x = blocks of MIJ_ES_WG subsequences over a (scan, first subsequence) work list */
 struct EsWork {
 	uint32_t scan, first;
@@ -522,8 +605,9 @@ struct EsWork {
 /* the scan's eight Huffman tables and its EsLocal into LDS (im == nullptr: no block placement needed); ends in a barrier */
 /* pr != nullptr: also the pair tables (EsPair); for_write: in the write pass's format -- the SECOND symbol behind the one the
  * window starts with, as code length << 12 | symbol << 4 | bits of the first symbol (0: no second symbol inside the window) */
+__device__ __forceinline__ void es_build_uni(const DevScan &sc, const EsTab *l, EsUni *un);
 __device__ __forceinline__ void es_load_tables(const DevScan &sc, const DevImage *im, const DevHuff *__restrict__ g, EsTab *l, EsLocal *loc, EsPair *pr = nullptr,
-																bool for_write = false)
+																bool for_write = false, EsUni *un = nullptr)
 {
 	for (uint32_t i = threadIdx.x; i < 8u * 512u; i += blockDim.x) {
 		const DevHuff &h = g[i >> 9];
@@ -590,6 +674,66 @@ __device__ __forceinline__ void es_load_tables(const DevScan &sc, const DevImage
 		}
 		__syncthreads();
 	}
+	if (un)
+		es_build_uni(sc, l, un);
+}
+
+/* EsUni from the tables already in LDS (after es_load_tables' barrier); ends in a barrier */
+__device__ __forceinline__ void es_build_uni(const DevScan &sc, const EsTab *l, EsUni *un)
+{
+	/* the (at most two) AC and DC tables of the scan's components, in order of first use; a third one has no entry table (es_state_slow) */
+	uint32_t ua[2] = {255u, 255u}, ud[2] = {255u, 255u}, na = 0, nd = 0;
+	for (uint32_t c = 0; c < 4u; ++c) {
+		const uint32_t ta = sc.ac_tab[c] & 7u, td = sc.dc_tab[c] & 7u;
+		if (ta != ua[0] && ta != ua[1] && na < 2u)
+			ua[na++] = ta;
+		if (td != ud[0] && td != ud[1] && nd < 2u)
+			ud[nd++] = td;
+	}
+	if (threadIdx.x < 12u) {
+		const uint32_t ci = sc.blk_comp[threadIdx.x] & 3u, ta = sc.ac_tab[ci] & 7u, td = sc.dc_tab[ci] & 7u;
+		const uint32_t sa = ta == ua[0] ? 0u : (ta == ua[1] ? 1u : 2u), sd = td == ud[0] ? 0u : (td == ud[1] ? 1u : 3u);
+		un->off[threadIdx.x] = (uint16_t)((sa < 2u ? sa << MIJ_ES_PAIR_BITS : 0x8000u) | sd << 13);
+	}
+	for (uint32_t i = threadIdx.x; i < 2u << MIJ_ES_PAIR_BITS; i += blockDim.x) {
+		const uint32_t k = i >> MIJ_ES_PAIR_BITS, w = i & ((1u << MIJ_ES_PAIR_BITS) - 1u);
+		uint32_t e = 0;
+		if (ua[k] != 255u) {
+			const EsTab &h = l[ua[k]];
+			uint32_t len1 = 0;
+			const int s1 = es_symbol(h, (uint64_t)w << (64u - MIJ_ES_PAIR_BITS), len1);
+			const uint32_t n1 = (uint32_t)s1 & 15u, r1 = ((uint32_t)s1 >> 4) & 15u, bits1 = len1 + n1;
+			if (s1 >= 0 && len1 && len1 <= MIJ_ES_PAIR_BITS) { /* the code lies inside the index: its extra bits may reach past it */
+				const uint32_t eob1 = (!n1 && r1 != 15u) ? 1u : 0u, adv1 = eob1 ? 0u : (n1 ? r1 + 1u : 16u);
+				e = bits1 | adv1 << 5 | eob1 << 10;
+				if (!eob1 && bits1 < MIJ_ES_PAIR_BITS) {
+					const uint32_t rem = MIJ_ES_PAIR_BITS - bits1;
+					uint32_t len2 = 0;
+					const int s2 = es_symbol(h, (uint64_t)w << (64u - MIJ_ES_PAIR_BITS + bits1), len2);
+					const uint32_t n2 = (uint32_t)s2 & 15u, r2 = ((uint32_t)s2 >> 4) & 15u;
+					if (s2 >= 0 && len2 && len2 + n2 <= rem) {
+						const uint32_t eob2 = (!n2 && r2 != 15u) ? 1u : 0u, adv2 = eob2 ? 0u : (n2 ? r2 + 1u : 16u);
+						e = 0x8000u | (bits1 + len2 + n2) | adv1 << 4 | adv2 << 9 | eob2 << 14;
+					}
+				}
+			}
+		}
+		un->ac[k][w] = (uint16_t)e;
+	}
+	for (uint32_t i = threadIdx.x; i < 2u << MIJ_ES_DC_BITS; i += blockDim.x) {
+		const uint32_t k = i >> MIJ_ES_DC_BITS, w = i & ((1u << MIJ_ES_DC_BITS) - 1u);
+		uint32_t e = 0;
+		if (ud[k] != 255u) {
+			const EsTab &h = l[ud[k]];
+			uint32_t len = 0;
+			const int sy = es_symbol(h, (uint64_t)w << (64u - MIJ_ES_DC_BITS), len);
+			/* DC: the reference takes categories up to 16; nothing a conforming stream uses beyond 11 (es_state_slow slips a bit there, like the ordinary path) */
+			if (sy >= 0 && len && len <= MIJ_ES_DC_BITS && sy <= 11)
+				e = (len + (uint32_t)sy) | 1u << 5;
+		}
+		un->dc[k][w] = (uint16_t)e;
+	}
+	__syncthreads();
 }
 
 MIJ_ES_KERNEL void k_es_cold(const DevScan *__restrict__ scans, const EsWork *__restrict__ work, const DevHuff *__restrict__ huff,
@@ -597,10 +741,10 @@ MIJ_ES_KERNEL void k_es_cold(const DevScan *__restrict__ scans, const EsWork *__
 {
 	__shared__ EsTab tabs[8];
 	__shared__ EsLocal loc;
-	__shared__ EsPair pair;
+	__shared__ EsUni uni;
 	const EsWork wk = work[blockIdx.x];
 	const DevScan &sc = scans[wk.scan];
-	es_load_tables(sc, nullptr, huff + sc.tab_off, tabs, &loc, MIJ_ES_PAIR ? &pair : nullptr);
+	es_load_tables(sc, nullptr, huff + sc.tab_off, tabs, &loc, nullptr, false, &uni);
 	const uint32_t i = wk.first + threadIdx.x;
 	if (i >= sc.nsub)
 		return;
@@ -610,7 +754,7 @@ MIJ_ES_KERNEL void k_es_cold(const DevScan *__restrict__ scans, const EsWork *__
 	s.c = 0;
 	start[sc.sub_off + i] = es_pack(s);
 	const uint32_t pe = min((i + 1u) * sc.sub_bits, sc.nbits);
-	cnt[sc.sub_off + i] = es_decode<false, MIJ_ES_PAIR != 0>(sc, loc, tabs, streams + sc.stream_off, s, pe, nullptr, nullptr, &pair);
+	cnt[sc.sub_off + i] = es_state_walk(sc, loc, tabs, uni, streams + sc.stream_off, s, pe);
 	end[sc.sub_off + i] = es_pack(s);
 }
 
@@ -644,7 +788,7 @@ MIJ_ES_KERNEL void k_es_sync(const DevScan *__restrict__ scans, const EsWork *__
 {
 	__shared__ EsTab tabs[8];
 	__shared__ EsLocal loc;
-	__shared__ EsPair pair;
+	__shared__ EsUni uni;
 	const EsWork wk = work[blockIdx.x];
 	const DevScan &sc = scans[wk.scan];
 	const uint32_t i = wk.first + threadIdx.x;
@@ -662,13 +806,13 @@ MIJ_ES_KERNEL void k_es_sync(const DevScan *__restrict__ scans, const EsWork *__
 	}
 	if (!__syncthreads_or(redo ? 1 : 0))
 		return;
-	es_load_tables(sc, nullptr, huff + sc.tab_off, tabs, &loc, MIJ_ES_PAIR ? &pair : nullptr);
+	es_load_tables(sc, nullptr, huff + sc.tab_off, tabs, &loc, nullptr, false, &uni);
 	if (!redo)
 		return;
 	start[slot] = want;
 	EsState s = es_unpack(want);
 	const uint32_t pe = min((i + 1u) * sc.sub_bits, sc.nbits);
-	cnt[slot] = es_decode<false, MIJ_ES_PAIR != 0>(sc, loc, tabs, streams + sc.stream_off, s, pe, nullptr, nullptr, &pair);
+	cnt[slot] = es_state_walk(sc, loc, tabs, uni, streams + sc.stream_off, s, pe);
 	const uint64_t now = es_pack(s);
 	end_out[slot] = now;
 	es_push(i + 1u < sc.nsub && now != was, i + 1u, now, sc.sub_off, &pending[wk.scan], qidx, qstate);
@@ -685,13 +829,13 @@ MIJ_ES_KERNEL void k_es_syncq(const DevScan *__restrict__ scans, const EsWork *_
 {
 	__shared__ EsTab tabs[8];
 	__shared__ EsLocal loc;
-	__shared__ EsPair pair;
+	__shared__ EsUni uni;
 	const EsWork wk = work[blockIdx.x];
 	const uint32_t n = n_in[wk.scan];
 	if (wk.first >= n) /* most workgroups, from the second round on: gone before the tables are copied */
 		return;
 	const DevScan &sc = scans[wk.scan];
-	es_load_tables(sc, nullptr, huff + sc.tab_off, tabs, &loc, MIJ_ES_PAIR ? &pair : nullptr);
+	es_load_tables(sc, nullptr, huff + sc.tab_off, tabs, &loc, nullptr, false, &uni);
 	const uint32_t t = wk.first + threadIdx.x;
 	if (t >= n)
 		return;
@@ -703,7 +847,7 @@ MIJ_ES_KERNEL void k_es_syncq(const DevScan *__restrict__ scans, const EsWork *_
 	start[slot] = want;
 	EsState s = es_unpack(want);
 	const uint32_t pe = min((i + 1u) * sc.sub_bits, sc.nbits);
-	cnt[slot] = es_decode<false, MIJ_ES_PAIR != 0>(sc, loc, tabs, streams + sc.stream_off, s, pe, nullptr, nullptr, &pair);
+	cnt[slot] = es_state_walk(sc, loc, tabs, uni, streams + sc.stream_off, s, pe);
 	const uint64_t now = es_pack(s), was = end[slot];
 	end[slot] = now;
 	es_push(i + 1u < sc.nsub && now != was, i + 1u, now, sc.sub_off, &pending[wk.scan], qidx, qstate);
