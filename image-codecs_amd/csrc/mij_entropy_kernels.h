@@ -148,19 +148,14 @@ struct EsTab {
 	__attribute__((aligned(16))) int32_t delta[8];
 };
 
-/* The passes that only track the decoder's state (k_es_cold, k_es_sync) do not need coefficient values: what an AC symbol
- * does to the state is "so many bits, so many positions, or end of block".  For the two AC tables a scan normally uses, a
- * second table indexed by the next MIJ_ES_PAIR_BITS bits of the stream folds TWO consecutive AC symbols (code + extra bits of the
- * first, code + extra bits of the second) into one 16-bit entry whenever both lie inside the window -- at the benchmark's
- * 1.8 bit/px that is most pairs -- so the serial chain lookup -> shift -> lookup runs half as often:
- *   0                          no entry (long code, or the first symbol alone leaves the window): the ordinary path
- *   bit 15 clear               one symbol:  bits [0:4) = code + extra bits, [4:11) = positions (64 = EOB)
- *   bit 15 set                 two symbols: bits [0:4) = bits of both, [4:9) = positions of the first, [9:14) of the second,
- *                              bit 14 = the second is an EOB
- * A pair is only taken when the first symbol leaves the block open and the second starts before the subsequence ends, i.e.
- * exactly when the one-symbol loop would decode both: the hand-over states between subsequences do not change. */
+/* Pair tables: a table indexed by the next MIJ_ES_PAIR_BITS bits of the stream folds TWO consecutive AC symbols (code + extra bits of the
+ * first, code + extra bits of the second) into one 16-bit entry whenever both lie inside the window -- at the benchmark's 1.8 bit/px that
+ * is most pairs -- so the serial chain lookup -> shift -> lookup runs half as often.  The state-only passes have their form of it in
+ * EsUni below (round 2 kept it here); the write pass's form (EsPair, for_write in es_load_tables) holds per window the SECOND symbol behind
+ * the one the window starts with.  A pair is only taken when the first symbol leaves the block open and the second starts before the
+ * subsequence ends, i.e. exactly when the one-symbol loop would decode both: the hand-over states between subsequences do not change. */
 #define MIJ_ES_PAIR_BITS 12u
-#ifndef MIJ_ES_PAIR /* A/B switch: 0 = the state-only passes decode one symbol per iteration like the write pass */
+#ifndef MIJ_ES_PAIR /* A/B switch: 0 = the write pass decodes one symbol per iteration */
 #define MIJ_ES_PAIR 1
 #endif
 struct EsPair {
@@ -178,13 +173,16 @@ struct EsPair {
  *                     (EOB); a DC symbol moves one position
  *   bit 15 set        two AC symbols (EsPair's format): bits [0:4) = bits of both, [4:9) = positions of the first, [9:14) of the second,
  *                     bit 14 = the second is an EOB
+ * (the first symbol of a pair is never an EOB, and a ZRL moves sixteen positions)
  * A single AC symbol only needs its CODE inside the twelve bits: what the extra bits are does not matter to the state. */
 #define MIJ_ES_DC_BITS 9u
 struct EsUni {
 	uint16_t ac[2][1u << MIJ_ES_PAIR_BITS];
 	uint16_t dc[2][1u << MIJ_ES_DC_BITS];
-	uint16_t off[12]; /* block-in-MCU -> index of its AC table's first entry in ac[][] (0 or 4096) | 0x8000 if it has none; bits 13-14: the same for dc[][] (0 / 1, 3 = none) */
+	uint16_t zero[2];  /* entry 0: where the index of a table without entries is clamped to (MIJ_ES_UNI_ZERO) */
+	uint32_t base[12]; /* block-in-MCU -> index (in uint16 units from ac[0][0]) of its AC table's first entry | its DC table's << 16; 0xffff: no entries */
 };
+#define MIJ_ES_UNI_ZERO ((2u << MIJ_ES_PAIR_BITS) + (2u << MIJ_ES_DC_BITS))
 
 /* codec/jpeg.c:193-243: returns the symbol and its code length, or -1 */
 __device__ __forceinline__ int es_symbol_e(const EsTab &h, uint64_t win, uint32_t e, uint32_t &len); /* the same with the fast-table entry already fetched */
@@ -345,18 +343,18 @@ struct EsWriter { /* where the blocks of the write pass go */
  * WRITE = false: only the state and the number of completed blocks.  WRITE = true: coefficients are stored,
  * decoding stops at block ordinal sc.nblocks, malformed input sets *anom.
  */
-template <bool WRITE, bool PAIR = false, bool PAIRW = false>
+template <bool WRITE, bool PAIRW = false>
 __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &loc, const EsTab *__restrict__ tabs, const uint8_t *__restrict__ stream, EsState &s,
 															 uint32_t p_end, EsWriter *wr, uint32_t *anom, const EsPair *__restrict__ pr = nullptr)
 {
-	static_assert(!(WRITE && PAIR) && !(PAIRW && !WRITE), "PAIR: the state-only passes' pair table; PAIRW: the write pass's");
+	static_assert(!(PAIRW && !WRITE), "PAIRW: the write pass's pair table");
 	uint32_t done = 0, guard = 0;
 	const uint32_t limit = sc.nbits + 64u; /* the arena is zero padded: never read far past the data */
 	EsBits br;
 	br.start(stream, s.p);
 	uint32_t tb = loc.tabs[s.c]; /* the current block's component and tables; changes with s.c only */
 	const uint16_t *t2cur = nullptr; /* the pair table of the block's AC table (state-only passes), off the per-symbol chain */
-	if (PAIR || PAIRW) {
+	if (PAIRW) {
 		const uint32_t slot = pr->slot[tb >> 16];
 		t2cur = slot < 2u ? pr->t2[slot] : nullptr;
 	}
@@ -372,45 +370,12 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &
 			break;
 		const uint64_t win = br.win;
 		const bool isdc = s.z == 0;
-		bool paired = false;
 		/* both lookups leave together (one LDS round trip on the serial chain, not two): the ordinary fast-table entry of the
 		 * table this symbol uses, and -- state-only passes -- the pair entry of the block's AC table */
 		const EsTab &htab = tabs[isdc ? (tb >> 8) & 255u : tb >> 16];
 		const uint32_t e9 = htab.fast16[(uint32_t)(win >> 55)];
 		const uint32_t e2w = (PAIRW && t2cur && !isdc) ? t2cur[(uint32_t)(win >> (64u - MIJ_ES_PAIR_BITS))] : 0u;
-		if (PAIR) {
-			/* State-only pass: what this iteration consumes (bits) and where it leaves the block (znew) come out of selects over the
-			 * three sources -- pair entry, one-symbol entry, ordinary fast-table entry -- and ONE window update follows; only a code
-			 * longer than nine bits or a non-code leaves this path (the ordinary code below).  The lanes of a wave sit in all three
-			 * cases all the time, so three branches would each run on every iteration. */
-			const uint32_t e = (t2cur && !isdc) ? t2cur[(uint32_t)(win >> (64u - MIJ_ES_PAIR_BITS))] : 0u;
-			const uint32_t a1 = (e >> 4) & 31u;
-			const bool two = (e & 0x8000u) && s.z + a1 < 64u && s.p + (e & 15u) <= p_end;
-			const bool one = e && !(e & 0x8000u);
-			uint32_t len9 = e9 >> 8, sym9 = e9 & 255u;
-			bool fast = e9 != 0xffffu;
-			if (!two && !one && !fast) { /* a code longer than nine bits outside the pair table: the reference's slow path, then the same update */
-				const int sl = es_symbol_e(htab, win, e9, len9);
-				sym9 = (uint32_t)sl & 255u;
-				fast = sl >= 0;
-			}
-			const uint32_t n9 = isdc ? sym9 : (sym9 & 15u), r9 = sym9 >> 4;
-			fast = fast && len9 && !(isdc && sym9 > 11u);
-			if (two || one || fast) {
-				const uint32_t z9 = isdc ? 1u : (n9 ? s.z + r9 + 1u : (r9 == 15u ? s.z + 16u : 64u));
-				const uint32_t bits = two ? (e & 15u) : (one ? (e & 15u) : len9 + n9);
-				const uint32_t znew = two ? ((e & 0x4000u) ? 64u : s.z + a1 + ((e >> 9) & 31u)) : (one ? s.z + ((e >> 4) & 127u) : z9);
-				s.p += bits;
-				br.take(bits);
-				s.z = znew;
-				paired = true;
-			} else { /* a guessed start ran into a non-code: slip one bit and keep looking for the true sequence */
-				s.p += 1;
-				br.take(1);
-				continue;
-			}
-		}
-		if (!PAIR && !paired) {
+		{
 		uint32_t len = 0;
 		const int sym = es_symbol_e(htab, win, e9, len);
 		/* DC: the reference takes categories up to 16; nothing a conforming stream uses beyond 11 */
@@ -486,7 +451,7 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &
 		}
 		if (PAIRW)
 			br.take(used);
-		} /* !paired */
+		}
 		if (s.z >= 64u) { /* block complete (ZRL past the end ends it too: same as the host loop's k < 64 test) */
 			s.z = 0;
 			++done;
@@ -515,7 +480,7 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &
 				}
 			}
 			tb = loc.tabs[s.c];
-			if (PAIR || PAIRW) {
+			if (PAIRW) {
 				const uint32_t slot = pr->slot[tb >> 16];
 				t2cur = slot < 2u ? pr->t2[slot] : nullptr;
 			}
@@ -540,32 +505,30 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &
 __device__ __forceinline__ uint32_t es_state_walk(const DevScan &sc, const EsLocal &loc, const EsTab *__restrict__ tabs, const EsUni &un, const uint8_t *__restrict__ stream,
 																  EsState &s, uint32_t p_end)
 {
-	uint32_t done = 0, guard = 0;
-	const uint32_t limit = sc.nbits + 64u, bpm = sc.bpm;
+	uint32_t done = 0;
+	const uint32_t bpm = sc.bpm;
 	const uint16_t *__restrict__ u16 = &un.ac[0][0]; /* ac[2][4096], then dc[2][512] */
 	EsBits br;
 	br.start(stream, s.p);
-	uint32_t off = un.off[s.c];
-	while (s.p < p_end && s.z != MIJ_ES_DEAD) {
-		if (++guard > MIJ_ES_BITS + 64u) { /* every iteration takes at least one bit: cannot happen, but a wave must always end */
-			s.z = MIJ_ES_DEAD;
-			break;
-		}
+	uint32_t base = un.base[s.c];
+	/* every iteration takes at least one bit (an entry holds a whole symbol, the search a code or a slipped bit), so the position alone
+	 * ends the loop: no iteration guard, and no state here is ever MIJ_ES_DEAD (only the write pass makes that one) */
+	while (s.p < p_end) {
 		const uint32_t hi = (uint32_t)(br.win >> 32);
 		const bool isdc = s.z == 0;
-		const uint32_t sd = off >> 13 & 3u;
-		const uint32_t idx = isdc ? (2u << MIJ_ES_PAIR_BITS) + ((sd & 1u) << MIJ_ES_DC_BITS) + (hi >> (32u - MIJ_ES_DC_BITS)) : (off & (1u << MIJ_ES_PAIR_BITS)) + (hi >> (32u - MIJ_ES_PAIR_BITS));
-		const bool have = isdc ? sd < 2u : !(off & 0x8000u);
-		const uint32_t e = have ? u16[idx] : 0u;
-		const bool pair = (e & 0x8000u) != 0;
+		/* a table without entries has base 0xffff: the index lands beyond the tables and is clamped to the zero entry */
+		const uint32_t idx = min(isdc ? (base >> 16) + (hi >> (32u - MIJ_ES_DC_BITS)) : (base & 0xffffu) + (hi >> (32u - MIJ_ES_PAIR_BITS)), MIJ_ES_UNI_ZERO);
+		const uint32_t e = u16[idx];
+		/* everything by selects (bitwise on the comparison results: no short-circuit, no divergent branches): the lanes of a wave sit in
+		 * both entry formats all the time.  one symbol: bits [0:5), positions [5:10), EOB bit 10; two: bits [0:4), positions [4:9) + [9:14), EOB bit 14 */
+		const uint32_t pair = e >> 15;
 		const uint32_t a1 = (e >> 4) & 31u;
-		const bool two = pair && s.z + a1 < 64u && s.p + (e & 15u) <= p_end;
-		const bool one = e != 0u && !pair;
-		uint32_t bits, znew;
-		if (two || one) {
-			bits = pair ? (e & 15u) : (e & 31u);
-			znew = pair ? ((e & 0x4000u) ? 64u : s.z + a1 + ((e >> 9) & 31u)) : ((e & 0x400u) ? 64u : s.z + ((e >> 5) & 31u));
-		} else { /* a code longer than the index, a table without entries, a pair that may not be taken, a non-code: one symbol by the reference's search */
+		const uint32_t bits_e = e & (pair ? 15u : 31u);
+		const uint32_t adv = pair ? a1 + ((e >> 9) & 31u) : (e >> 5) & 31u;
+		const uint32_t ends = e & (pair ? 0x4000u : 0x400u);
+		const uint32_t ok = pair ? (uint32_t)(s.z + a1 < 64u) & (uint32_t)(s.p + bits_e <= p_end) : (uint32_t)(e != 0u);
+		uint32_t bits = bits_e, znew = ends ? 64u : s.z + adv;
+		if (!ok) { /* a code longer than the index, a table without entries, a pair that may not be taken, a non-code: one symbol by the reference's search */
 			const uint32_t tb = loc.tabs[s.c];
 			const EsTab &htab = tabs[isdc ? (tb >> 8) & 255u : tb >> 16];
 			uint32_t len = 0;
@@ -587,11 +550,7 @@ __device__ __forceinline__ uint32_t es_state_walk(const DevScan &sc, const EsLoc
 			++done;
 			if (++s.c == bpm)
 				s.c = 0;
-			off = un.off[s.c];
-		}
-		if (s.p > limit) {
-			s.z = MIJ_ES_DEAD;
-			break;
+			base = un.base[s.c];
 		}
 	}
 	return done;
@@ -692,9 +651,11 @@ __device__ __forceinline__ void es_build_uni(const DevScan &sc, const EsTab *l, 
 	}
 	if (threadIdx.x < 12u) {
 		const uint32_t ci = sc.blk_comp[threadIdx.x] & 3u, ta = sc.ac_tab[ci] & 7u, td = sc.dc_tab[ci] & 7u;
-		const uint32_t sa = ta == ua[0] ? 0u : (ta == ua[1] ? 1u : 2u), sd = td == ud[0] ? 0u : (td == ud[1] ? 1u : 3u);
-		un->off[threadIdx.x] = (uint16_t)((sa < 2u ? sa << MIJ_ES_PAIR_BITS : 0x8000u) | sd << 13);
+		const uint32_t sa = ta == ua[0] ? 0u : (ta == ua[1] ? 1u : 2u), sd = td == ud[0] ? 0u : (td == ud[1] ? 1u : 2u);
+		un->base[threadIdx.x] = (sa < 2u ? sa << MIJ_ES_PAIR_BITS : 0xffffu) | (sd < 2u ? (2u << MIJ_ES_PAIR_BITS) + (sd << MIJ_ES_DC_BITS) : 0xffffu) << 16;
 	}
+	if (threadIdx.x < 2u)
+		un->zero[threadIdx.x] = 0;
 	for (uint32_t i = threadIdx.x; i < 2u << MIJ_ES_PAIR_BITS; i += blockDim.x) {
 		const uint32_t k = i >> MIJ_ES_PAIR_BITS, w = i & ((1u << MIJ_ES_PAIR_BITS) - 1u);
 		uint32_t e = 0;
@@ -942,7 +903,7 @@ MIJ_ES_KERNEL void k_es_write(const DevScan *__restrict__ scans, const EsWork *_
 	if (!sc.fmt)
 		wr.locate(s.c);
 	const uint32_t pe = min((i + 1u) * sc.sub_bits, sc.nbits);
-	es_decode<true, false, MIJ_ES_PAIR != 0>(sc, loc, tabs, streams + sc.stream_off, s, pe, &wr, &anom[wk.scan], &pair);
+	es_decode<true, MIJ_ES_PAIR != 0>(sc, loc, tabs, streams + sc.stream_off, s, pe, &wr, &anom[wk.scan], &pair);
 }
 
 /* the rest of every block that began in the previous subsequence: single coefficients into the block that the
