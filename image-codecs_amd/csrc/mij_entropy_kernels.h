@@ -176,7 +176,7 @@ struct EsPair {
  * (the first symbol of a pair is never an EOB, and a ZRL moves sixteen positions)
  * A single AC symbol only needs its CODE inside the twelve bits: what the extra bits are does not matter to the state. */
 #define MIJ_ES_DC_BITS 9u
-struct EsUni {
+struct __attribute__((aligned(16))) EsUni { /* a multiple of 16 bytes: copied as uint4 (k_es_tables -> global -> LDS) */
 	uint16_t ac[2][1u << MIJ_ES_PAIR_BITS];
 	uint16_t dc[2][1u << MIJ_ES_DC_BITS];
 	uint16_t zero[2];  /* entry 0: where the index of a table without entries is clamped to (MIJ_ES_UNI_ZERO) */
@@ -565,9 +565,15 @@ struct EsWork {
 /* pr != nullptr: also the pair tables (EsPair); for_write: in the write pass's format -- the SECOND symbol behind the one the
  * window starts with, as code length << 12 | symbol << 4 | bits of the first symbol (0: no second symbol inside the window) */
 __device__ __forceinline__ void es_build_uni(const DevScan &sc, const EsTab *l, EsUni *un);
+/* un: the state-only passes' entry tables, copied from uni_src (what k_es_tables built for the picture's table set) or built here */
 __device__ __forceinline__ void es_load_tables(const DevScan &sc, const DevImage *im, const DevHuff *__restrict__ g, EsTab *l, EsLocal *loc, EsPair *pr = nullptr,
-																bool for_write = false, EsUni *un = nullptr)
+																bool for_write = false, EsUni *un = nullptr, const uint4 *__restrict__ uni_src = nullptr)
 {
+	if (un && uni_src) {
+		uint4 *dst = reinterpret_cast<uint4 *>(un);
+		for (uint32_t i = threadIdx.x; i < sizeof(EsUni) / 16u; i += blockDim.x)
+			dst[i] = uni_src[i];
+	}
 	for (uint32_t i = threadIdx.x; i < 8u * 512u; i += blockDim.x) {
 		const DevHuff &h = g[i >> 9];
 		const uint32_t k = h.fast[i & 511u]; /* 255 = not in the fast table; entry 255 itself is never fast (:203) */
@@ -633,7 +639,7 @@ __device__ __forceinline__ void es_load_tables(const DevScan &sc, const DevImage
 		}
 		__syncthreads();
 	}
-	if (un)
+	if (un && !uni_src)
 		es_build_uni(sc, l, un);
 }
 
@@ -697,15 +703,33 @@ __device__ __forceinline__ void es_build_uni(const DevScan &sc, const EsTab *l, 
 	__syncthreads();
 }
 
+/* The entry tables of the state-only passes, once per picture (= per set of eight Huffman tables; tabscan[t] = a scan that uses set t):
+ * every workgroup of those passes used to build them for itself -- sixteen thousand table decodes per workgroup, four workgroups per 1080p
+ * picture, three passes -- and now copies 18 KiB.  One workgroup per table set. */
+__global__ __launch_bounds__(256) void k_es_tables(const DevScan *__restrict__ scans, const uint32_t *__restrict__ tabscan, const DevHuff *__restrict__ huff,
+																	uint4 *__restrict__ unis)
+{
+	__shared__ EsTab tabs[8];
+	__shared__ EsLocal loc;
+	__shared__ EsUni uni;
+	const DevScan &sc = scans[tabscan[blockIdx.x]];
+	es_load_tables(sc, nullptr, huff + sc.tab_off, tabs, &loc, nullptr, false, &uni);
+	uint4 *dst = unis + (size_t)(sc.tab_off >> 3) * (sizeof(EsUni) / 16u);
+	const uint4 *src = reinterpret_cast<const uint4 *>(&uni);
+	for (uint32_t i = threadIdx.x; i < sizeof(EsUni) / 16u; i += blockDim.x)
+		dst[i] = src[i];
+}
+
 MIJ_ES_KERNEL void k_es_cold(const DevScan *__restrict__ scans, const EsWork *__restrict__ work, const DevHuff *__restrict__ huff,
-																 const uint8_t *__restrict__ streams, uint64_t *__restrict__ start, uint64_t *__restrict__ end, uint32_t *__restrict__ cnt)
+																 const uint8_t *__restrict__ streams, uint64_t *__restrict__ start, uint64_t *__restrict__ end, uint32_t *__restrict__ cnt,
+																 const uint4 *__restrict__ unis)
 {
 	__shared__ EsTab tabs[8];
 	__shared__ EsLocal loc;
 	__shared__ EsUni uni;
 	const EsWork wk = work[blockIdx.x];
 	const DevScan &sc = scans[wk.scan];
-	es_load_tables(sc, nullptr, huff + sc.tab_off, tabs, &loc, nullptr, false, &uni);
+	es_load_tables(sc, nullptr, huff + sc.tab_off, tabs, &loc, nullptr, false, &uni, unis + (size_t)(sc.tab_off >> 3) * (sizeof(EsUni) / 16u));
 	const uint32_t i = wk.first + threadIdx.x;
 	if (i >= sc.nsub)
 		return;
@@ -745,7 +769,7 @@ __device__ __forceinline__ void es_push(bool push, uint32_t j, uint64_t state, u
 MIJ_ES_KERNEL void k_es_sync(const DevScan *__restrict__ scans, const EsWork *__restrict__ work, const DevHuff *__restrict__ huff,
 																 const uint8_t *__restrict__ streams, uint64_t *__restrict__ start, const uint64_t *__restrict__ end_in,
 																 uint64_t *__restrict__ end_out, uint32_t *__restrict__ cnt, uint32_t *__restrict__ pending, uint32_t *__restrict__ qidx,
-																 uint64_t *__restrict__ qstate)
+																 uint64_t *__restrict__ qstate, const uint4 *__restrict__ unis)
 {
 	__shared__ EsTab tabs[8];
 	__shared__ EsLocal loc;
@@ -767,7 +791,7 @@ MIJ_ES_KERNEL void k_es_sync(const DevScan *__restrict__ scans, const EsWork *__
 	}
 	if (!__syncthreads_or(redo ? 1 : 0))
 		return;
-	es_load_tables(sc, nullptr, huff + sc.tab_off, tabs, &loc, nullptr, false, &uni);
+	es_load_tables(sc, nullptr, huff + sc.tab_off, tabs, &loc, nullptr, false, &uni, unis + (size_t)(sc.tab_off >> 3) * (sizeof(EsUni) / 16u));
 	if (!redo)
 		return;
 	start[slot] = want;
@@ -786,7 +810,7 @@ MIJ_ES_KERNEL void k_es_sync(const DevScan *__restrict__ scans, const EsWork *__
 MIJ_ES_KERNEL void k_es_syncq(const DevScan *__restrict__ scans, const EsWork *__restrict__ work, const DevHuff *__restrict__ huff,
 																  const uint8_t *__restrict__ streams, uint64_t *__restrict__ start, uint64_t *__restrict__ end, uint32_t *__restrict__ cnt,
 																  const uint32_t *__restrict__ n_in, const uint32_t *__restrict__ qidx_in, const uint64_t *__restrict__ qstate_in,
-																  uint32_t *__restrict__ pending, uint32_t *__restrict__ qidx, uint64_t *__restrict__ qstate)
+																  uint32_t *__restrict__ pending, uint32_t *__restrict__ qidx, uint64_t *__restrict__ qstate, const uint4 *__restrict__ unis)
 {
 	__shared__ EsTab tabs[8];
 	__shared__ EsLocal loc;
@@ -796,7 +820,7 @@ MIJ_ES_KERNEL void k_es_syncq(const DevScan *__restrict__ scans, const EsWork *_
 	if (wk.first >= n) /* most workgroups, from the second round on: gone before the tables are copied */
 		return;
 	const DevScan &sc = scans[wk.scan];
-	es_load_tables(sc, nullptr, huff + sc.tab_off, tabs, &loc, nullptr, false, &uni);
+	es_load_tables(sc, nullptr, huff + sc.tab_off, tabs, &loc, nullptr, false, &uni, unis + (size_t)(sc.tab_off >> 3) * (sizeof(EsUni) / 16u));
 	const uint32_t t = wk.first + threadIdx.x;
 	if (t >= n)
 		return;

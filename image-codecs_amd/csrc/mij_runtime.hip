@@ -1603,6 +1603,8 @@ struct EsArena {
 	WorkIdct *h_pack, *d_pack; /* k_es_pack: (slot, component, first block) per 256 blocks of every compact-plane slot */
 	size_t pack_cap, pack_used;
 	uint64_t *d_start, *d_end[2]; /* d_end[0]: the cold pass's end states, d_end[1]: the current ones (first round on) */
+	uint4 *d_uni;          /* k_es_tables: one EsUni per table set */
+	uint32_t *h_tabscan, *d_tabscan; /* table set -> a scan that uses it */
 	uint32_t *d_qidx[2];  /* the queues of k_es_syncq, alternating by round: subsequence ... */
 	uint64_t *d_qstate[2]; /* ... and the start state it has to run from; a scan's entries start at its sub_off */
 	uint32_t *d_cnt, *d_base;
@@ -1641,6 +1643,9 @@ static void es_free(EsArena *e)
 	if (e->d_start) (void)hipFree(e->d_start);
 	if (e->d_end[0]) (void)hipFree(e->d_end[0]);
 	if (e->d_end[1]) (void)hipFree(e->d_end[1]);
+	if (e->d_uni) (void)hipFree(e->d_uni);
+	if (e->h_tabscan) (void)hipHostFree(e->h_tabscan);
+	if (e->d_tabscan) (void)hipFree(e->d_tabscan);
 	for (int q = 0; q < 2; ++q) {
 		if (e->d_qidx[q]) (void)hipFree(e->d_qidx[q]);
 		if (e->d_qstate[q]) (void)hipFree(e->d_qstate[q]);
@@ -1709,6 +1714,9 @@ extern "C" int mij_batch_entropy_reserve(mij_batch *b, size_t stream_bytes)
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_start), sizeof(uint64_t) * e->sub_cap);
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_end[0]), sizeof(uint64_t) * e->sub_cap);
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_end[1]), sizeof(uint64_t) * e->sub_cap);
+	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_uni), sizeof(EsUni) * n);
+	if (r == hipSuccess) r = hipHostMalloc(reinterpret_cast<void **>(&e->h_tabscan), sizeof(uint32_t) * n, hipHostMallocDefault);
+	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_tabscan), sizeof(uint32_t) * n);
 	for (int q = 0; q < 2; ++q) {
 		if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_qidx[q]), sizeof(uint32_t) * e->sub_cap);
 		if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_qstate[q]), sizeof(uint64_t) * e->sub_cap);
@@ -1826,6 +1834,7 @@ extern "C" int mij_batch_add_stream(mij_batch *b, const mjg_scan *scan, uint8_t 
 	static_assert(sizeof(DevHuff) == sizeof(mjg_huff), "mjg_huff and DevHuff must match");
 	const size_t tab = e->n_tabs++;
 	memcpy(&e->h_huff[8 * tab], scan->huff, sizeof(mjg_huff) * 8);
+	e->h_tabscan[tab] = (uint32_t)e->scan_slot.size(); /* the first of this picture's scans */
 	uint32_t first_mcu = 0;
 	for (uint32_t g = 0; g < nseg; ++g) {
 		const size_t k = e->scan_slot.size();
@@ -1935,10 +1944,10 @@ static int es_enqueue_round(mij_batch *b)
 	const int r = e->last_rounds;
 	if (r == 0)
 		hipLaunchKernelGGL(k_es_sync, gw, blk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, e->d_start, e->d_end[0], e->d_end[1], e->d_cnt, v_changed, e->d_qidx[0],
-								 e->d_qstate[0]);
+								 e->d_qstate[0], e->d_uni);
 	else
 		hipLaunchKernelGGL(k_es_syncq, gw, blk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, e->d_start, e->d_end[1], e->d_cnt, v_changed - e->scan_cap,
-								 e->d_qidx[(r - 1) & 1], e->d_qstate[(r - 1) & 1], v_changed, e->d_qidx[r & 1], e->d_qstate[r & 1]);
+								 e->d_qidx[(r - 1) & 1], e->d_qstate[(r - 1) & 1], v_changed, e->d_qidx[r & 1], e->d_qstate[r & 1], e->d_uni);
 	HIP_TRY(hipGetLastError());
 	++e->last_rounds;
 	return MIJ_OK;
@@ -1963,6 +1972,7 @@ extern "C" int mij_batch_entropy_launch(mij_batch *b)
 	HIP_TRY(copy_table(b->d_imgs, b->h_imgs, sizeof(DevImage) * n, st));
 	HIP_TRY(copy_table(e->d_scans, e->h_scans, sizeof(DevScan) * ns, st));
 	HIP_TRY(copy_table(e->d_huff, e->h_huff, sizeof(DevHuff) * 8 * e->n_tabs, st));
+	HIP_TRY(copy_table(e->d_tabscan, e->h_tabscan, sizeof(uint32_t) * e->n_tabs, st));
 	HIP_TRY(copy_table(e->d_work, e->h_work, sizeof(EsWork) * e->work_used, st));
 	HIP_TRY(copy_table(e->d_pack, e->h_pack, sizeof(WorkIdct) * e->pack_used, st));
 	/* streams: one copy from the first to the last byte in use */
@@ -1982,7 +1992,9 @@ extern "C" int mij_batch_entropy_launch(mij_batch *b)
 	HIP_TRY(hipMemsetAsync(e->d_verdict, 0, sizeof(uint32_t) * 5 * e->scan_cap, st));
 	HIP_TRY(hipMemsetAsync(e->d_changed, 0, sizeof(uint32_t) * ES_MAX_ROUNDS * e->scan_cap, st));
 	const dim3 gw((unsigned)e->work_used), blk(MIJ_ES_WG);
-	hipLaunchKernelGGL(k_es_cold, gw, blk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, e->d_start, e->d_end[0], e->d_cnt);
+	hipLaunchKernelGGL(k_es_tables, dim3((unsigned)e->n_tabs), dim3(256), 0, st, e->d_scans, e->d_tabscan, e->d_huff, e->d_uni);
+	HIP_TRY(hipGetLastError());
+	hipLaunchKernelGGL(k_es_cold, gw, blk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, e->d_start, e->d_end[0], e->d_cnt, e->d_uni);
 	HIP_TRY(hipGetLastError());
 	e->cur = 0;
 	e->last_rounds = 0;
