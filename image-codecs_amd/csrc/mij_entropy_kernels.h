@@ -151,9 +151,10 @@ struct EsTab {
 /* Pair tables: a table indexed by the next MIJ_ES_PAIR_BITS bits of the stream folds TWO consecutive AC symbols (code + extra bits of the
  * first, code + extra bits of the second) into one 16-bit entry whenever both lie inside the window -- at the benchmark's 1.8 bit/px that
  * is most pairs -- so the serial chain lookup -> shift -> lookup runs half as often.  The state-only passes have their form of it in
- * EsUni below (round 2 kept it here); the write pass's form (EsPair, for_write in es_load_tables) holds per window the SECOND symbol behind
- * the one the window starts with.  A pair is only taken when the first symbol leaves the block open and the second starts before the
- * subsequence ends, i.e. exactly when the one-symbol loop would decode both: the hand-over states between subsequences do not change. */
+ * EsUni below (round 2 kept it here).  The write pass needs the symbols themselves: EsPair holds its AC tables in the fast table's format
+ * under a twelve-bit index, and an iteration looks up a second symbol behind the first in the same table.  A second symbol is only taken
+ * when the first leaves the block open and the second starts before the subsequence ends, i.e. exactly when the one-symbol loop would
+ * decode both: the hand-over states between subsequences do not change. */
 #define MIJ_ES_PAIR_BITS 12u
 #ifndef MIJ_ES_PAIR /* A/B switch: 0 = the write pass decodes one symbol per iteration */
 #define MIJ_ES_PAIR 1
@@ -373,8 +374,9 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &
 		/* both lookups leave together (one LDS round trip on the serial chain, not two): the ordinary fast-table entry of the
 		 * table this symbol uses, and -- state-only passes -- the pair entry of the block's AC table */
 		const EsTab &htab = tabs[isdc ? (tb >> 8) & 255u : tb >> 16];
-		const uint32_t e9 = htab.fast16[(uint32_t)(win >> 55)];
-		const uint32_t e2w = (PAIRW && t2cur && !isdc) ? t2cur[(uint32_t)(win >> (64u - MIJ_ES_PAIR_BITS))] : 0u;
+		/* the write pass looks AC symbols up by twelve bits (EsPair: the fast table's format under a longer index), so that the search for
+		 * long codes -- which a wavefront runs whenever one of its lanes needs it -- only remains for codes beyond twelve bits */
+		const uint32_t e9 = (PAIRW && t2cur && !isdc) ? t2cur[(uint32_t)(win >> (64u - MIJ_ES_PAIR_BITS))] : htab.fast16[(uint32_t)(win >> 55)];
 		{
 		uint32_t len = 0;
 		const int sym = es_symbol_e(htab, win, e9, len);
@@ -393,8 +395,8 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &
 		const int ext = es_extend(win, len, n ? n : 1u);
 		const int v = n ? ext : 0;
 		s.p += len + n;
-		/* the write pass shifts the window once per iteration: a pair lies inside the twelve bits its entry was built from, so the second
-		 * symbol needs no refill in between */
+		/* the write pass shifts the window once per iteration: the window holds 32 valid bits at every symbol start, and a second symbol is
+		 * only taken when it ends inside them */
 		uint32_t used = len + n;
 		if (!PAIRW)
 			br.take(used);
@@ -422,12 +424,17 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &
 				s.z = k + 1;
 			}
 		}
-		/* Write pass: the second AC symbol of the pair the window started with, when the first one left the block open and the
-		 * second starts inside this subsequence -- the same symbol the next iteration would decode, without its lookup, its
-		 * checks and its trip round the loop. */
-		if (PAIRW && e2w && s.z < 64u && s.p < p_end) {
-			const uint32_t len2 = e2w >> 12, n2 = (e2w >> 4) & 15u, r2 = (e2w >> 8) & 15u;
-			const int v2 = n2 ? es_extend(win << used, len2, n2) : 0;
+		/* Write pass: a second AC symbol in the same iteration, when the first symbol (a DC term or an AC symbol) left the block open and
+		 * the second starts inside this subsequence -- the same symbol the next iteration would decode, from the same table, without its
+		 * checks and its trip round the loop.  (Until round 3's second session the second symbol came out of a pair table and had to lie
+		 * inside twelve bits together with the first.) */
+		uint32_t e2 = 0xffffu;
+		const uint64_t win2 = win << (used & 31u);
+		if (PAIRW && t2cur && s.z < 64u && s.p < p_end && used <= 32u - MIJ_ES_PAIR_BITS)
+			e2 = t2cur[(uint32_t)(win2 >> (64u - MIJ_ES_PAIR_BITS))];
+		if (PAIRW && e2 != 0xffffu && used + (e2 >> 8) + (e2 & 15u) <= 32u) {
+			const uint32_t len2 = e2 >> 8, n2 = e2 & 15u, r2 = (e2 >> 4) & 15u;
+			const int v2 = n2 ? es_extend(win2, len2, n2) : 0;
 			s.p += len2 + n2;
 			used += len2 + n2;
 			if (n2 == 0) {
@@ -562,8 +569,7 @@ struct EsWork {
 };
 
 /* the scan's eight Huffman tables and its EsLocal into LDS (im == nullptr: no block placement needed); ends in a barrier */
-/* pr != nullptr: also the pair tables (EsPair); for_write: in the write pass's format -- the SECOND symbol behind the one the
- * window starts with, as code length << 12 | symbol << 4 | bits of the first symbol (0: no second symbol inside the window) */
+/* pr != nullptr: also the write pass's twelve-bit tables of its (at most two) AC tables (EsPair) */
 __device__ __forceinline__ void es_build_uni(const DevScan &sc, const EsTab *l, EsUni *un);
 /* un: the state-only passes' entry tables, copied from uni_src (what k_es_tables built for the picture's table set) or built here */
 __device__ __forceinline__ void es_load_tables(const DevScan &sc, const DevImage *im, const DevHuff *__restrict__ g, EsTab *l, EsLocal *loc, EsPair *pr = nullptr,
@@ -612,28 +618,15 @@ __device__ __forceinline__ void es_load_tables(const DevScan &sc, const DevImage
 			pr->slot[threadIdx.x] = threadIdx.x == used[0] ? 0 : (threadIdx.x == used[1] ? 1 : 255);
 		for (uint32_t i = threadIdx.x; i < 2u << MIJ_ES_PAIR_BITS; i += blockDim.x) {
 			const uint32_t k = i >> MIJ_ES_PAIR_BITS, w = i & ((1u << MIJ_ES_PAIR_BITS) - 1u);
-			uint32_t e = 0;
+			/* the fast table's entry format (code length << 8 | symbol, 0xffff = not here) under a twelve-bit index: full decode (long codes
+			 * included) of the window padded with zeros; a symbol counts only if its code lies inside the bits the window really holds */
+			uint32_t e = 0xffffu;
 			if (used[k] != 255u) {
-				/* full decode (long codes included) of the window padded with zeros: a symbol counts only if its code and its
-				 * extra bits lie inside the bits the window really holds */
 				const EsTab &h = l[used[k]];
 				uint32_t len1 = 0;
 				const int s1 = es_symbol(h, (uint64_t)w << (64u - MIJ_ES_PAIR_BITS), len1);
-				const uint32_t n1 = (uint32_t)s1 & 15u, r1 = ((uint32_t)s1 >> 4) & 15u, bits1 = len1 + n1;
-				if (s1 >= 0 && len1 && bits1 <= MIJ_ES_PAIR_BITS) {
-					const uint32_t adv1 = n1 ? r1 + 1u : (r1 == 15u ? 16u : 64u);
-					e = for_write ? 0u : (bits1 | adv1 << 4);
-					const uint32_t rem = MIJ_ES_PAIR_BITS - bits1;
-					if (adv1 != 64u && rem) {
-						uint32_t len2 = 0;
-						const int s2 = es_symbol(h, (uint64_t)w << (64u - MIJ_ES_PAIR_BITS + bits1), len2);
-						const uint32_t n2 = (uint32_t)s2 & 15u, r2 = ((uint32_t)s2 >> 4) & 15u;
-						if (s2 >= 0 && len2 && len2 + n2 <= rem) {
-							const uint32_t eob2 = (!n2 && r2 != 15u) ? 1u : 0u, adv2 = eob2 ? 0u : (n2 ? r2 + 1u : 16u);
-							e = for_write ? (len2 << 12 | ((uint32_t)s2 & 255u) << 4 | bits1) : (0x8000u | (bits1 + len2 + n2) | adv1 << 4 | adv2 << 9 | eob2 << 14);
-						}
-					}
-				}
+				if (s1 >= 0 && len1 && len1 <= MIJ_ES_PAIR_BITS)
+					e = len1 << 8 | ((uint32_t)s1 & 255u);
 			}
 			pr->t2[k][w] = (uint16_t)e;
 		}
