@@ -633,6 +633,7 @@ def leg_wide420(ica, ctx, args, checker):
     res = out["segments"]
     res.update({"workload": "%d x %dx%d baseline 4:2:0 q=90, coefficients resident" % (n, w, h), "kernel": "mij::k_fused420c<3,false,true>", "algorithmic_bytes_per_launch": algo,
                 "parity_against": checker[1], "two_pass_kernels_on_the_same_pictures": {k: out["two_pass"][k] for k in ("kernel_ms_per_launch", "mpix_s", "frac", "parity")}})
+    add_traffic(res, "k_fused420c_compact_%d" % n)
     return res
 
 

@@ -47,6 +47,7 @@ LEGS = [  # (traffic key, kernel substring, which dispatches, algorithmic bytes,
     ("k_encode444_512", "k_encode444", "last", legs.get("config5_q95_444", {}).get("algorithmic_bytes_per_launch"), legs.get("config5_q95_444", {}).get("kernel_ms_per_launch")),
     ("k_fused440_compact_256", "k_fused440w<3, false, true>", "last1", legs.get("two_pass", {}).get("h1v2_440", {}).get("algorithmic_bytes_per_launch"),
      legs.get("two_pass", {}).get("h1v2_440", {}).get("ms_per_launch")),
+    ("k_fused420c_compact_22", "k_fused420c<3, false, true>", "last1", legs.get("wide_420", {}).get("algorithmic_bytes_per_launch"), legs.get("wide_420", {}).get("kernel_ms_per_launch")),
     ("k_fused1x1c_cmyk_256", "k_fused1x1c<3, false, true>", "last1", legs.get("two_pass", {}).get("cmyk_adobe", {}).get("algorithmic_bytes_per_launch"),
      legs.get("two_pass", {}).get("cmyk_adobe", {}).get("ms_per_launch")),
 ]
