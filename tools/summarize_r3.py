@@ -127,7 +127,7 @@ for key, kern, which, algo, bms in LEGS:
 json.dump(tj, open(tpath, "w"), indent=1)
 lines.append("")
 lines += ["## 3. issue counters of the timed launches (mean per launch)", "", "| leg | SQ_INSTS_VALU | lane-ops / px | SQ_WAVE_CYCLES | SQ_BUSY_CYCLES | SQ_WAIT_ANY / SQ_WAVE_CYCLES | SQ_INSTS_LDS |", "|---|---|---|---|---|---|---|"]
-px = {"k_fused444_compact_32": 32 * 4096 * 4096, "k_fused422_compact_512": 512 * 1920 * 1080, "k_encode444_512": 512 * 1920 * 1080, "k_fused440_compact_256": 256 * 1920 * 1080,
+px = {"k_fused420c_compact_22": 22 * 6000 * 4000, "k_fused444_compact_32": 32 * 4096 * 4096, "k_fused422_compact_512": 512 * 1920 * 1080, "k_encode444_512": 512 * 1920 * 1080, "k_fused440_compact_256": 256 * 1920 * 1080,
       "k_fused1x1c_cmyk_256": 256 * 1920 * 1080}
 for key, kern, which, algo, bms in LEGS:
     v = {c: leg_counter(sq, kern, which, c) for c in ("SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_LDS")}
