@@ -420,3 +420,36 @@ CB_PATTERNS = (
     lambda k: 1,
     lambda k: 1 + (k * 7) % 128,
 )
+
+
+def third_tables(data):
+    """The same baseline picture with a THIRD pair of Huffman tables: every DHT table with id 1 is repeated with id 2 and the scan's third
+    component is pointed at DC / AC table 2 (the reference accepts table ids 0..3 in a baseline file, codec/jpeg.c:1016-1040, :1070-1085).
+    Decodes to the same pixels; the GPU walk's entry tables hold two tables of each class, so the third takes its search path."""
+    out, i, extra = bytearray(data[:2]), 2, bytearray()
+    while i < len(data):
+        assert data[i] == 0xFF
+        m = data[i + 1]
+        if m == 0xDA:
+            n = (data[i + 2] << 8) | data[i + 3]
+            seg = bytearray(data[i:i + 2 + n])
+            ns = seg[4]
+            assert ns == 3
+            seg[5 + 2 * 2 + 1] = 0x22  # third component: Td = Ta = 2
+            if extra:
+                out += b"\xff\xc4" + bytes([(len(extra) + 2) >> 8, (len(extra) + 2) & 255]) + extra
+            out += seg + data[i + 2 + n:]
+            return bytes(out)
+        n = (data[i + 2] << 8) | data[i + 3]
+        seg = data[i:i + 2 + n]
+        if m == 0xC4:
+            j = 4
+            while j < len(seg):
+                tc_th = seg[j]
+                cnt = sum(seg[j + 1:j + 17])
+                if (tc_th & 15) == 1:
+                    extra += bytes([(tc_th & 0xF0) | 2]) + seg[j + 1:j + 17 + cnt]
+                j += 17 + cnt
+        out += seg
+        i += 2 + n
+    raise AssertionError("no SOS")

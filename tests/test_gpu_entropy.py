@@ -412,3 +412,33 @@ def test_default_front_end_twice_without_a_reset(ica, oracle, gpu_ctx, golden):
             else:
                 assert np.array_equal(b.fetch(s), want)
     b.close()
+
+
+def test_gpu_walk_with_a_third_pair_of_tables(ica, oracle, gpu_ctx):
+    """The walk's entry tables (EsUni, EsPair) hold the first two DC and the first two AC tables a scan uses; a baseline file may name a
+    third pair (the reference takes ids 0..3).  Its blocks go through the search path of both the state-only passes and the write pass: same
+    planes as the host walk, same pixels as the oracle, nothing handed back."""
+    datas = []
+    for i, (w, h, q) in enumerate(((200, 120, 90), (640, 480, 85), (1920, 1080, 90), (333, 77, 95))):
+        base = ica.synth_jpeg(w, h, i, q)
+        datas.append(helpers.third_tables(base))
+        assert np.array_equal(oracle.load(datas[-1], 3)[1], oracle.load(base, 3)[1])
+    for fmt in ("compact", "int16"):
+        b = ica.Batch(gpu_ctx, len(datas), 64 << 20, 64 << 20, 64 << 20)
+        b.set_coef_format(fmt)
+        b.entropy_reserve(16 << 20)
+        slots = []
+        for d in datas:
+            st, slot = b.add_jpeg_stream(d, 3)
+            assert st == 1, (st, b.last_reason)
+            slots.append(slot)
+        assert b.entropy_run() == []
+        for d, s in zip(datas, slots):
+            desc, want = ica.HostDecoder.decode(d, 3)
+            for ci, (pg, pw) in enumerate(zip(ica.detile_coefficients(desc, b.fetch_coef(s)), ica.detile_coefficients(desc, want))):
+                assert np.array_equal(pg, pw), (fmt, len(d), ci, int((pg != pw).sum()))
+        b.submit()
+        b.wait()
+        for d, s in zip(datas, slots):
+            assert np.array_equal(b.fetch(s), oracle.load(d, 3)[1]), (fmt, len(d))
+        b.close()
