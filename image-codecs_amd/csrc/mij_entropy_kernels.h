@@ -262,7 +262,6 @@ struct EsWriter { /* where the blocks of the write pass go */
 	uint64_t grp;        /* the eight bytes of group curq gathered so far */
 	uint32_t curq;
 	bool esc;            /* the current block has an escaped coefficient (written by this thread) */
-	bool bytewise;       /* k_es_tails: single byte stores (the head's group stores came first and wrote zeros beside them) */
 	int dcd;             /* DC difference of the current block */
 	uint32_t acc;        /* L1 of the AC coefficients written by this thread into it */
 	uint32_t *pfinal;    /* where the bit position after the scan's last block is recorded */
@@ -290,10 +289,11 @@ struct EsWriter { /* where the blocks of the write pass go */
 			*reinterpret_cast<uint64_t *>(zz + 8u * curq) = grp;
 		grp = 0;
 	}
+	template <bool CB, bool BW>
 	__device__ __forceinline__ void put(uint32_t k, int v, uint32_t c)
 	{
-		if (sc->fmt) {
-			if (bytewise)
+		if (CB) {
+			if (BW)
 				zz[k] = (uint8_t)v;
 			else {
 				const uint32_t q = k >> 3;
@@ -307,7 +307,7 @@ struct EsWriter { /* where the blocks of the write pass go */
 				uint8_t *hi8 = escape_bytes(c);
 				/* the block's first escape clears its 64 escape bytes (nothing else does); a tail looks at the flag
 				 * the head may have left (an earlier kernel) */
-				if (!esc && !(bytewise && zz[0] != 0)) {
+				if (!esc && !(BW && zz[0] != 0)) {
 					uint4 *h = reinterpret_cast<uint4 *>(hi8);
 					h[0] = h[1] = h[2] = h[3] = make_uint4(0, 0, 0, 0);
 				}
@@ -320,10 +320,11 @@ struct EsWriter { /* where the blocks of the write pass go */
 	/* the block (or the head of one that continues in the next subsequence) is done: its bytes and its meta word.  Per-block
 	 * L1 without atomics: whoever holds the block's start stores the word, the thread that finishes a block begun elsewhere
 	 * (k_es_tails, a later launch) adds to its L1 half */
+	template <bool CB, bool BW>
 	__device__ __forceinline__ void end_block()
 	{
-		if (sc->fmt) {
-			if (!bytewise)
+		if (CB) {
+			if (!BW)
 				flush_group();
 			if (esc)
 				zz[0] = 1; /* the flags byte sits in the DC's place; behind this lane's own store of group 0 */
@@ -331,7 +332,7 @@ struct EsWriter { /* where the blocks of the write pass go */
 		if (owner) {
 			if (!((MIJ_VARIANT & 512) && acc != 0x12345678u)) /* ablation bit 512: no meta stores */
 				meta[ord] = (uint64_t)acc | ((uint64_t)(uint16_t)(int16_t)dcd << 32);
-		} else if (!sc->fmt)
+		} else if (!CB)
 			reinterpret_cast<uint32_t *>(meta + ord)[0] += acc;
 		acc = 0;
 		esc = false;
@@ -344,13 +345,14 @@ struct EsWriter { /* where the blocks of the write pass go */
  * WRITE = false: only the state and the number of completed blocks.  WRITE = true: coefficients are stored,
  * decoding stops at block ordinal sc.nblocks, malformed input sets *anom.
  */
-template <bool WRITE, bool PAIRW = false>
+/* CB: compact planes (DevScan.fmt), BW: the tails pass's byte stores -- template parameters since round 3's second session: the two plane
+ * formats and the two store forms were run-time branches inside put / end_block, dead code in every launch but in the way of the compiler */
+template <bool WRITE, bool PAIRW = false, bool CB = true, bool BW = false>
 __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &loc, const EsTab *__restrict__ tabs, const uint8_t *__restrict__ stream, EsState &s,
 															 uint32_t p_end, EsWriter *wr, uint32_t *anom, const EsPair *__restrict__ pr = nullptr)
 {
 	static_assert(!(PAIRW && !WRITE), "PAIRW: the write pass's pair table");
-	uint32_t done = 0, guard = 0;
-	const uint32_t limit = sc.nbits + 64u; /* the arena is zero padded: never read far past the data */
+	uint32_t done = 0;
 	EsBits br;
 	br.start(stream, s.p);
 	uint32_t tb = loc.tabs[s.c]; /* the current block's component and tables; changes with s.c only */
@@ -362,11 +364,9 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &
 	/* ONE symbol per iteration whatever it is: the lanes of a wave sit at DC terms, AC runs and block ends all the time,
 	 * so a loop with a DC branch and an AC branch executes both on almost every iteration (each at a fraction of the
 	 * lanes).  Here the table is chosen by data and the state update is a handful of selects. */
+	/* every iteration takes at least one bit (a code has a length, anything else ends the walk), so the position alone bounds the loop:
+	 * p_end <= nbits, and the arena is zero padded behind the data for the window's look-ahead */
 	while (s.p < p_end && s.z != MIJ_ES_DEAD) {
-		if (++guard > MIJ_ES_BITS + 64u) { /* every symbol takes at least one bit: cannot happen, but a wave must always end */
-			s.z = MIJ_ES_DEAD;
-			break;
-		}
 		if (WRITE && wr->ord >= sc.nblocks)
 			break;
 		const uint64_t win = br.win;
@@ -415,8 +415,8 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &
 				s.z = 64;
 			} else {
 				if (WRITE && !wr->skip) {
-					wr->put(k, v, s.c);
-					if (!sc.fmt) { /* compact planes: k_es_pack has the whole block in registers and sums its L1 there */
+					wr->template put<CB, BW>(k, v, s.c);
+					if (!CB) { /* compact planes: k_es_pack has the whole block in registers and sums its L1 there */
 						const int dq = (int)(int16_t)((uint32_t)v * loc.qz[tb & 255u][k]);
 						wr->acc += (uint32_t)(dq < 0 ? -dq : dq);
 					}
@@ -446,8 +446,8 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &
 					s.z = 64;
 				} else {
 					if (!wr->skip) {
-						wr->put(k2, v2, s.c);
-						if (!sc.fmt) {
+						wr->template put<CB, BW>(k2, v2, s.c);
+						if (!CB) {
 							const int dq = (int)(int16_t)((uint32_t)v2 * loc.qz[tb & 255u][k2]);
 							wr->acc += (uint32_t)(dq < 0 ? -dq : dq);
 						}
@@ -466,7 +466,7 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &
 				if (s.p > sc.nbits)
 					atomicOr(anom, 16u); /* the data ran out inside this block: the reference decodes on with zero bits */
 				if (!wr->skip)
-					wr->end_block();
+					wr->template end_block<CB, BW>();
 				wr->acc = 0;
 				if (wr->stop_after_block) { /* k_es_tails: only the rest of the block the subsequence started in */
 					s.z = 0;
@@ -491,16 +491,12 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &
 				const uint32_t slot = pr->slot[tb >> 16];
 				t2cur = slot < 2u ? pr->t2[slot] : nullptr;
 			}
-			if (WRITE && !sc.fmt && wr->ord < sc.nblocks)
+			if (WRITE && !CB && wr->ord < sc.nblocks)
 				wr->locate(s.c);
-		}
-		if (s.p > limit) {
-			s.z = MIJ_ES_DEAD;
-			break;
 		}
 	}
 	if (WRITE && wr->owner && wr->ord < sc.nblocks && !wr->skip && s.z != 0 && s.z != MIJ_ES_DEAD)
-		wr->end_block(); /* a block that continues in the next subsequence: its bytes so far and the meta word of its head */
+		wr->template end_block<CB, BW>(); /* a block that continues in the next subsequence: its bytes so far and the meta word of its head */
 	return done;
 }
 
@@ -864,6 +860,8 @@ __global__ __launch_bounds__(256) void k_es_offsets(const DevScan *__restrict__ 
 /* Every coefficient is stored where it belongs in planes cleared beforehand (hipMemsetAsync): no staging, so the
  * pass runs at the occupancy of the cold pass.  (Round 1 also had a variant that staged each block in LDS and stored
  * it whole: 37 KiB of LDS per workgroup, 3 waves per SIMD, 5.4 ms against 3.4 ms per 256 images -- removed.) */
+/* CB: the scans with compact planes (true) or with int16 planes (false); a workgroup of the other kind leaves at once */
+template <bool CB>
 MIJ_ES_KERNEL void k_es_write(const DevScan *__restrict__ scans, const EsWork *__restrict__ work, const DevHuff *__restrict__ huff,
 																  const uint8_t *__restrict__ streams, const DevImage *__restrict__ imgs, const uint64_t *__restrict__ start,
 																  const uint32_t *__restrict__ base, int16_t *__restrict__ coef, uint64_t *__restrict__ meta,
@@ -876,6 +874,8 @@ MIJ_ES_KERNEL void k_es_write(const DevScan *__restrict__ scans, const EsWork *_
 	__shared__ uint16_t toff[64];
 	const EsWork wk = work[blockIdx.x];
 	const DevScan &sc = scans[wk.scan];
+	if ((sc.fmt != 0u) != CB)
+		return;
 	if (threadIdx.x < 64) {
 		const uint32_t P = mij_zigzag_pos[threadIdx.x];
 		zpos[threadIdx.x] = (uint8_t)P;
@@ -898,7 +898,6 @@ MIJ_ES_KERNEL void k_es_write(const DevScan *__restrict__ scans, const EsWork *_
 	wr.grp = 0;
 	wr.curq = 0;
 	wr.esc = false;
-	wr.bytewise = false;
 	wr.dcd = 0;
 	wr.blk = nullptr;
 	wr.mx = wr.my = 0;
@@ -917,14 +916,15 @@ MIJ_ES_KERNEL void k_es_write(const DevScan *__restrict__ scans, const EsWork *_
 	wr.zz = zz + ((size_t)(sc.blk_off + wr.ord) << 6);
 	wr.my = m / sc.mcu_x;
 	wr.mx = m - wr.my * sc.mcu_x;
-	if (!sc.fmt)
+	if (!CB)
 		wr.locate(s.c);
 	const uint32_t pe = min((i + 1u) * sc.sub_bits, sc.nbits);
-	es_decode<true, MIJ_ES_PAIR != 0>(sc, loc, tabs, streams + sc.stream_off, s, pe, &wr, &anom[wk.scan], &pair);
+	es_decode<true, MIJ_ES_PAIR != 0, CB, false>(sc, loc, tabs, streams + sc.stream_off, s, pe, &wr, &anom[wk.scan], &pair);
 }
 
 /* the rest of every block that began in the previous subsequence: single coefficients into the block that the
  * previous thread's k_es_write stored whole (stream order makes this the later write) */
+template <bool CB>
 MIJ_ES_KERNEL void k_es_tails(const DevScan *__restrict__ scans, const EsWork *__restrict__ work, const DevHuff *__restrict__ huff,
 																  const uint8_t *__restrict__ streams, const DevImage *__restrict__ imgs, const uint64_t *__restrict__ start,
 																  const uint32_t *__restrict__ base, int16_t *__restrict__ coef, uint64_t *__restrict__ meta,
@@ -936,6 +936,8 @@ MIJ_ES_KERNEL void k_es_tails(const DevScan *__restrict__ scans, const EsWork *_
 	__shared__ uint16_t toff[64];
 	const EsWork wk = work[blockIdx.x];
 	const DevScan &sc = scans[wk.scan];
+	if ((sc.fmt != 0u) != CB)
+		return;
 	if (threadIdx.x < 64) {
 		const uint32_t P = mij_zigzag_pos[threadIdx.x];
 		zpos[threadIdx.x] = (uint8_t)P;
@@ -964,7 +966,6 @@ MIJ_ES_KERNEL void k_es_tails(const DevScan *__restrict__ scans, const EsWork *_
 	wr.grp = 0;
 	wr.curq = 0;
 	wr.esc = false;
-	wr.bytewise = true;
 	wr.dcd = 0;
 	wr.blk = nullptr;
 	wr.mx = wr.my = 0;
@@ -981,10 +982,10 @@ MIJ_ES_KERNEL void k_es_tails(const DevScan *__restrict__ scans, const EsWork *_
 	wr.zz = zz + ((size_t)(sc.blk_off + wr.ord) << 6);
 	wr.my = m / sc.mcu_x;
 	wr.mx = m - wr.my * sc.mcu_x;
-	if (!sc.fmt)
+	if (!CB)
 		wr.locate(s.c);
 	/* k_es_write walked the same symbols and reported what there was to report: verdict bits go to a scratch word */
-	es_decode<true>(sc, loc, tabs, streams + sc.stream_off, s, sc.nbits, &wr, scratch + 1);
+	es_decode<true, false, CB, true>(sc, loc, tabs, streams + sc.stream_off, s, sc.nbits, &wr, scratch + 1);
 }
 
 /* The intermediate image of the write pass (64 bytes per block in zigzag order, blocks in scan order) -> the tiles of

@@ -1910,12 +1910,24 @@ static int es_enqueue_tail(mij_batch *b)
 		}
 		if (hi > lo)
 			HIP_TRY(hipMemsetAsync(b->d_coef + lo, 0, hi - lo, st));
-		hipLaunchKernelGGL(k_es_write, gw, wblk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, b->d_imgs, e->d_start, e->d_base,
-								 reinterpret_cast<int16_t *>(b->d_coef), e->d_meta, v_anom, v_pfinal, e->d_zz);
+		/* one launch per plane format in use (the other kind's workgroups leave at once) */
+		bool any_fmt[2] = {false, false};
+		for (size_t k = 0; k < ns; ++k)
+			any_fmt[e->h_scans[k].fmt ? 1 : 0] = true;
+		if (any_fmt[1])
+			hipLaunchKernelGGL(k_es_write<true>, gw, wblk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, b->d_imgs, e->d_start, e->d_base,
+									 reinterpret_cast<int16_t *>(b->d_coef), e->d_meta, v_anom, v_pfinal, e->d_zz);
+		if (any_fmt[0])
+			hipLaunchKernelGGL(k_es_write<false>, gw, wblk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, b->d_imgs, e->d_start, e->d_base,
+									 reinterpret_cast<int16_t *>(b->d_coef), e->d_meta, v_anom, v_pfinal, e->d_zz);
+		HIP_TRY(hipGetLastError());
+		if (any_fmt[1])
+			hipLaunchKernelGGL(k_es_tails<true>, gw, wblk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, b->d_imgs, e->d_start, e->d_base,
+									 reinterpret_cast<int16_t *>(b->d_coef), e->d_meta, e->d_rounds_changed, e->d_zz);
+		if (any_fmt[0])
+			hipLaunchKernelGGL(k_es_tails<false>, gw, wblk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, b->d_imgs, e->d_start, e->d_base,
+									 reinterpret_cast<int16_t *>(b->d_coef), e->d_meta, e->d_rounds_changed, e->d_zz);
 	}
-	HIP_TRY(hipGetLastError());
-	hipLaunchKernelGGL(k_es_tails, gw, wblk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, b->d_imgs, e->d_start, e->d_base,
-							 reinterpret_cast<int16_t *>(b->d_coef), e->d_meta, e->d_rounds_changed, e->d_zz);
 	HIP_TRY(hipGetLastError());
 	if (e->pack_used) {
 		hipLaunchKernelGGL(k_es_pack, dim3((unsigned)e->pack_used), blk, 0, st, b->d_imgs, e->d_pack, e->d_zz, b->d_coef, e->d_meta);
