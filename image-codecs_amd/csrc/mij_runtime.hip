@@ -1613,6 +1613,10 @@ struct EsArena {
 	int rounds0;       /* synchronisation rounds queued before the first look at the verdicts */
 	uint64_t *d_meta; /* per block: L1 of its AC coefficients | DC difference << 32 */
 	uint8_t *d_zz; /* compact planes: the write pass's intermediate image, 64 bytes per block in zigzag order */
+	uint64_t *d_rec;  /* compact planes, record form (k_es_writer / k_es_pack2): rec_region64 eight-byte words per subsequence */
+	uint32_t rec_region64;
+	size_t rec_words;
+	bool use_records;
 	size_t blk_cap;
 	uint32_t *d_verdict, *h_verdict; /* [5][scan_cap]: anomaly, changed, total, l1max, final bit position */
 	uint32_t *d_rounds_changed, *h_rounds_changed; /* [MAX_ROUNDS] sum over scans, for tuning */
@@ -1654,6 +1658,7 @@ static void es_free(EsArena *e)
 	if (e->d_base) (void)hipFree(e->d_base);
 	if (e->d_meta) (void)hipFree(e->d_meta);
 	if (e->d_zz) (void)hipFree(e->d_zz);
+	if (e->d_rec) (void)hipFree(e->d_rec);
 	if (e->d_verdict) (void)hipFree(e->d_verdict);
 	if (e->h_verdict) (void)hipHostFree(e->h_verdict);
 	if (e->d_rounds_changed) (void)hipFree(e->d_rounds_changed);
@@ -1724,7 +1729,15 @@ extern "C" int mij_batch_entropy_reserve(mij_batch *b, size_t stream_bytes)
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_cnt), sizeof(uint32_t) * e->sub_cap);
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_base), sizeof(uint32_t) * e->sub_cap);
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_meta), sizeof(uint64_t) * e->blk_cap);
-	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_zz), 64 * e->blk_cap);
+	/* the write pass's intermediate form for compact planes: the record stream (mij_entropy_kernels.h) when its arena's record indices fit
+	 * 32 bits (8 GiB: streams of about 1 GiB per batch) and MIJ_ES_RECORDS / the environment allow it, else the zigzag image */
+	e->rec_region64 = (e->sub_bits + MIJ_ES_REC_SLACK) / 8u;
+	e->rec_words = (e->sub_cap + 1) * (size_t)e->rec_region64;
+	e->use_records = MIJ_ES_RECORDS && e->rec_words < ((size_t)1 << 30) && !(getenv("MIJ_ES_RECORDS") && getenv("MIJ_ES_RECORDS")[0] == '0');
+	if (e->use_records) {
+		if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_rec), sizeof(uint64_t) * e->rec_words);
+	} else if (r == hipSuccess)
+		r = hipMalloc(reinterpret_cast<void **>(&e->d_zz), 64 * e->blk_cap);
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_verdict), sizeof(uint32_t) * 5 * e->scan_cap);
 	if (r == hipSuccess) r = hipHostMalloc(reinterpret_cast<void **>(&e->h_verdict), sizeof(uint32_t) * 5 * e->scan_cap, hipHostMallocDefault);
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_rounds_changed), sizeof(uint32_t) * ES_MAX_ROUNDS);
@@ -1892,8 +1905,10 @@ static int es_enqueue_tail(mij_batch *b)
 		 * tiles, k_es_dc the DC array, the first escape of a block clears its escape bytes: the planes themselves need
 		 * no clearing).  int16 planes: the write pass only stores non-zero coefficients, so the planes of those images
 		 * are cleared (neighbours in the arena as one range). */
-		if (e->pack_used)
+		if (e->pack_used && !e->use_records)
 			HIP_TRY(hipMemsetAsync(e->d_zz, 0, 64 * e->blk_used, st));
+		if (e->pack_used && e->use_records) /* record form: "no subsequence began this block" until the write pass says where its records start */
+			HIP_TRY(hipMemsetAsync(e->d_meta, 0xff, sizeof(uint64_t) * e->blk_used, st));
 		size_t lo = 0, hi = 0;
 		for (const Slot &sl : b->slots) {
 			if (!sl.dev_coef || sl.clone_of >= 0 || sl.coef_bytes_fmt)
@@ -1914,14 +1929,17 @@ static int es_enqueue_tail(mij_batch *b)
 		bool any_fmt[2] = {false, false};
 		for (size_t k = 0; k < ns; ++k)
 			any_fmt[e->h_scans[k].fmt ? 1 : 0] = true;
-		if (any_fmt[1])
+		if (any_fmt[1] && e->use_records)
+			hipLaunchKernelGGL(k_es_writer, gw, wblk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, e->d_start, e->d_base, e->d_meta, v_anom, v_pfinal, e->d_rec,
+									 e->rec_region64);
+		else if (any_fmt[1])
 			hipLaunchKernelGGL(k_es_write<true>, gw, wblk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, b->d_imgs, e->d_start, e->d_base,
 									 reinterpret_cast<int16_t *>(b->d_coef), e->d_meta, v_anom, v_pfinal, e->d_zz);
 		if (any_fmt[0])
 			hipLaunchKernelGGL(k_es_write<false>, gw, wblk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, b->d_imgs, e->d_start, e->d_base,
 									 reinterpret_cast<int16_t *>(b->d_coef), e->d_meta, v_anom, v_pfinal, e->d_zz);
 		HIP_TRY(hipGetLastError());
-		if (any_fmt[1])
+		if (any_fmt[1] && !e->use_records)
 			hipLaunchKernelGGL(k_es_tails<true>, gw, wblk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, b->d_imgs, e->d_start, e->d_base,
 									 reinterpret_cast<int16_t *>(b->d_coef), e->d_meta, e->d_rounds_changed, e->d_zz);
 		if (any_fmt[0])
@@ -1930,7 +1948,10 @@ static int es_enqueue_tail(mij_batch *b)
 	}
 	HIP_TRY(hipGetLastError());
 	if (e->pack_used) {
-		hipLaunchKernelGGL(k_es_pack, dim3((unsigned)e->pack_used), blk, 0, st, b->d_imgs, e->d_pack, e->d_zz, b->d_coef, e->d_meta);
+		if (e->use_records)
+			hipLaunchKernelGGL(k_es_pack2, dim3((unsigned)e->pack_used), blk, 0, st, b->d_imgs, e->d_pack, e->d_rec, (uint32_t)e->rec_words, b->d_coef, e->d_meta);
+		else
+			hipLaunchKernelGGL(k_es_pack, dim3((unsigned)e->pack_used), blk, 0, st, b->d_imgs, e->d_pack, e->d_zz, b->d_coef, e->d_meta);
 		HIP_TRY(hipGetLastError());
 	}
 	hipLaunchKernelGGL(k_es_dc, gs, blk, 0, st, e->d_scans, b->d_imgs, v_total, v_changed, reinterpret_cast<int16_t *>(b->d_coef), e->d_meta,
