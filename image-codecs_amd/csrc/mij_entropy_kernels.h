@@ -500,6 +500,121 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &
 	return done;
 }
 
+/* The write pass's tables (record form).  Entries in the fast table's format (code length << 8 | symbol, 0 = not here) under a twelve-bit
+ * index for the scan's (at most two) AC tables and a nine-bit index for its DC tables; an iteration looks the symbol its window starts with up
+ * and a second AC symbol behind it in the same table.  The search for codes beyond the index runs on EsLong.  Built once per picture by
+ * k_es_tables, copied by every workgroup of k_es_writer: 21 KiB, which leaves room for the record buffers (below) at four workgroups a CU. */
+struct __attribute__((aligned(16))) EsLong { /* what the search for a code of ten bits or more needs of a table (EsTab without its fast table) */
+	uint8_t values[256];
+	uint32_t maxcode[8];
+	int32_t delta[8];
+	uint32_t maxlo[12]; /* lengths 1..9 of stbi__huffman.maxcode / .delta: only a table WITHOUT window entries (a third pair) is searched from length 1 */
+	int32_t dello[12];
+};
+struct __attribute__((aligned(16))) EsW {
+	uint16_t ac[2][1u << MIJ_ES_PAIR_BITS];
+	uint16_t dc[2][1u << MIJ_ES_DC_BITS];
+	uint16_t zero[8];  /* right behind dc[][]: entry 0 = where the index of a table without entries is clamped to (MIJ_ES_W_ZERO) */
+	EsLong lng[8];     /* the scan's eight tables, for the codes beyond the windows (in LDS: a wavefront meets one in a third of its iterations,
+	                    * and a search over tables in global memory made the pass wait 79 % of its time) */
+	uint32_t base[12]; /* block-in-MCU -> index of its AC table's first entry | its DC table's << 16; 0xffff: no entries */
+	uint32_t tabs[12]; /* EsLocal.tabs: component | DC table << 8 | AC table << 16 (the search) */
+};
+#define MIJ_ES_W_ZERO ((2u << MIJ_ES_PAIR_BITS) + (2u << MIJ_ES_DC_BITS))
+
+/* codec/jpeg.c:219-243 for a code of ten bits or more (es_symbol_e's search on EsLong): returns the symbol and its code length, or -1 */
+__device__ __forceinline__ int es_symbol_long(const EsLong &h, uint64_t win, uint32_t &len)
+{
+	const uint32_t top16 = (uint32_t)(win >> 48);
+	const uint4 m0 = *reinterpret_cast<const uint4 *>(&h.maxcode[0]), m1 = *reinterpret_cast<const uint4 *>(&h.maxcode[4]);
+	const uint4 d0 = *reinterpret_cast<const uint4 *>(&h.delta[0]), d1 = *reinterpret_cast<const uint4 *>(&h.delta[4]);
+	const uint32_t ge[7] = {top16 >= m0.x, top16 >= m0.y, top16 >= m0.z, top16 >= m0.w, top16 >= m1.x, top16 >= m1.y, top16 >= m1.z};
+	const uint32_t l = 10u + ge[0] + ge[1] + ge[2] + ge[3] + ge[4] + ge[5] + ge[6];
+	if (l >= 17u)
+		return -1;
+	uint32_t dl = d0.x;
+	dl = l == 11u ? d0.y : dl;
+	dl = l == 12u ? d0.z : dl;
+	dl = l == 13u ? d0.w : dl;
+	dl = l == 14u ? d1.x : dl;
+	dl = l == 15u ? d1.y : dl;
+	dl = l == 16u ? d1.z : dl;
+	const int c = (int)((top16 >> (16u - l)) & ((1u << l) - 1u)) + (int)dl;
+	if (c < 0 || c > 255)
+		return -1;
+	len = l;
+	return h.values[c];
+}
+
+/* a table without window entries: every length (the reference's loop from 1: its fast table is a shortcut of the same search) */
+__device__ __forceinline__ int es_symbol_full(const EsLong &h, uint64_t win, uint32_t &len)
+{
+	const uint32_t top16 = (uint32_t)(win >> 48);
+	for (uint32_t l = 1; l < 10u; ++l)
+		if (top16 < h.maxlo[l]) {
+			const int c = (int)(top16 >> (16u - l)) + h.dello[l];
+			if (c < 0 || c > 255)
+				return -1;
+			len = l;
+			return h.values[c];
+		}
+	return es_symbol_long(h, win, len);
+}
+
+__device__ __forceinline__ void es_build_w(const DevScan &sc, const EsTab *l, const DevHuff *__restrict__ g, EsW *w)
+{
+	uint32_t ua[2] = {255u, 255u}, ud[2] = {255u, 255u}, na = 0, nd = 0;
+	for (uint32_t c = 0; c < 4u; ++c) {
+		const uint32_t ta = sc.ac_tab[c] & 7u, td = sc.dc_tab[c] & 7u;
+		if (ta != ua[0] && ta != ua[1] && na < 2u)
+			ua[na++] = ta;
+		if (td != ud[0] && td != ud[1] && nd < 2u)
+			ud[nd++] = td;
+	}
+	if (threadIdx.x < 12u) {
+		const uint32_t ci = sc.blk_comp[threadIdx.x] & 3u, ta = sc.ac_tab[ci] & 7u, td = sc.dc_tab[ci] & 7u;
+		const uint32_t sa = ta == ua[0] ? 0u : (ta == ua[1] ? 1u : 2u), sd = td == ud[0] ? 0u : (td == ud[1] ? 1u : 2u);
+		w->base[threadIdx.x] = (sa < 2u ? sa << MIJ_ES_PAIR_BITS : 0xffffu) | (sd < 2u ? (2u << MIJ_ES_PAIR_BITS) + (sd << MIJ_ES_DC_BITS) : 0xffffu) << 16;
+		w->tabs[threadIdx.x] = ci | td << 8 | ta << 16;
+	}
+	if (threadIdx.x < 8u)
+		w->zero[threadIdx.x] = 0;
+	for (uint32_t i = threadIdx.x; i < 8u * 256u; i += blockDim.x)
+		w->lng[i >> 8].values[i & 255u] = l[i >> 8].values[i & 255u];
+	if (threadIdx.x < 64u) {
+		w->lng[threadIdx.x >> 3].maxcode[threadIdx.x & 7u] = l[threadIdx.x >> 3].maxcode[threadIdx.x & 7u];
+		w->lng[threadIdx.x >> 3].delta[threadIdx.x & 7u] = l[threadIdx.x >> 3].delta[threadIdx.x & 7u];
+	}
+	if (threadIdx.x < 96u) {
+		const uint32_t t = threadIdx.x / 12u, j = threadIdx.x % 12u;
+		w->lng[t].maxlo[j] = j < 10u ? g[t].maxcode[j] : 0xffffffffu;
+		w->lng[t].dello[j] = j < 10u ? g[t].delta[j] : 0;
+	}
+	for (uint32_t i = threadIdx.x; i < 2u << MIJ_ES_PAIR_BITS; i += blockDim.x) {
+		const uint32_t k = i >> MIJ_ES_PAIR_BITS, wd = i & ((1u << MIJ_ES_PAIR_BITS) - 1u);
+		uint32_t e = 0;
+		if (ua[k] != 255u) {
+			uint32_t len1 = 0;
+			const int s1 = es_symbol(l[ua[k]], (uint64_t)wd << (64u - MIJ_ES_PAIR_BITS), len1);
+			if (s1 >= 0 && len1 && len1 <= MIJ_ES_PAIR_BITS)
+				e = len1 << 8 | ((uint32_t)s1 & 255u);
+		}
+		w->ac[k][wd] = (uint16_t)e;
+	}
+	for (uint32_t i = threadIdx.x; i < 2u << MIJ_ES_DC_BITS; i += blockDim.x) {
+		const uint32_t k = i >> MIJ_ES_DC_BITS, wd = i & ((1u << MIJ_ES_DC_BITS) - 1u);
+		uint32_t e = 0;
+		if (ud[k] != 255u) {
+			uint32_t len = 0;
+			const int sy = es_symbol(l[ud[k]], (uint64_t)wd << (64u - MIJ_ES_DC_BITS), len);
+			if (sy >= 0 && len && len <= MIJ_ES_DC_BITS && sy <= 11)
+				e = len << 8 | (uint32_t)sy;
+		}
+		w->dc[k][wd] = (uint16_t)e;
+	}
+	__syncthreads();
+}
+
 /* ------------------------------------------------------------------ the write pass as a record stream (compact planes; round 3, second session)
  *
  * The write pass above places every coefficient where it belongs in a 64-byte image of its block: group bookkeeping, escape bytes, a
@@ -527,88 +642,111 @@ __device__ __forceinline__ uint32_t es_decode(const DevScan &sc, const EsLocal &
 #define MIJ_ES_REC_ESC 0xb000u
 #define MIJ_ES_REC_PAD 0xf000u
 
+/* Why the records do not go out as they come.  gfx950 counts loads and stores in ONE counter (vmcnt), so the wait for the stream word that
+ * refills a lane's window also waits for every store issued before it -- and with 64 lanes emitting at their own pace there is a store in
+ * flight in every iteration: without its stores this pass takes 0.70 ms per 256 pictures, with them 1.31.  So a lane gathers its records in
+ * LDS (dword j of all lanes side by side: every lane its own bank), and every MIJ_ES_REC_EVERY iterations the whole wavefront stores its
+ * complete 8-byte words together: one iteration in MIJ_ES_REC_EVERY has stores to wait behind. */
+#define MIJ_ES_REC_BUF 32u  /* records of LDS per lane */
+#define MIJ_ES_REC_EVERY 7u /* an iteration emits at most four records: 7 x 4 + 3 left over < 32 */
 struct EsRecOut {
 	uint64_t *slot;  /* the next 8 bytes of the region */
-	uint64_t acc;    /* records gathered for it */
-	uint32_t cnt;    /* how many (0..3) */
-	uint32_t index;  /* record index of the next record in the arena */
+	uint32_t *buf;   /* this lane's column of the workgroup's record buffer: dword j at buf[j * MIJ_ES_WG] */
+	uint32_t cnt;    /* records in it */
+	uint32_t index;  /* record index (in the arena) of the record at position 0 of the buffer */
 	__device__ __forceinline__ void emit(uint32_t rec)
 	{
-		acc |= (uint64_t)rec << (16u * cnt);
-		++index;
-		if (++cnt == 4u) {
-			*slot = acc; /* an ordinary store: the lane fills its cache lines eight bytes at a time, and L2 merges them (streamed past L2 they become partial-line writes: 2.29 against 1.?? ms) */
-			++slot;
-			acc = 0;
-			cnt = 0;
-		}
+		reinterpret_cast<uint16_t *>(buf + (cnt >> 1) * MIJ_ES_WG)[cnt & 1u] = (uint16_t)rec;
+		++cnt;
+	}
+	/* the complete 8-byte words go out, the (at most three) records behind them move to the front */
+	__device__ __forceinline__ void flush()
+	{
+		const uint32_t words = cnt >> 2;
+#pragma unroll
+		for (uint32_t j = 0; j < MIJ_ES_REC_BUF / 4u; ++j)
+			if (j < words) {
+				const uint64_t v = (uint64_t)buf[(2u * j) * MIJ_ES_WG] | (uint64_t)buf[(2u * j + 1u) * MIJ_ES_WG] << 32;
+				if (!((MIJ_VARIANT & 4096) && v != 0x123456789abcdefull)) /* ablation bit 4096: no record stores */
+					slot[j] = v;
+			}
+		const uint32_t r0 = buf[(2u * words) * MIJ_ES_WG], r1 = buf[(2u * words + 1u) * MIJ_ES_WG]; /* words <= 7: inside the buffer */
+		buf[0] = r0;
+		buf[MIJ_ES_WG] = r1;
+		slot += words;
+		index += 4u * words;
+		cnt &= 3u;
 	}
 	__device__ __forceinline__ void finish()
 	{
-		while (cnt)
+		while (cnt & 3u)
 			emit(MIJ_ES_REC_PAD);
+		flush();
 	}
 };
 
 /* es_decode<true> for compact planes in record form: same symbols, same anomalies, same hand-over rule */
-__device__ __forceinline__ void es_write_records(const DevScan &sc, const EsLocal &loc, const EsTab *__restrict__ tabs, const EsPair *__restrict__ pr,
-																 const uint8_t *__restrict__ stream, EsState &s, uint32_t p_end, uint32_t &ord, EsRecOut &out, uint32_t *__restrict__ meta_idx,
-																 uint32_t *__restrict__ anom, uint32_t *__restrict__ pfinal)
+__device__ __forceinline__ void es_write_records(const DevScan &sc, const EsW &w, const uint8_t *__restrict__ stream, EsState &s, uint32_t p_end, uint32_t &ord,
+																 EsRecOut &out, uint32_t *__restrict__ meta_idx, uint32_t *__restrict__ anom, uint32_t *__restrict__ pfinal)
 {
 	EsBits br;
 	br.start(stream, s.p);
-	uint32_t tb = loc.tabs[s.c];
-	const uint16_t *t2cur = nullptr;
-	{
-		const uint32_t slot = pr->slot[tb >> 16];
-		t2cur = slot < 2u ? pr->t2[slot] : nullptr;
-	}
-	while (s.p < p_end && s.z != MIJ_ES_DEAD && ord < sc.nblocks) {
+	const uint16_t *__restrict__ w16 = &w.ac[0][0]; /* ac[2][4096], dc[2][512], zero[] */
+	const uint32_t bpm = sc.bpm, nblocks = sc.nblocks, nbits = sc.nbits;
+	uint32_t base = w.base[s.c], it = 0;
+	while (s.p < p_end && s.z != MIJ_ES_DEAD && ord < nblocks) {
 		const uint64_t win = br.win;
+		const uint32_t hi = (uint32_t)(win >> 32);
 		const bool isdc = s.z == 0;
-		const EsTab &htab = tabs[isdc ? (tb >> 8) & 255u : tb >> 16];
-		const uint32_t e9 = (t2cur && !isdc) ? t2cur[(uint32_t)(win >> (64u - MIJ_ES_PAIR_BITS))] : htab.fast16[(uint32_t)(win >> 55)];
-		uint32_t len = 0;
-		const int sym = es_symbol_e(htab, win, e9, len);
-		if (sym < 0 || len == 0 || (isdc && sym > 11)) {
-			atomicOr(anom, 1u);
-			s.z = MIJ_ES_DEAD;
-			break;
+		const uint32_t idx = min(isdc ? (base >> 16) + (hi >> (32u - MIJ_ES_DC_BITS)) : (base & 0xffffu) + (hi >> (32u - MIJ_ES_PAIR_BITS)), MIJ_ES_W_ZERO);
+		uint32_t e = w16[idx];
+		if (e == 0u) { /* a code beyond the index, a third table, or no code at all: the reference's search */
+			const uint32_t tb = w.tabs[s.c];
+			const EsLong &hl = w.lng[isdc ? (tb >> 8) & 255u : tb >> 16];
+			uint32_t len = 0;
+			const int sym = (isdc ? base >> 16 : base & 0xffffu) != 0xffffu ? es_symbol_long(hl, win, len) : es_symbol_full(hl, win, len);
+			if (sym < 0 || len == 0 || (isdc && sym > 11)) {
+				atomicOr(anom, 1u);
+				s.z = MIJ_ES_DEAD;
+				break;
+			}
+			e = len << 8 | ((uint32_t)sym & 255u);
 		}
-		const uint32_t n = isdc ? (uint32_t)sym : ((uint32_t)sym & 15u), r = isdc ? 0u : ((uint32_t)sym >> 4);
-		const int v = n ? es_extend(win, len, n) : 0;
-		uint32_t used = len + n;
+		const uint32_t len1 = e >> 8, n1 = isdc ? (e & 255u) : (e & 15u), r1 = isdc ? 0u : ((e >> 4) & 15u);
+		const int v1 = n1 ? es_extend(win, len1, n1) : 0;
+		uint32_t used = len1 + n1;
 		s.p += used;
 		if (isdc) {
-			meta_idx[2u * ord] = out.index; /* low dword of the block's meta word: where its records start */
-			out.emit(MIJ_ES_REC_DC | ((uint32_t)v & 0xfffu));
+			meta_idx[2u * ord] = out.index + out.cnt; /* low dword of the block's meta word: where its records start */
+			out.emit(MIJ_ES_REC_DC | ((uint32_t)v1 & 0xfffu));
 			s.z = 1;
-		} else if (n == 0) {
-			s.z = r == 15u ? s.z + 16u : 64u; /* ZRL, or EOB */
+		} else if (n1 == 0u) {
+			s.z = r1 == 15u ? s.z + 16u : 64u; /* ZRL, or EOB */
 		} else {
-			const uint32_t k = s.z + r;
+			const uint32_t k = s.z + r1;
 			if (k > 63u) { /* the reference would write through its padded de-zigzag table: leave that to the host */
 				atomicOr(anom, 1u);
 				s.z = 64;
 			} else {
-				const bool esc = (uint32_t)(v + 128) > 255u;
-				out.emit(k << 8 | ((uint32_t)v & 255u) | (esc ? 0x4000u : 0u));
+				const bool esc = (uint32_t)(v1 + 128) > 255u;
+				out.emit(k << 8 | ((uint32_t)v1 & 255u) | (esc ? 0x4000u : 0u));
 				if (esc)
-					out.emit(MIJ_ES_REC_ESC | (((uint32_t)(v + 128) >> 8) & 255u));
+					out.emit(MIJ_ES_REC_ESC | (((uint32_t)(v1 + 128) >> 8) & 255u));
 				s.z = k + 1;
 			}
 		}
-		/* a second AC symbol in the same iteration (es_decode's rule) */
-		uint32_t e2 = 0xffffu;
+		/* a second AC symbol in the same iteration, from the same table, when the first symbol left the block open, the second starts inside
+		 * this subsequence and ends inside the window's 32 valid bits (es_decode's rule: the hand-over states do not change) */
+		uint32_t e2 = 0;
 		const uint64_t win2 = win << (used & 31u);
-		if (t2cur && s.z < 64u && s.p < p_end && used <= 32u - MIJ_ES_PAIR_BITS)
-			e2 = t2cur[(uint32_t)(win2 >> (64u - MIJ_ES_PAIR_BITS))];
-		if (e2 != 0xffffu && used + (e2 >> 8) + (e2 & 15u) <= 32u) {
+		if ((base & 0xffffu) != 0xffffu && s.z < 64u && s.p < p_end && used <= 32u - MIJ_ES_PAIR_BITS)
+			e2 = w16[(base & 0xffffu) + (uint32_t)(win2 >> (64u - MIJ_ES_PAIR_BITS))];
+		if (e2 != 0u && used + (e2 >> 8) + (e2 & 15u) <= 32u) {
 			const uint32_t len2 = e2 >> 8, n2 = e2 & 15u, r2 = (e2 >> 4) & 15u;
 			const int v2 = n2 ? es_extend(win2, len2, n2) : 0;
 			s.p += len2 + n2;
 			used += len2 + n2;
-			if (n2 == 0) {
+			if (n2 == 0u) {
 				s.z = r2 == 15u ? s.z + 16u : 64u;
 			} else {
 				const uint32_t k2 = s.z + r2;
@@ -627,17 +765,20 @@ __device__ __forceinline__ void es_write_records(const DevScan &sc, const EsLoca
 		br.take(used);
 		if (s.z >= 64u) { /* block complete */
 			s.z = 0;
-			if (s.p > sc.nbits)
+			if (s.p > nbits)
 				atomicOr(anom, 16u); /* the data ran out inside this block: the reference decodes on with zero bits */
-			if (++ord == sc.nblocks)
+			if (++ord == nblocks)
 				*pfinal = s.p;
-			if (++s.c == sc.bpm)
+			if (++s.c == bpm)
 				s.c = 0;
-			tb = loc.tabs[s.c];
-			const uint32_t slot = pr->slot[tb >> 16];
-			t2cur = slot < 2u ? pr->t2[slot] : nullptr;
+			base = w.base[s.c];
+		}
+		if (++it == MIJ_ES_REC_EVERY) { /* the same iteration for every lane still in the loop: they entered it together */
+			out.flush();
+			it = 0;
 		}
 	}
+	out.flush();
 }
 
 /* The state-only passes' walk (EsUni): from state s until the bit position reaches p_end (a symbol that starts before p_end is finished, a pair
@@ -836,16 +977,22 @@ __device__ __forceinline__ void es_build_uni(const DevScan &sc, const EsTab *l, 
  * every workgroup of those passes used to build them for itself -- sixteen thousand table decodes per workgroup, four workgroups per 1080p
  * picture, three passes -- and now copies 18 KiB.  One workgroup per table set. */
 __global__ __launch_bounds__(256) void k_es_tables(const DevScan *__restrict__ scans, const uint32_t *__restrict__ tabscan, const DevHuff *__restrict__ huff,
-																	uint4 *__restrict__ unis)
+																	uint4 *__restrict__ unis, uint4 *__restrict__ wtabs)
 {
 	__shared__ EsTab tabs[8];
 	__shared__ EsLocal loc;
 	__shared__ EsUni uni;
+	__shared__ EsW w;
 	const DevScan &sc = scans[tabscan[blockIdx.x]];
 	es_load_tables(sc, nullptr, huff + sc.tab_off, tabs, &loc, nullptr, false, &uni);
+	es_build_w(sc, tabs, huff + sc.tab_off, &w);
 	uint4 *dst = unis + (size_t)(sc.tab_off >> 3) * (sizeof(EsUni) / 16u);
 	const uint4 *src = reinterpret_cast<const uint4 *>(&uni);
 	for (uint32_t i = threadIdx.x; i < sizeof(EsUni) / 16u; i += blockDim.x)
+		dst[i] = src[i];
+	dst = wtabs + (size_t)(sc.tab_off >> 3) * (sizeof(EsW) / 16u);
+	src = reinterpret_cast<const uint4 *>(&w);
+	for (uint32_t i = threadIdx.x; i < sizeof(EsW) / 16u; i += blockDim.x)
 		dst[i] = src[i];
 }
 
@@ -1133,16 +1280,21 @@ MIJ_ES_KERNEL void k_es_tails(const DevScan *__restrict__ scans, const EsWork *_
 MIJ_ES_KERNEL void k_es_writer(const DevScan *__restrict__ scans, const EsWork *__restrict__ work, const DevHuff *__restrict__ huff,
 																	const uint8_t *__restrict__ streams, const uint64_t *__restrict__ start, const uint32_t *__restrict__ base,
 																	uint64_t *__restrict__ meta, uint32_t *__restrict__ anom, uint32_t *__restrict__ pfinal, uint64_t *__restrict__ rec,
-																	uint32_t region64)
+																	uint32_t region64, const uint4 *__restrict__ wtabs)
 {
-	__shared__ EsTab tabs[8];
-	__shared__ EsLocal loc;
-	__shared__ EsPair pair;
+	__shared__ EsW w;
+	__shared__ uint32_t rbuf[MIJ_ES_REC_BUF / 2u][MIJ_ES_WG]; /* EsRecOut: dword j of every lane's records side by side */
 	const EsWork wk = work[blockIdx.x];
 	const DevScan &sc = scans[wk.scan];
 	if (!sc.fmt)
 		return;
-	es_load_tables(sc, nullptr, huff + sc.tab_off, tabs, &loc, &pair, true);
+	{
+		const uint4 *src = wtabs + (size_t)(sc.tab_off >> 3) * (sizeof(EsW) / 16u);
+		uint4 *dst = reinterpret_cast<uint4 *>(&w);
+		for (uint32_t q = threadIdx.x; q < sizeof(EsW) / 16u; q += blockDim.x)
+			dst[q] = src[q];
+		__syncthreads();
+	}
 	const uint32_t i = wk.first + threadIdx.x;
 	if (i >= sc.nsub)
 		return;
@@ -1153,7 +1305,7 @@ MIJ_ES_KERNEL void k_es_writer(const DevScan *__restrict__ scans, const EsWork *
 		return;
 	EsRecOut out;
 	out.slot = rec + (size_t)slot * region64;
-	out.acc = 0;
+	out.buf = &rbuf[0][threadIdx.x];
 	out.cnt = 0;
 	out.index = slot * region64 * 4u;
 	const uint32_t ml = ord / sc.bpm;
@@ -1162,13 +1314,15 @@ MIJ_ES_KERNEL void k_es_writer(const DevScan *__restrict__ scans, const EsWork *
 		s.z = MIJ_ES_DEAD;
 	} else {
 		const uint32_t pe = min((i + 1u) * sc.sub_bits, sc.nbits);
-		es_write_records(sc, loc, tabs, &pair, streams + sc.stream_off, s, pe, ord, out, reinterpret_cast<uint32_t *>(meta + sc.blk_off), &anom[wk.scan], &pfinal[wk.scan]);
+		es_write_records(sc, w, streams + sc.stream_off, s, pe, ord, out, reinterpret_cast<uint32_t *>(meta + sc.blk_off), &anom[wk.scan], &pfinal[wk.scan]);
 	}
 	/* every region ends in a way out: on to the next subsequence's records, or the end of the scan's */
 	if (ord >= sc.nblocks || s.z == MIJ_ES_DEAD || i + 1u >= sc.nsub)
 		out.emit(MIJ_ES_REC_END);
 	else {
 		const uint32_t next = (slot + 1u) * region64 * 4u;
+		if ((out.cnt & 3u) >= 2u) /* a jump and its two index records stay inside one 8-byte word (k_es_pack2 reads them from the word in hand) */
+			out.finish();
 		out.emit(MIJ_ES_REC_JUMP);
 		out.emit(next & 0xffffu);
 		out.emit(next >> 16);
@@ -1298,35 +1452,36 @@ __global__ __launch_bounds__(256) void k_es_pack2(const DevImage *__restrict__ i
 		const uint32_t idx = reinterpret_cast<const uint32_t *>(meta + im.es_blk_off + ord)[0];
 		uint8_t *const lane_bytes = reinterpret_cast<uint8_t *>(&stage[wv][0][ln]); /* byte k of the block: lane_bytes[(k >> 2) * 256 + (k & 3)] */
 		uint8_t *const hi8 = coef + cp.hi_off + ((size_t)L << 6);
-		uint32_t a = idx >> 2, left = 0, prevk = 0;
-		uint64_t cur = 0;
+		uint32_t a = idx >> 2, prevk = 0;
 		bool going = idx != 0xffffffffu && a < rec_words; /* 0xffffffff: no subsequence ever began this block (the image is handed back) */
-		if (going) {
-			cur = rec[a] >> (16u * (idx & 3u));
-			left = 4u - (idx & 3u);
+		uint64_t cur = going ? rec[a] : 0ull;
+		if (idx & 3u) { /* the records in front of this block's in its first word: padding to the reader */
+			const uint64_t m = (1ull << (16u * (idx & 3u))) - 1ull;
+			cur = (cur & ~m) | (0xf000f000f000f000ull & m);
 		}
 		bool first = true;
 		/* a block has at most 1 + 63 records, as many escapes and a jump per subsequence it crosses: the bound only guards against a chain
-		 * that was never written (an image with an anomaly) */
-		for (uint32_t step = 0; going && step < 512u; ++step) {
-			if (left == 0u) {
-				if (++a >= rec_words)
-					break;
-				cur = rec[a];
-				left = 4;
-			}
-			const uint32_t r = (uint32_t)cur & 0xffffu;
-			cur >>= 16;
-			--left;
-			if (!(r & 0x8000u)) { /* AC coefficient */
-				prevk = (r >> 8) & 63u;
-				lane_bytes[(prevk >> 2) * 256u + (prevk & 3u)] = (uint8_t)r;
-			} else {
+		 * that was never written (an image with an anomaly).  One 8-byte word = four records per step, the next word already on its way. */
+		for (uint32_t step = 0; going && step < 160u; ++step) {
+			uint64_t nxt = rec[min(a + 1u, rec_words - 1u)];
+			bool jumped = false;
+#pragma unroll
+			for (uint32_t q = 0; q < 4u; ++q) {
+				const uint32_t r = (uint32_t)(cur >> (16u * q)) & 0xffffu;
+				if (!going || jumped)
+					continue;
+				if (!(r & 0x8000u)) { /* AC coefficient */
+					prevk = (r >> 8) & 63u;
+					lane_bytes[(prevk >> 2) * 256u + (prevk & 3u)] = (uint8_t)r;
+					continue;
+				}
 				const uint32_t kind = r & 0xf000u;
 				if (kind == MIJ_ES_REC_DC) {
 					if (!first)
-						break; /* the next block's: done */
-					dcd = ((int)(r << 20)) >> 20;
+						going = false; /* the next block's: done */
+					else
+						dcd = ((int)(r << 20)) >> 20;
+					first = false;
 				} else if (kind == MIJ_ES_REC_ESC) {
 					if (!escaped) { /* the block's first escape clears its 64 escape bytes (nothing else does) */
 						uint4 *h = reinterpret_cast<uint4 *>(hi8);
@@ -1334,34 +1489,22 @@ __global__ __launch_bounds__(256) void k_es_pack2(const DevImage *__restrict__ i
 						escaped = true;
 					}
 					hi8[mij_zigzag_pos[prevk]] = (uint8_t)r;
-				} else if (kind == MIJ_ES_REC_JUMP) {
-					uint32_t t[2];
-					for (int q = 0; q < 2; ++q) {
-						if (left == 0u) {
-							if (++a >= rec_words) {
-								going = false;
-								break;
-							}
-							cur = rec[a];
-							left = 4;
-						}
-						t[q] = (uint32_t)cur & 0xffffu;
-						cur >>= 16;
-						--left;
-					}
-					if (!going)
-						break;
-					const uint32_t nidx = t[0] | t[1] << 16; /* the first record of a region: a multiple of four */
-					a = nidx >> 2;
-					if (a >= rec_words)
-						break;
-					cur = rec[a];
-					left = 4;
+				} else if (kind == MIJ_ES_REC_JUMP) { /* q <= 1 (k_es_writer): its index is in this word */
+					const uint32_t nidx = ((uint32_t)(cur >> (16u * ((q + 1u) & 3u))) & 0xffffu) | ((uint32_t)(cur >> (16u * ((q + 2u) & 3u))) & 0xffffu) << 16;
+					a = (nidx >> 2) - 1u; /* the first record of a region: a multiple of four */
+					if (q > 1u || a + 1u >= rec_words)
+						going = false;
+					else
+						nxt = rec[a + 1u];
+					jumped = true;
 				} else if (kind == MIJ_ES_REC_END)
-					break;
+					going = false;
 				/* padding: nothing */
 			}
-			first = false;
+			cur = nxt;
+			++a;
+			if (a >= rec_words)
+				going = false;
 		}
 		if (escaped)
 			lane_bytes[0] = 1; /* the flags byte sits in the DC's place */

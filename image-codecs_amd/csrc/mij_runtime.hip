@@ -1604,6 +1604,7 @@ struct EsArena {
 	size_t pack_cap, pack_used;
 	uint64_t *d_start, *d_end[2]; /* d_end[0]: the cold pass's end states, d_end[1]: the current ones (first round on) */
 	uint4 *d_uni;          /* k_es_tables: one EsUni per table set */
+	uint4 *d_wtab;         /* ... and one EsW (the record-form write pass's tables) */
 	uint32_t *h_tabscan, *d_tabscan; /* table set -> a scan that uses it */
 	uint32_t *d_qidx[2];  /* the queues of k_es_syncq, alternating by round: subsequence ... */
 	uint64_t *d_qstate[2]; /* ... and the start state it has to run from; a scan's entries start at its sub_off */
@@ -1648,6 +1649,7 @@ static void es_free(EsArena *e)
 	if (e->d_end[0]) (void)hipFree(e->d_end[0]);
 	if (e->d_end[1]) (void)hipFree(e->d_end[1]);
 	if (e->d_uni) (void)hipFree(e->d_uni);
+	if (e->d_wtab) (void)hipFree(e->d_wtab);
 	if (e->h_tabscan) (void)hipHostFree(e->h_tabscan);
 	if (e->d_tabscan) (void)hipFree(e->d_tabscan);
 	for (int q = 0; q < 2; ++q) {
@@ -1720,6 +1722,7 @@ extern "C" int mij_batch_entropy_reserve(mij_batch *b, size_t stream_bytes)
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_end[0]), sizeof(uint64_t) * e->sub_cap);
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_end[1]), sizeof(uint64_t) * e->sub_cap);
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_uni), sizeof(EsUni) * n);
+	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_wtab), sizeof(EsW) * n);
 	if (r == hipSuccess) r = hipHostMalloc(reinterpret_cast<void **>(&e->h_tabscan), sizeof(uint32_t) * n, hipHostMallocDefault);
 	if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void **>(&e->d_tabscan), sizeof(uint32_t) * n);
 	for (int q = 0; q < 2; ++q) {
@@ -1931,7 +1934,7 @@ static int es_enqueue_tail(mij_batch *b)
 			any_fmt[e->h_scans[k].fmt ? 1 : 0] = true;
 		if (any_fmt[1] && e->use_records)
 			hipLaunchKernelGGL(k_es_writer, gw, wblk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, e->d_start, e->d_base, e->d_meta, v_anom, v_pfinal, e->d_rec,
-									 e->rec_region64);
+									 e->rec_region64, e->d_wtab);
 		else if (any_fmt[1])
 			hipLaunchKernelGGL(k_es_write<true>, gw, wblk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, b->d_imgs, e->d_start, e->d_base,
 									 reinterpret_cast<int16_t *>(b->d_coef), e->d_meta, v_anom, v_pfinal, e->d_zz);
@@ -2025,7 +2028,7 @@ extern "C" int mij_batch_entropy_launch(mij_batch *b)
 	HIP_TRY(hipMemsetAsync(e->d_verdict, 0, sizeof(uint32_t) * 5 * e->scan_cap, st));
 	HIP_TRY(hipMemsetAsync(e->d_changed, 0, sizeof(uint32_t) * ES_MAX_ROUNDS * e->scan_cap, st));
 	const dim3 gw((unsigned)e->work_used), blk(MIJ_ES_WG);
-	hipLaunchKernelGGL(k_es_tables, dim3((unsigned)e->n_tabs), dim3(256), 0, st, e->d_scans, e->d_tabscan, e->d_huff, e->d_uni);
+	hipLaunchKernelGGL(k_es_tables, dim3((unsigned)e->n_tabs), dim3(256), 0, st, e->d_scans, e->d_tabscan, e->d_huff, e->d_uni, e->d_wtab);
 	HIP_TRY(hipGetLastError());
 	hipLaunchKernelGGL(k_es_cold, gw, blk, 0, st, e->d_scans, e->d_work, e->d_huff, e->d_stream, e->d_start, e->d_end[0], e->d_cnt, e->d_uni);
 	HIP_TRY(hipGetLastError());
