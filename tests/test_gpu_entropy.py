@@ -442,3 +442,37 @@ def test_gpu_walk_with_a_third_pair_of_tables(ica, oracle, gpu_ctx):
         for d, s in zip(datas, slots):
             assert np.array_equal(b.fetch(s), oracle.load(d, 3)[1]), (fmt, len(d))
         b.close()
+
+
+def test_gpu_walk_zigzag_image_form_of_the_write_pass(ica, oracle, gpu_ctx, monkeypatch):
+    """Compact planes normally come out of the write pass as a record stream (k_es_writer / k_es_pack2, round 3); an arena whose record
+    indices would not fit 32 bits -- or MIJ_ES_RECORDS=0, read when the arena is reserved -- keeps the older form (k_es_write / k_es_tails /
+    k_es_pack over a zigzag image).  Same planes, same pixels: escapes, restart intervals, straddling blocks, a third pair of tables."""
+    rng = np.random.default_rng(5)
+    datas = [ica.synth_jpeg(640, 480, 1, 90), ica.synth_jpeg(1920, 1080, 2, 90), ica.stbi_write_jpg_to_memory(rng.integers(0, 256, (211, 307, 3)).astype(np.uint8), 92),
+             helpers.third_tables(ica.synth_jpeg(333, 77, 3, 85))]
+    plan, du = ica.host_transform(ica.synth_rgb(400, 300, 4), 95)
+    datas.append(helpers.baseline_from_du(plan, du, 5, "native"))
+    planes = {}
+    for form in ("0", "1"):
+        monkeypatch.setenv("MIJ_ES_RECORDS", form)
+        b = ica.Batch(gpu_ctx, len(datas), 64 << 20, 64 << 20, 64 << 20)
+        b.entropy_reserve(16 << 20)
+        slots = []
+        for d in datas:
+            st, slot = b.add_jpeg_stream(d, 3)
+            assert st == 1, (st, b.last_reason)
+            slots.append(slot)
+        assert b.entropy_run() == []
+        planes[form] = []
+        for d, s in zip(datas, slots):
+            desc, want = ica.HostDecoder.decode(d, 3)
+            got = ica.detile_coefficients(desc, b.fetch_coef(s))
+            for ci, (pg, pw) in enumerate(zip(got, ica.detile_coefficients(desc, want))):
+                assert np.array_equal(pg, pw), (form, len(d), ci)
+            planes[form].append(got)
+        b.submit()
+        b.wait()
+        for d, s in zip(datas, slots):
+            assert np.array_equal(b.fetch(s), oracle.load(d, 3)[1]), (form, len(d))
+        b.close()
