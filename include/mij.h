@@ -297,7 +297,8 @@ typedef struct {
 	uint32_t n_seg, restart_mcus, seg_table_off, reserved;
 } mjg_scan;
 
-/* pinned + device arenas for stream_bytes of unstuffed entropy data; once per batch */
+/* pinned + device arenas for stream_bytes of unstuffed entropy data; once per batch.  Device memory: about 9 bytes per stream byte (the write
+ * pass's record arena takes 8.1 of them; streams beyond about 1 GiB per batch fall back to a form that needs 64 bytes per block instead). */
 int mij_batch_entropy_reserve(mij_batch *b, size_t stream_bytes);
 /* pinned region where the caller writes streams (capacity as reserved; reset by mij_batch_reset) */
 uint8_t *mij_batch_entropy_stage(mij_batch *b, size_t *capacity);
