@@ -476,3 +476,38 @@ def test_gpu_walk_zigzag_image_form_of_the_write_pass(ica, oracle, gpu_ctx, monk
         for d, s in zip(datas, slots):
             assert np.array_equal(b.fetch(s), oracle.load(d, 3)[1]), (form, len(d))
         b.close()
+
+
+def test_gpu_walk_densest_record_stream(ica, oracle, gpu_ctx):
+    """The record form of the write pass sizes a subsequence's region for one record per two bits of stream -- the densest a stream can be:
+    a flat picture with optimal tables spends two bits per block (a one-bit DC code for category 0, a one-bit EOB).  Such streams, with and without restart intervals, through the walk at two
+    subsequence lengths: planes == host walk,
+    pixels == oracle, nothing handed back."""
+    flat = np.full((1080, 1920, 3), 117, np.uint8)
+    plan, du = ica.host_transform(flat, 90)
+    datas = [helpers.baseline_from_du(plan, du, 0, "native"), helpers.baseline_from_du(plan, du, 64, "native")]
+    # (Blocks full of +-1 coefficients come as close to two bits per record from the other side, but a stream of near-equal symbol lengths
+    # has little for a wrong start to re-synchronise on: its chain settles a subsequence per round, and the walk -- in either form of the
+    # write pass, since round 1 -- hands such a picture back to the host after 96 rounds.  Seen while writing this test; DESIGN.md 4b.)
+    for d in datas:
+        assert oracle.load(d, 3)[0] == "ok"
+    for n_batch in (len(datas), 1):  # a batch of one picture walks with 1024-bit subsequences
+        for d in (datas if n_batch == 1 else [None]):
+            group = [d] if n_batch == 1 else datas
+            b = ica.Batch(gpu_ctx, len(group), 64 << 20, 64 << 20, 64 << 20)
+            b.entropy_reserve(8 << 20)
+            slots = []
+            for x in group:
+                st, slot = b.add_jpeg_stream(x, 3)
+                assert st == 1, (st, b.last_reason)
+                slots.append(slot)
+            assert b.entropy_run() == []
+            for x, sl in zip(group, slots):
+                desc, want = ica.HostDecoder.decode(x, 3)
+                for ci, (pg, pw) in enumerate(zip(ica.detile_coefficients(desc, b.fetch_coef(sl)), ica.detile_coefficients(desc, want))):
+                    assert np.array_equal(pg, pw), (n_batch, len(x), ci)
+            b.submit()
+            b.wait()
+            for x, sl in zip(group, slots):
+                assert np.array_equal(b.fetch(sl), oracle.load(x, 3)[1]), (n_batch, len(x))
+            b.close()
