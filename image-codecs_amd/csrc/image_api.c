@@ -218,9 +218,11 @@ static void vertical_flip(void *image, int w, int h, int bytes_per_pixel)
 static size_t gpu_walk_min_pixels(void)
 {
 	const char *e = getenv("MIJ_GPU_WALK_MIN_PIXELS");
-	/* measured per call on an MI355X box (tools/bench_single.py, profiles/r02v_single_call.json): the host walk costs 1.9 ms per
-	 * megapixel, the GPU walk of a one-picture batch 1.5-2.2 ms + 0.2 ms per megapixel: they cross between 1 and 1.3 megapixels */
-	return e ? (size_t)strtoull(e, NULL, 10) : (size_t)1280 * 1024;
+	/* measured per call on an MI355X box (tools/bench_single.py): the host walk costs 2.0 ms per megapixel; the GPU walk of a one-picture
+	 * batch took 1.5-2.2 ms + 0.2 ms per megapixel in round 2 (crossing between 1 and 1.3 megapixels: the threshold was 1280 x 1024) and takes
+	 * 0.9-1.1 ms up to a megapixel since round 3's walk: 720 x 576 0.87 against 1.03 ms, 800 x 600 1.00 against 0.93, 1024 x 768 1.59
+	 * against 1.09 (profiles/r03_single_call.json) */
+	return e ? (size_t)strtoull(e, NULL, 10) : (size_t)800 * 600;
 }
 
 /* One image through the GPU Huffman walk: NULL when the file is not a layout the walk takes, when the walk reports the

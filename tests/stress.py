@@ -143,7 +143,7 @@ def main():
                 n_cmp += 1
             b.close()
         # the one-picture path of the public API, Huffman walk on the GPU whatever the size (1024-bit subsequences)
-        os.environ["MIJ_GPU_WALK_MIN_PIXELS"] = "0" if rounds % 2 else "1310720"
+        os.environ["MIJ_GPU_WALK_MIN_PIXELS"] = "0" if rounds % 2 else "480000"
         for i in range(0, len(datas), 5):
             got = ica.stbi_load_from_memory(datas[i], req)
             kind, want, _ = wants[i]

@@ -304,7 +304,7 @@ def test_gpu_walk_is_the_default_front_end(ica, oracle, gpu_ctx, golden, monkeyp
 
 
 def test_stbi_load_from_memory_takes_the_gpu_walk_for_large_pictures(ica, oracle, gpu_ctx, golden, monkeypatch):
-    """>= 1280x1024 pixels from memory (MIJ_GPU_WALK_MIN_PIXELS): header on the host, Huffman walk + everything else on the GPU.  With the threshold
+    """>= 800x600 pixels from memory (MIJ_GPU_WALK_MIN_PIXELS): header on the host, Huffman walk + everything else on the GPU.  With the threshold
     at zero every golden stream goes through the same entry: what the GPU walk does not take or reports back falls
     through to the host walk, so results and failure reasons stay the reference's."""
     for (w, h, q) in ((512, 512, 90), (1920, 1080, 90), (800, 600, 95), (1280, 1024, 90), (2048, 1536, 85)):

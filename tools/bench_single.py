@@ -22,7 +22,8 @@ def main():
     L.stbi_image_free.argtypes = [C.c_void_p]
     x, y, c = C.c_int(), C.c_int(), C.c_int()
     out = {}
-    for (w, h) in ((256, 256), (512, 512), (1024, 768), (1024, 1024), (1920, 1080), (2048, 2048), (4096, 4096)):
+    sizes = [tuple(int(v) for v in a.split('x')) for a in sys.argv[1:]] or [(256, 256), (512, 512), (1024, 768), (1024, 1024), (1920, 1080), (2048, 2048), (4096, 4096)]
+    for (w, h) in sizes:
         data = ica.stbi_write_jpg_to_memory(ica.synth_rgb(w, h, 1), 90)
         row = {"bytes": len(data)}
         for mode, thr in (("host_walk", str(1 << 40)), ("gpu_walk", "0")):
