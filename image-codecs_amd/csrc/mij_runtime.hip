@@ -1226,6 +1226,20 @@ extern "C" int mij_batch_upload(mij_batch *b)
 		}
 		if (b->slots[i].desc.flags & MIJ_FLAG_STAGED_COMPACT) { /* compact planes written by the host stage: straight to their place, escape region only when used */
 			const Slot &sc = b->slots[i];
+			/* small pictures: a run of neighbours goes up in ONE copy, escape regions and all (unused ones carry whatever the staging arena held:
+			 * nothing reads them) -- a batch of 8192 thumbnails paid 8192 copy calls, 40 ms, where the int16 staging of round 2 went up in one */
+			const size_t small = (size_t)1 << 20;
+			if (sc.coef_bytes <= small) {
+				size_t j = i, bytes = 0;
+				while (j < n && b->slots[j].clone_of < 0 && !b->slots[j].dev_coef && !(b->slots[j].desc.flags & MIJ_FLAG_SKIP) && (b->slots[j].desc.flags & MIJ_FLAG_STAGED_COMPACT) &&
+						 b->slots[j].coef_bytes <= small && b->slots[j].stage_off == sc.stage_off + bytes && b->slots[j].coef_base == sc.coef_base + bytes) {
+					bytes += b->slots[j].coef_bytes;
+					++j;
+				}
+				HIP_TRY(hipMemcpyAsync(b->d_coef + sc.coef_base, b->stage + sc.stage_off, bytes, hipMemcpyHostToDevice, b->stream));
+				i = j;
+				continue;
+			}
 			const size_t main_bytes = mij_compact_main_bytes(&sc.desc);
 			HIP_TRY(hipMemcpyAsync(b->d_coef + sc.coef_base, b->stage + sc.stage_off, (sc.desc.flags & MIJ_FLAG_HAS_ESCAPES) ? sc.coef_bytes : main_bytes, hipMemcpyHostToDevice, b->stream));
 			++i;
