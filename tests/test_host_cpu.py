@@ -427,3 +427,19 @@ def test_progressive_refinement_without_pdep():
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", os.path.join(here, "test_host_cpu.py") + "::test_progressive_host_walk_vs_oracle_fuzz",
                         os.path.join(here, "test_progressive_writer.py")], env=env, cwd=os.path.dirname(here), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_third_pair_of_huffman_tables_host_walk(ica, oracle):
+    """A baseline file may name table ids up to 3 (codec/jpeg.c:1016-1040, :1070-1085); helpers.third_tables rewrites the writer's streams to
+    use a third DC / AC pair for the last component.  The oracle (and the reference, where present) decode them to the pixels of the
+    original stream, and the product's host walk stages the oracle's coefficients."""
+    ref = helpers.Reference() if helpers.Reference.available() else None
+    for i, (w, h, q) in enumerate(((64, 48, 90), (200, 120, 75), (333, 77, 95))):
+        base = ica.synth_jpeg(w, h, i, q)
+        data = helpers.third_tables(base)
+        kind, want, _ = oracle.load(data, 3)
+        assert kind == "ok" and np.array_equal(want, oracle.load(base, 3)[1])
+        if ref is not None:
+            assert np.array_equal(ref.load(data, 3)[1], want)
+        desc, arena = ica.HostDecoder.decode(data, 0)
+        assert np.array_equal(_dequantised_in_call_order(ica, desc, arena), oracle.coef(data)), (w, h, q)
